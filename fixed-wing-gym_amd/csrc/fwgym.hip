@@ -1,0 +1,717 @@
+// fwgym.hip -- libfwgym.so: fused HIP kernels for gfx950 (MI355X) + the C ABI declared in include/fwgym.h.
+//
+// Replaces, for a batch of N independent aircraft, the reference hot path FixedWingAircraft.step()/reset()
+// (gym_fixed_wing/fixed_wing.py:287-437) INCLUDING the simulator it calls (pyfly PyFly.step, fixed_wing.py:358).
+//
+// Mapping to the hardware: one wavefront lane = one aircraft, one 64-lane workgroup per wave so that 65 536 envs give
+// 1 024 workgroups = one wave on every SIMD of the 256 CUs.  Persistent state is SoA [field][env] in HBM (every
+// access is a 256-B coalesced row segment per wave); the un-predictable, config-driven parts (which variable feeds
+// which observation entry) are resolved through LDS tables [entry][lane] addressed with wave-uniform indices; lagged
+// observation rows and the action window stream from HBM straight into LDS (global_load_lds, no VGPR round trip)
+// while the RK4 integration runs; the [env][obs_dim] output is transposed through a padded LDS tile so that the
+// HBM writes are fully coalesced.  Everything -- action scaling, actuator + 6-DOF RK4, Dryden filter, goal/streak,
+// reward, target propagation, observation, metrics, auto-reset -- is ONE launch per env step.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include "fwgym_env.h"
+
+typedef __attribute__((address_space(1))) const void* fwg_gptr;
+typedef __attribute__((address_space(3))) void* fwg_lptr;
+
+// async HBM -> LDS copy of one SoA row segment (64 consecutive words) for this wave
+__device__ __forceinline__ void dma_row(const float* src_lane_ptr, float* lds_row) {
+    __builtin_amdgcn_global_load_lds((fwg_gptr)src_lane_ptr, (fwg_lptr)lds_row, 4, 0, 0);
+}
+// the compiler does not order LDS reads behind an in-flight global_load_lds: drain the vector-memory counter by hand
+#ifndef FWG_DMA_DRAIN
+#define FWG_DMA_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+__device__ __forceinline__ void dma_wait() {
+    FWG_DMA_DRAIN();
+    __syncthreads();
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, FWG_WAVE);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// step kernel
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool TURB>
+__global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp, const KArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const DevCfg& c = *cp;
+    const int lane = threadIdx.x;
+    const long env0 = (long)blockIdx.x * FWG_WAVE;
+    const bool valid = env0 + lane < A.N;
+    const long e = valid ? env0 + lane : A.N - 1;
+    const LdsMap M = lds_map(c.obs_dim, c.L.window, c.use_cmd_ring);
+    const fwg_layout& L = c.L;
+    const int W = L.window;
+
+    // ---- phase A: start the HBM -> LDS streams (lagged observation rows, action windows)
+    for (int r = 1; r < c.obs_length; ++r)
+        for (int j = 0; j < c.n_obs; ++j)
+            dma_row(&ROW(A.S, A.N, L.lag_ring + A.lag_slots[r] * c.n_obs + j, e), lds + M.tile + (r * c.n_obs + j) * FWG_TILE_STRIDE);
+    for (int s = 0; s < W * 3; ++s) dma_row(&ROW(A.S, A.N, L.act_ring + s, e), lds + M.aring + s * FWG_WAVE);
+    if (c.use_cmd_ring)
+        for (int s = 0; s < W * 3; ++s) dma_row(&ROW(A.S, A.N, L.cmd_ring + s, e), lds + M.cring + s * FWG_WAVE);
+    // raw actions [N][3]: three coalesced row segments, de-interleaved below (stride-3 LDS reads are conflict-free)
+    {
+        const long base = env0 * 3;
+        const long lim = A.N * 3 - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const long idx = base + i * FWG_WAVE + lane;
+            dma_row(A.actions + (idx < lim ? idx : lim), lds + M.ain + i * FWG_WAVE);
+        }
+    }
+    Env E;
+    load_env<TURB>(c, A.S, A.N, e, E);
+    dma_wait();
+
+    float raw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) raw[i] = lds[M.ain + lane * 3 + i];
+    // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        lds[M.aring + (A.slot_act * 3 + i) * FWG_WAVE + lane] = raw[i];
+        if (valid) ROW(A.S, A.N, L.act_ring + A.slot_act * 3 + i, e) = raw[i];
+    }
+
+    // ---- phase B: action scaling (fixed_wing.py:349-354,439-459) and the simulator step (fixed_wing.py:358)
+    float cmd[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        cmd[i] = raw[i];
+        if (c.scale_actions)
+            cmd[i] = (c.act_to_high[i] - c.act_to_low[i]) * (fclampf(raw[i], c.scale_low, c.scale_high) - c.scale_low) *
+                         c.inv_scale_span + c.act_to_low[i];
+    }
+    float cmd_c[3], sp[3];
+    constrain_commands(c, cmd, cmd_c, sp);
+    if (c.use_cmd_ring) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            lds[M.cring + (A.slot_act * 3 + i) * FWG_WAVE + lane] = cmd_c[i];
+            if (valid) ROW(A.S, A.N, L.cmd_ring + A.slot_act * 3 + i, e) = cmd_c[i];
+        }
+    }
+    if (c.metrics) {  // control_variation accumulator (fixed_wing.py:1109-1114)
+        if (E.steps > 0u) E.sdcmd += fabsf(cmd_c[0] - E.pcmd[0]) + fabsf(cmd_c[1] - E.pcmd[1]) + fabsf(cmd_c[2] - E.pcmd[2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) E.pcmd[i] = cmd_c[i];
+    }
+    float gust[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (TURB) dryden_output(c, E.dry, gust);
+    const int fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
+    const bool ok = fail == 0;
+    if (TURB && ok) {
+        const u4 b = philox4x32((unsigned)(A.env_base + e), E.steps, E.episode, FWG_STREAM_TURB, A.seed_lo, A.seed_hi);
+        float n[4];
+        box_muller(b, n);
+        dryden_advance(c, E.dry, n);
+    }
+
+    // ---- phase C: gym-side bookkeeping (fixed_wing.py:360-417)
+    E.steps += 1u;
+    E.sft += 1u;
+    bool done = false;
+    unsigned term = FWG_TERM_NONE;
+    if (c.steps_max > 0 && E.steps >= (unsigned)c.steps_max) { done = true; term = FWG_TERM_STEPS; }
+    fill_vars(E, lds + M.vars, lane);
+    float err[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < FWG_MAX_TARGETS; ++k)
+        if (k < c.n_targets) err[k] = target_error(c.target[k], E.tgt[k], lds[M.vars + c.target[k].var * FWG_WAVE + lane]);
+    float reward = 0.f;
+    const unsigned rec = E.steps;  // index of the record this step appends to the episode histories
+    if (ok) {
+        bool achieved_now = false, resample = false;
+        unsigned g = 0u;
+        if (c.goal_enabled) {
+            g = goal_flags(c, err);
+            goal_push(c, E, g, A.bit_goal, rec);
+            if (E.sft >= (unsigned)c.streak_req && ring_popcount(E.gring[3]) >= (unsigned)c.streak_min_count) {
+                achieved_now = !(E.flags & FWG_FLAG_GOAL_ACHIEVED);
+                E.flags |= FWG_FLAG_GOAL_ACHIEVED;
+                if (c.on_success == FWG_ON_SUCCESS_DONE) { done = true; term = FWG_TERM_SUCCESS; }
+                else if (c.on_success == FWG_ON_SUCCESS_NEW) resample = true;
+            }
+        }
+        // ---- reward (fixed_wing.py:674-774)
+        float nv[3] = {0.f, 0.f, 0.f}, sh[3] = {0.f, 0.f, 0.f};
+        for (int f = 0; f < c.n_factors; ++f) {
+            const DevFactor& F = c.factor[f];
+            float val = 0.f;
+            if (F.cls == FWG_RC_ACTION) {
+                if (F.type == FWG_RT_VALUE) val = fabsf(raw[0]) + fabsf(raw[1]) + fabsf(raw[2]);
+                else if (F.type == FWG_RT_DELTA) {
+                    if (E.steps > 1u) {
+                        const int m = (int)min(E.steps, (unsigned)F.window);
+                        for (int k = W - 2; k >= 0; --k) {
+                            if (k <= m - 2) {
+                                int s_new = A.slot_act - k; s_new += (s_new < 0) ? W : 0;
+                                int s_old = A.slot_act - k - 1; s_old += (s_old < 0) ? W : 0;
+#pragma unroll
+                                for (int i = 0; i < 3; ++i)
+                                    val += fabsf(lds[M.aring + (s_new * 3 + i) * FWG_WAVE + lane] -
+                                                 lds[M.aring + (s_old * 3 + i) * FWG_WAVE + lane]);
+                            }
+                        }
+                    }
+                } else {  // bound
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        val += raw[i] > c.act_bound_max[i] ? raw[i] - c.act_bound_max[i] : 0.f;
+                        val += raw[i] < c.act_bound_min[i] ? c.act_bound_min[i] - raw[i] : 0.f;
+                    }
+                }
+            } else if (F.cls == FWG_RC_STATE) {
+                val = (F.type == FWG_RT_VALUE) ? lds[M.vars + F.src * FWG_WAVE + lane]
+                                               : (F.src == 0 ? err[0] : (F.src == 1 ? err[1] : err[2]));
+            } else if (F.cls == FWG_RC_SUCCESS) {
+                val = achieved_now ? (F.value_is_timesteps ? (float)(c.steps_max - (int)E.steps) : F.value) : 0.f;
+            } else if (F.cls == FWG_RC_STEP) {
+                val = F.value;
+            } else {  // goal
+                if (F.type == FWG_RT_PER_STATE) {
+#pragma unroll
+                    for (int k = 0; k < FWG_MAX_TARGETS; ++k)
+                        if (k < c.n_targets && c.target[k].has_bound && ((g >> k) & 1u)) val += F.value / (float)c.n_targets;
+                } else {
+                    val = (g & 8u) ? F.value : 0.f;
+                }
+            }
+            if (F.fclass == FWG_FC_LINEAR) {
+                val = fabsf(val) * F.inv_scaling;
+                if (F.has_max) val = fminf(val, F.max);
+            } else {
+                val = val * val * F.inv_scaling;
+            }
+            val *= F.sign;
+            const int fc = F.fclass;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sh[i] += (i == fc && F.shaping) ? val : 0.f;
+                nv[i] += (i == fc && !F.shaping) ? val : 0.f;
+            }
+        }
+#pragma unroll
+        for (int fc = 0; fc < 3; ++fc) {
+            if (c.term_present[fc]) {
+                const bool prev_ok = (E.flags >> (FWG_FLAG_PREV_VALID_SHIFT + fc)) & 1u;
+                float v;
+                if (fc == FWG_FC_EXPONENTIAL) {
+                    float arg = nv[fc];
+                    if (c.reward_potential) { if (prev_ok) arg += sh[fc] - E.psh[fc]; }
+                    else arg += sh[fc];
+                    v = expf(arg) - 1.f;
+                } else {
+                    v = nv[fc];
+                    if (c.reward_potential) { if (prev_ok) v += sh[fc] - E.psh[fc]; }
+                    else v += sh[fc];
+                }
+                E.psh[fc] = sh[fc];
+                E.flags |= 1u << (FWG_FLAG_PREV_VALID_SHIFT + fc);
+                reward += c.term_weight[fc] * v;
+            }
+        }
+        // ---- target resampling / propagation (fixed_wing.py:397-404)
+        if (resample || (c.resample_every > 0 && E.sft >= (unsigned)c.resample_every))
+            sample_targets(c, A, e, E, lds + M.vars, lane, nullptr);
+        next_targets(c, E);
+#pragma unroll
+        for (int k = 0; k < FWG_MAX_TARGETS; ++k)
+            if (k < c.n_targets) err[k] = target_error(c.target[k], E.tgt[k], lds[M.vars + c.target[k].var * FWG_WAVE + lane]);
+        if (c.metrics) {  // streaming form of history["error"] (fixed_wing.py:1095-1157)
+#pragma unroll
+            for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+                if (k >= c.n_targets) continue;
+                const float lo_lim = fabsf(c.rise_low * E.e0[k]), hi_lim = fabsf(c.rise_high * E.e0[k]);
+                const float pa = fabsf(E.perr[k]), ca = fabsf(err[k]);
+                if ((E.rise[k] & 0xFFFFu) == 0xFFFFu && pa >= lo_lim && ca < lo_lim) E.rise[k] = (E.rise[k] & 0xFFFF0000u) | (rec - 1u);
+                if ((E.rise[k] >> 16) == 0xFFFFu && pa >= hi_lim && ca < hi_lim) E.rise[k] = (E.rise[k] & 0xFFFFu) | ((rec - 1u) << 16);
+                E.esum[k] += err[k]; E.eabs[k] += fabsf(err[k]);
+                E.emin[k] = fminf(E.emin[k], err[k]); E.emax[k] = fmaxf(E.emax[k], err[k]);
+                E.perr[k] = err[k];
+                if (valid) ROW(A.S, A.N, L.end_ring + A.slot_end * 3 + k, e) = err[k];
+            }
+        }
+    } else {
+        done = true;
+        reward = c.step_fail_timesteps ? (float)((int)E.steps - c.steps_max) : c.step_fail_value;
+        term = FWG_TERM_VAR0 + (unsigned)(fail - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+        if (k < c.n_targets) {
+            lds[M.tgt + k * FWG_WAVE + lane] = E.tgt[k];
+            lds[M.err + k * FWG_WAVE + lane] = err[k];
+        }
+    }
+
+    // ---- phase D: observation (fixed_wing.py:776-846)
+    build_row0(c, A, e, lane, E, lds, M, A.slot_lag, ok, A.slot_act, valid);
+    if (c.obs_length > 1 && (!ok || (int)E.steps <= (c.obs_length - 1) * c.obs_step))
+        fix_lagged_rows(c, A, e, lane, E, lds, M, ok);
+    if (c.obs_noise) add_obs_noise(c, A, e, lane, E, lds, M);
+
+    // ---- phase E: episode end -- metrics block, success reduction, terminal observation, auto-reset
+    const unsigned long long done_mask = __ballot(done && valid);
+    if (done_mask != 0ull) {
+        float red[FWG_N_REDUCE];
+#pragma unroll
+        for (int i = 0; i < FWG_N_REDUCE; ++i) red[i] = 0.f;
+        if (done && valid) {
+            const unsigned n_rec = ok ? E.steps + 1u : E.steps;  // records in the episode histories
+            float mt[FWG_N_METRICS];
+#pragma unroll
+            for (int i = 0; i < FWG_N_METRICS; ++i) mt[i] = NAN;
+            if (c.metrics) {
+#pragma unroll
+                for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+                    if (k >= c.n_targets) continue;
+                    const unsigned lo = E.rise[k] & 0xFFFFu, hi = E.rise[k] >> 16;
+                    mt[FWG_M_RISE_TIME + k] = (lo == 0xFFFFu || hi == 0xFFFFu) ? NAN : (float)lo - (float)hi;
+                    const float ext = E.e0[k] > 0.f ? E.emin[k] : E.emax[k];
+                    mt[FWG_M_OVERSHOOT + k] = (fsignf(ext) == fsignf(E.e0[k])) ? NAN : fabsf(ext / E.e0[k]);
+                    mt[FWG_M_TOTAL_ERROR + k] = E.eabs[k];
+                    mt[FWG_M_AVG_ERROR + k] = fabsf(E.e0[k]) >= 0.01f ? fabsf((E.esum[k] / (float)n_rec) / E.e0[k]) : NAN;
+                    // end_error: |mean of the last <=50 errors| from the ring
+                    const int cnt = (int)min(n_rec, (unsigned)FWG_END_WINDOW);
+                    int p = ok ? A.slot_end : A.slot_end - 1;
+                    p += (p < 0) ? FWG_END_WINDOW : 0;
+                    float s = 0.f;
+                    for (int q = 0; q < cnt; ++q) {
+                        int slot = p - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
+                        s += ROW(A.S, A.N, L.end_ring + slot * 3 + k, e);
+                    }
+                    mt[FWG_M_END_ERROR + k] = fabsf(s / (float)cnt);
+                }
+                mt[FWG_M_CONTROL_VARIATION] = E.sdcmd / (3.f * c.dt * (float)(E.steps - 1u));
+                if (c.goal_enabled) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool present = (r == 3) || (r < c.n_targets && c.target[r].has_bound);
+                        if (present) {
+                            const unsigned st = pack16_get(E.settle, r);
+                            mt[FWG_M_SETTLING_TIME + r] = st == 0xFFFFu ? NAN : (float)st;
+                            mt[FWG_M_SUCCESS + r] = st == 0xFFFFu ? 0.f : 1.f;
+                            mt[FWG_M_SUCCESS_TIME_FRAC + r] = (float)E.gcnt[r] / (float)n_rec;
+                        }
+                    }
+                }
+                if (A.metrics != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < FWG_N_METRICS; ++i) ROW(A.metrics, A.N, i, e) = mt[i];
+                }
+                red[0] = 1.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[1 + r] = mt[FWG_M_SUCCESS + r] == 1.f ? 1.f : 0.f;
+                    red[12 + r] = mt[FWG_M_SUCCESS_TIME_FRAC + r] == mt[FWG_M_SUCCESS_TIME_FRAC + r] ? mt[FWG_M_SUCCESS_TIME_FRAC + r] : 0.f;
+                }
+                red[5] = mt[FWG_M_CONTROL_VARIATION] == mt[FWG_M_CONTROL_VARIATION] ? mt[FWG_M_CONTROL_VARIATION] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    red[6 + k] = mt[FWG_M_END_ERROR + k] == mt[FWG_M_END_ERROR + k] ? mt[FWG_M_END_ERROR + k] : 0.f;
+                    red[9 + k] = mt[FWG_M_TOTAL_ERROR + k] == mt[FWG_M_TOTAL_ERROR + k] ? mt[FWG_M_TOTAL_ERROR + k] : 0.f;
+                }
+            } else {
+                red[0] = 1.f;
+            }
+        }
+        // per-wave reduction by shuffles, one atomic per value per wave (the per-GPU part of the success reduction of
+        // examples/train_rl_controller.py:51-66,80-85)
+#pragma unroll
+        for (int i = 0; i < FWG_N_REDUCE; ++i) {
+            const float s = wave_sum(red[i]);
+            if (lane == 0 && s != 0.f) atomicAdd(A.reduce + i, s);
+        }
+        __syncthreads();
+        if (A.term_obs != nullptr) write_tile(lds + M.tile, A.term_obs, env0, A.N, c.obs_dim, lane, done_mask);
+        __syncthreads();
+        if (c.auto_reset && done && valid) reset_env<TURB>(c, A, e, lane, E, lds, M, A.slot_end, A.slot_lag, A.bit_goal);
+    }
+    __syncthreads();
+
+    // ---- phase F: coalesced outputs and the state write-back
+    write_tile(lds + M.tile, A.obs, env0, A.N, c.obs_dim, lane, ~0ull);
+    if (valid) {
+        A.rew[e] = reward;
+        A.done[e] = done ? 1 : 0;
+        A.term[e] = (uint8_t)term;
+        if (A.tgt_out != nullptr) {
+#pragma unroll
+            for (int k = 0; k < FWG_MAX_TARGETS; ++k)
+                if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
+        }
+        store_env<TURB>(c, A.S, A.N, e, E);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// reset kernel
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool TURB>
+__global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ cp, const KArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const DevCfg& c = *cp;
+    const int lane = threadIdx.x;
+    const long env0 = (long)blockIdx.x * FWG_WAVE;
+    const bool valid = env0 + lane < A.N;
+    const long e = valid ? env0 + lane : A.N - 1;
+    const LdsMap M = lds_map(c.obs_dim, c.L.window, c.use_cmd_ring);
+    const bool sel = valid && (A.mask == nullptr || A.mask[e] != 0);
+    const unsigned long long sel_mask = __ballot(sel);
+    if (sel_mask == 0ull) return;
+    Env E;
+    load_env<TURB>(c, A.S, A.N, e, E);
+    if (sel) reset_env<TURB>(c, A, e, lane, E, lds, M, A.slot_end, A.slot_lag, A.bit_goal);
+    __syncthreads();
+    write_tile(lds + M.tile, A.obs, env0, A.N, c.obs_dim, lane, sel_mask);
+    if (sel) {
+        store_env<TURB>(c, A.S, A.N, e, E);
+        if (A.tgt_out != nullptr) {
+#pragma unroll
+            for (int k = 0; k < FWG_MAX_TARGETS; ++k)
+                if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
+        }
+    }
+}
+
+__global__ void k_check_nan(const float* __restrict__ a, long n, int* flag) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i] != a[i]) atomicOr(flag, 1);
+}
+
+// =====================================================================================================================
+// host side: config lowering, handle, C ABI
+// =====================================================================================================================
+static thread_local std::string g_err;
+static int fail_with(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(x)                                                                                         \
+    do {                                                                                                   \
+        hipError_t _e = (x);                                                                               \
+        if (_e != hipSuccess) return fail_with(FWG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct fwg_handle {
+    fwg_config cfg;
+    DevCfg h;
+    DevCfg* d_cfg;
+    float* d_reduce;
+    int* d_flag;
+    float* arena;
+    int64_t n_envs;
+    int64_t env_base;
+    int device;
+    uint64_t seed;
+    int64_t gstep;  // number of env steps taken so far (drives the ring slots)
+    size_t lds_bytes;
+};
+
+static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) {
+    if (c.n_actions != 3) { *why = "n_actions must be 3 (elevator, aileron, throttle)"; return -1; }
+    if (c.n_targets < 1 || c.n_targets > FWG_MAX_TARGETS) { *why = "n_targets out of range"; return -1; }
+    if (c.n_obs < 1 || c.n_obs > FWG_MAX_OBS) { *why = "n_obs out of range"; return -1; }
+    if (c.obs_length < 1 || c.obs_length > FWG_MAX_ROWS || c.obs_step < 1) { *why = "observation length/step out of range"; return -1; }
+    if (c.n_factors < 0 || c.n_factors > FWG_MAX_FACTORS) { *why = "too many reward factors"; return -1; }
+    if (c.streak_req > FWG_MAX_STREAK) { *why = "success_streak_req > 128"; return -1; }
+    if (c.steps_max >= 65535) { *why = "steps_max must be < 65535"; return -1; }
+    if (c.n_substeps < 1) { *why = "n_substeps < 1"; return -1; }
+    int window = 2;
+    int use_cmd = 0;
+    for (int j = 0; j < c.n_obs; ++j)
+        if (c.obs[j].type == FWG_OBS_ACTION) {
+            if (c.obs[j].window > window) window = c.obs[j].window;
+            if (!c.scale_actions) use_cmd = 1;
+            if (c.obs[j].src < 0 || c.obs[j].src > 2) { *why = "action observation source"; return -1; }
+        }
+    for (int f = 0; f < c.n_factors; ++f)
+        if (c.factor[f].cls == FWG_RC_ACTION && c.factor[f].type == FWG_RT_DELTA && c.factor[f].window > window)
+            window = c.factor[f].window;
+    if (window > FWG_MAX_WINDOW) { *why = "action window_size > 8"; return -1; }
+    int o = 0;
+    L->phys = o; o += NY;
+    L->wind = o; o += 3;
+    L->dryden = o; o += c.turbulence ? FWG_N_DRYDEN : 0;
+    L->derived = o; o += 6;
+    L->target = o; o += 3 + 4 * FWG_MAX_TARGETS;
+    L->counters = o; o += 4;
+    L->prev_shaping = o; o += 3;
+    L->act_ring = o; o += window * 3;
+    L->cmd_ring = o; o += use_cmd ? window * 3 : 0;
+    L->prev_cmd = o; o += 3;
+    L->goal_ring = o; o += 16;
+    L->goal_count = o; o += 4;
+    L->met = o; o += 24;
+    L->end_ring = o; o += FWG_END_WINDOW * 3;
+    L->lag_depth = c.obs_length > 1 ? (c.obs_length - 1) * c.obs_step + 1 : 0;
+    L->lag_ring = o; o += L->lag_depth * c.n_obs;
+    L->window = window;
+    L->rows = o;
+    return use_cmd;
+}
+
+static float f32(double x) { return (float)x; }
+static float lim32(double x, bool is_min) {
+    if (std::isnan(x)) return is_min ? -INFINITY : INFINITY;
+    return (float)x;
+}
+
+static int lower_config(const fwg_config& c, DevCfg* d, std::string* why) {
+    memset(d, 0, sizeof(DevCfg));
+    const int use_cmd = compute_layout(c, &d->L, why);
+    if (use_cmd < 0) return -1;
+    const double* P = c.param;
+    d->dt = f32(c.dt);
+    d->nsub = c.n_substeps;
+    const double h = c.dt / c.n_substeps;
+    d->h = f32(h); d->half_h = f32(0.5 * h); d->h_sixth = f32(h / 6.0);
+    d->turbulence = c.turbulence;
+    d->half_rho_S = f32(0.5 * c.rho * P[FWG_P_S_WING]);
+    d->mg = f32(P[FWG_P_MASS] * c.g);
+    d->inv_mass = f32(1.0 / P[FWG_P_MASS]);
+    d->inv_Jy = f32(1.0 / P[FWG_P_JY]);
+    {
+        const double Jx = P[FWG_P_JX], Jy = P[FWG_P_JY], Jz = P[FWG_P_JZ], Jxz = P[FWG_P_JXZ];
+        const double G = Jx * Jz - Jxz * Jxz;
+        d->G1 = f32(Jxz * (Jx - Jy + Jz) / G); d->G2 = f32((Jz * (Jz - Jy) + Jxz * Jxz) / G);
+        d->G3 = f32(Jz / G); d->G4 = f32(Jxz / G); d->G5 = f32((Jz - Jx) / Jy); d->G6 = f32(Jxz / Jy);
+        d->G7 = f32(((Jx - Jy) * Jx + Jxz * Jxz) / G); d->G8 = f32(Jx / G);
+    }
+    d->M = f32(P[FWG_P_M]); d->Ma0 = f32(P[FWG_P_M] * P[FWG_P_A_0]);
+    d->CL0 = f32(P[FWG_P_C_LIFT_0]); d->CLa = f32(P[FWG_P_C_LIFT_ALPHA]);
+    d->cLq = f32(P[FWG_P_C_LIFT_Q] * P[FWG_P_C]); d->CLde = f32(P[FWG_P_C_LIFT_DELTA_E]);
+    d->CDp = f32(P[FWG_P_C_D_P]); d->kInd = f32(1.0 / (M_PI * P[FWG_P_E] * P[FWG_P_AR]));
+    d->CDb1 = f32(P[FWG_P_C_D_BETA1]); d->CDb2 = f32(P[FWG_P_C_D_BETA2]);
+    d->cDq = f32(P[FWG_P_C_D_Q] * P[FWG_P_C]); d->CDde = f32(P[FWG_P_C_D_DELTA_E]);
+    d->Cm0 = f32(P[FWG_P_C_M_0]); d->Cma = f32(P[FWG_P_C_M_ALPHA]);
+    d->cmq = f32(P[FWG_P_C_M_Q] * P[FWG_P_B]); d->Cmde = f32(P[FWG_P_C_M_DELTA_E]); d->Cmfp = f32(P[FWG_P_C_M_FP]);
+    d->chord = f32(P[FWG_P_C]); d->span = f32(P[FWG_P_B]);
+    d->CY0 = f32(P[FWG_P_C_Y_0]); d->CYb = f32(P[FWG_P_C_Y_BETA]);
+    d->cYp = f32(P[FWG_P_C_Y_P] * P[FWG_P_B]); d->cYr = f32(P[FWG_P_C_Y_R] * P[FWG_P_B]); d->CYda = f32(P[FWG_P_C_Y_DELTA_A]);
+    d->Cl0 = f32(P[FWG_P_C_ROLL_0]); d->Clb = f32(P[FWG_P_C_ROLL_BETA]);
+    d->clp = f32(P[FWG_P_C_ROLL_P] * P[FWG_P_B]); d->clr = f32(P[FWG_P_C_ROLL_R] * P[FWG_P_B]); d->Clda = f32(P[FWG_P_C_ROLL_DELTA_A]);
+    d->Cn0 = f32(P[FWG_P_C_N_0]); d->Cnb = f32(P[FWG_P_C_N_BETA]);
+    d->cnp = f32(P[FWG_P_C_N_P] * P[FWG_P_B]); d->cnr = f32(P[FWG_P_C_N_R] * P[FWG_P_B]); d->Cnda = f32(P[FWG_P_C_N_DELTA_A]);
+    d->kprop = f32(0.5 * c.rho * P[FWG_P_S_PROP] * P[FWG_P_C_PROP]);
+    d->kmotor = f32(P[FWG_P_K_MOTOR]);
+    d->ktp = f32(P[FWG_P_K_T_P] * P[FWG_P_K_OMEGA] * P[FWG_P_K_OMEGA]);
+    d->con_mask = 0;
+    for (int v = 0; v < FWG_N_VARS; ++v) {
+        d->con_min[v] = lim32(c.con_min[v], true); d->con_max[v] = lim32(c.con_max[v], false);
+        d->val_min[v] = lim32(c.val_min[v], true); d->val_max[v] = lim32(c.val_max[v], false);
+        d->init_min[v] = std::isnan(c.init_min[v]) ? 0.f : f32(c.init_min[v]);
+        d->init_max[v] = std::isnan(c.init_max[v]) ? 0.f : f32(c.init_max[v]);
+        if (std::isfinite(c.con_min[v]) || std::isfinite(c.con_max[v])) d->con_mask |= 1u << v;
+    }
+    for (int i = 0; i < 2; ++i) {
+        d->w0sq[i] = f32(c.elevon_omega0[i] * c.elevon_omega0[i]);
+        d->two_zeta_w0[i] = f32(2.0 * c.elevon_zeta[i] * c.elevon_omega0[i]);
+        d->dot_max[i] = std::isfinite(c.elevon_dot_max[i]) ? f32(c.elevon_dot_max[i]) : INFINITY;
+    }
+    d->inv_tau = f32(1.0 / c.throttle_tau);
+    for (int i = 0; i < FWG_N_DRYDEN * FWG_N_DRYDEN; ++i) d->dryA[i] = f32(c.dryden_A[i]);
+    for (int i = 0; i < FWG_N_DRYDEN * 4; ++i) d->dryB[i] = f32(c.dryden_B[i]);
+    for (int i = 0; i < 6 * FWG_N_DRYDEN; ++i) d->dryC[i] = f32(c.dryden_C[i]);
+
+    d->steps_max = c.steps_max; d->obs_length = c.obs_length; d->obs_step = c.obs_step; d->n_obs = c.n_obs;
+    d->obs_dim = c.obs_length * c.n_obs;
+    d->obs_noise = c.obs_noise; d->obs_noise_mean = f32(c.obs_noise_mean); d->obs_noise_std = f32(c.obs_noise_std);
+    for (int j = 0; j < c.n_obs; ++j) {
+        const fwg_obs_desc& o = c.obs[j];
+        if (o.type == FWG_OBS_STATE && (o.src < 0 || o.src >= FWG_N_VARS)) { *why = "observation state source"; return -1; }
+        if ((o.type == FWG_OBS_TARGET_RELATIVE || o.type == FWG_OBS_TARGET_ABSOLUTE) && (o.src < 0 || o.src >= c.n_targets)) {
+            *why = "observation target source"; return -1;
+        }
+        d->obs[j] = DevObs{o.type, o.src, o.window < 1 ? 1 : o.window, (c.obs_normalize && o.norm) ? 1 : 0, f32(o.mean), f32(1.0 / o.var)};
+    }
+    d->scale_actions = c.scale_actions;
+    d->scale_low = f32(c.scale_low); d->scale_high = f32(c.scale_high);
+    d->inv_scale_span = c.scale_actions ? f32(1.0 / (c.scale_high - c.scale_low)) : 0.f;
+    for (int i = 0; i < 3; ++i) {
+        d->act_to_low[i] = f32(c.act_to_low[i]); d->act_to_high[i] = f32(c.act_to_high[i]);
+        d->inv_act_span[i] = f32(1.0 / (c.act_to_high[i] - c.act_to_low[i]));
+        d->act_bound_min[i] = c.has_action_bounds ? f32(c.act_bound_min[i]) : -INFINITY;
+        d->act_bound_max[i] = c.has_action_bounds ? f32(c.act_bound_max[i]) : INFINITY;
+    }
+    d->has_action_bounds = c.has_action_bounds;
+    d->n_targets = c.n_targets; d->resample_every = c.resample_every; d->streak_req = c.streak_req;
+    d->on_success = c.on_success; d->goal_enabled = c.streak_req > 0;
+    {   // smallest count whose float64 mean over the window reaches the fraction (np.mean(...) >= fraction)
+        int mc = 0;
+        while (mc <= c.streak_req && !((double)mc / (double)(c.streak_req > 0 ? c.streak_req : 1) >= c.streak_fraction)) ++mc;
+        d->streak_min_count = mc;
+    }
+    d->any_dynamic_target = 0;
+    for (int k = 0; k < c.n_targets; ++k) {
+        const fwg_target_desc& t = c.target[k];
+        if (t.var < 0 || t.var >= FWG_N_VARS) { *why = "target variable"; return -1; }
+        if (t.cls >= FWG_TGT_LINEAR) d->any_dynamic_target = 1;
+        if (t.cls == FWG_TGT_COMPENSATE && t.var != FWG_V_VA) { *why = "class compensate is only defined for Va"; return -1; }
+        d->target[k] = DevTarget{t.var, t.cls, t.wrap, t.has_delta, t.has_bound, f32(t.low), f32(t.high), f32(t.delta), f32(t.bound),
+                                 f32(t.slope_low), f32(t.slope_high), f32(t.amplitude_low), f32(t.amplitude_high),
+                                 f32(t.period_low), f32(t.period_high)};
+    }
+    d->reward_potential = c.reward_potential; d->step_fail_timesteps = c.step_fail_timesteps;
+    d->step_fail_value = f32(c.step_fail_value);
+    for (int i = 0; i < 3; ++i) { d->term_present[i] = c.term_present[i]; d->term_weight[i] = f32(c.term_weight[i]); }
+    d->n_factors = c.n_factors;
+    for (int f = 0; f < c.n_factors; ++f) {
+        const fwg_factor_desc& F = c.factor[f];
+        if (F.fclass < 0 || F.fclass > 2 || !c.term_present[F.fclass]) { *why = "reward factor without a matching term"; return -1; }
+        if (F.cls == FWG_RC_ACTION && F.type == FWG_RT_BOUND && !c.has_action_bounds) { *why = "action bound factor needs bounds_multiplier"; return -1; }
+        d->factor[f] = DevFactor{F.cls, F.type, F.src, F.fclass, F.shaping, F.window < 1 ? 1 : F.window, F.has_max,
+                                 F.value_is_timesteps, f32(F.sign > 0 ? 1.0 : (F.sign < 0 ? -1.0 : 0.0)), f32(1.0 / F.scaling),
+                                 f32(F.max), f32(F.value)};
+    }
+    d->metrics = c.metrics; d->auto_reset = c.auto_reset; d->use_cmd_ring = use_cmd;
+    d->rise_low = f32(c.rise_low); d->rise_high = f32(c.rise_high);
+    return 0;
+}
+
+extern "C" {
+
+int fwg_abi_version(void) { return FWG_ABI_VERSION; }
+const char* fwg_last_error(void) { return g_err.c_str(); }
+
+int fwg_get_layout(const fwg_config* cfg, fwg_layout* out) {
+    if (!cfg || !out) return fail_with(FWG_ERR_INVALID, "null argument");
+    if (cfg->abi_version != FWG_ABI_VERSION || cfg->struct_bytes != sizeof(fwg_config))
+        return fail_with(FWG_ERR_ABI, "fwg_config version/size mismatch");
+    std::string why;
+    if (compute_layout(*cfg, out, &why) < 0) return fail_with(FWG_ERR_INVALID, why);
+    return FWG_OK;
+}
+
+int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_arena, int64_t env_id_base, fwg_handle** out) {
+    if (!cfg || !out || !state_arena || n_envs < 1) return fail_with(FWG_ERR_INVALID, "null/invalid argument");
+    if (cfg->abi_version != FWG_ABI_VERSION || cfg->struct_bytes != sizeof(fwg_config))
+        return fail_with(FWG_ERR_ABI, "fwg_config version/size mismatch");
+    fwg_handle* h = new fwg_handle();
+    h->cfg = *cfg;
+    std::string why;
+    if (lower_config(*cfg, &h->h, &why) != 0) { delete h; return fail_with(FWG_ERR_INVALID, why); }
+    h->n_envs = n_envs; h->env_base = env_id_base; h->device = device; h->seed = 0; h->gstep = 0;
+    h->arena = (float*)state_arena;
+    const LdsMap M = lds_map(h->h.obs_dim, h->h.L.window, h->h.use_cmd_ring);
+    h->lds_bytes = (size_t)M.total * sizeof(float);
+    if (h->lds_bytes > 64 * 1024) { delete h; return fail_with(FWG_ERR_INVALID, "observation too large for the LDS tile"); }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc((void**)&h->d_cfg, sizeof(DevCfg)));
+    HIP_TRY(hipMalloc((void**)&h->d_reduce, sizeof(float) * FWG_N_REDUCE));
+    HIP_TRY(hipMalloc((void**)&h->d_flag, sizeof(int)));
+    HIP_TRY(hipMemcpy(h->d_cfg, &h->h, sizeof(DevCfg), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->d_reduce, 0, sizeof(float) * FWG_N_REDUCE));
+    HIP_TRY(hipMemset(h->d_flag, 0, sizeof(int)));
+    *out = h;
+    return FWG_OK;
+}
+
+int fwg_destroy(fwg_handle* h) {
+    if (!h) return FWG_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->d_cfg); (void)hipFree(h->d_reduce); (void)hipFree(h->d_flag);
+    delete h;
+    return FWG_OK;
+}
+
+int fwg_update_config(fwg_handle* h, const fwg_config* cfg) {
+    if (!h || !cfg) return fail_with(FWG_ERR_INVALID, "null argument");
+    if (cfg->abi_version != FWG_ABI_VERSION || cfg->struct_bytes != sizeof(fwg_config))
+        return fail_with(FWG_ERR_ABI, "fwg_config version/size mismatch");
+    DevCfg d;
+    std::string why;
+    if (lower_config(*cfg, &d, &why) != 0) return fail_with(FWG_ERR_INVALID, why);
+    if (memcmp(&d.L, &h->h.L, sizeof(fwg_layout)) != 0 || d.obs_dim != h->h.obs_dim)
+        return fail_with(FWG_ERR_INVALID, "fwg_update_config must not change the state layout");
+    h->cfg = *cfg; h->h = d;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(h->d_cfg, &h->h, sizeof(DevCfg), hipMemcpyHostToDevice));
+    return FWG_OK;
+}
+
+int fwg_seed(fwg_handle* h, uint64_t seed) {
+    if (!h) return fail_with(FWG_ERR_INVALID, "null handle");
+    h->seed = seed;
+    return FWG_OK;
+}
+
+int64_t fwg_global_step(const fwg_handle* h) { return h ? h->gstep : -1; }
+
+static inline int pmod(int64_t a, int m) { return m > 0 ? (int)(((a % m) + m) % m) : 0; }
+
+static void fill_slots(const fwg_handle* h, int64_t g, KArgs* A) {
+    const DevCfg& d = h->h;
+    A->slot_act = pmod(g, d.L.window);
+    A->slot_end = pmod(g, FWG_END_WINDOW);
+    A->slot_lag = pmod(g, d.L.lag_depth);
+    A->bit_goal = pmod(g, d.streak_req);
+    for (int r = 0; r < FWG_MAX_ROWS; ++r) A->lag_slots[r] = pmod(g - (int64_t)r * d.obs_step, d.L.lag_depth);
+}
+
+static void base_args(const fwg_handle* h, KArgs* A) {
+    memset(A, 0, sizeof(KArgs));
+    A->S = h->arena; A->N = h->n_envs; A->env_base = h->env_base; A->reduce = h->d_reduce;
+    A->seed_lo = (unsigned)(h->seed & 0xFFFFFFFFull); A->seed_hi = (unsigned)(h->seed >> 32);
+}
+
+int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const float* init_target, float* obs_out, void* stream) {
+    if (!h || !obs_out) return fail_with(FWG_ERR_INVALID, "null argument");
+    KArgs A;
+    base_args(h, &A);
+    A.mask = mask; A.init_state = init_state; A.init_target = init_target; A.obs = obs_out;
+    fill_slots(h, h->gstep - 1, &A);  // initial records take the ring position of the last completed step
+    const dim3 grid((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), block(FWG_WAVE);
+    if (h->h.turbulence) hipLaunchKernelGGL(k_reset<true>, grid, block, h->lds_bytes, (hipStream_t)stream, h->d_cfg, A);
+    else hipLaunchKernelGGL(k_reset<false>, grid, block, h->lds_bytes, (hipStream_t)stream, h->d_cfg, A);
+    HIP_TRY(hipGetLastError());
+    return FWG_OK;
+}
+
+int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_out, uint8_t* done_out, uint8_t* term_code_out,
+             float* terminal_obs_out, float* metrics_out, float* target_out, void* stream) {
+    if (!h || !actions || !obs_out || !reward_out || !done_out || !term_code_out) return fail_with(FWG_ERR_INVALID, "null argument");
+    KArgs A;
+    base_args(h, &A);
+    A.actions = actions; A.obs = obs_out; A.rew = reward_out; A.done = done_out; A.term = term_code_out;
+    A.term_obs = terminal_obs_out; A.metrics = metrics_out; A.tgt_out = target_out;
+    fill_slots(h, h->gstep, &A);
+    const dim3 grid((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), block(FWG_WAVE);
+    if (h->h.turbulence) hipLaunchKernelGGL(k_step<true>, grid, block, h->lds_bytes, (hipStream_t)stream, h->d_cfg, A);
+    else hipLaunchKernelGGL(k_step<false>, grid, block, h->lds_bytes, (hipStream_t)stream, h->d_cfg, A);
+    HIP_TRY(hipGetLastError());
+    h->gstep += 1;
+    return FWG_OK;
+}
+
+int fwg_check_actions(fwg_handle* h, const float* actions, void* stream) {
+    if (!h || !actions) return fail_with(FWG_ERR_INVALID, "null argument");
+    const long n = (long)h->n_envs * 3;
+    HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_check_nan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, actions, n, h->d_flag);
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (flag) return fail_with(FWG_ERR_NAN_ACTION, "NaN in actions");
+    return FWG_OK;
+}
+
+int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream) {
+    if (!h || !out_host) return fail_with(FWG_ERR_INVALID, "null argument");
+    HIP_TRY(hipMemcpyAsync(out_host, h->d_reduce, sizeof(float) * FWG_N_REDUCE, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(h->d_reduce, 0, sizeof(float) * FWG_N_REDUCE, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return FWG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// fwgym_dev.h -- device-side constant block and small math helpers for the gfx950 kernels (internal, not ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fwgym.h"
+
+#define FWG_WAVE 64
+#define FWG_TILE_STRIDE 65  // LDS row stride (words) of the [entry][lane] tiles: (k + lane) % 32 banks, conflict-free
+
+// flags word (counters row 2)
+#define FWG_FLAG_GOAL_ACHIEVED 1u        // sticky for the env's lifetime (fixed_wing.py:51,381-382)
+#define FWG_FLAG_PREV_VALID_SHIFT 1      // bits 1..3: prev_shaping[fclass] is not None (fixed_wing.py:327-328,756,765)
+#define FWG_FLAG_RESAMPLE_SHIFT 8        // bits 8..31: target resample counter inside the episode (RNG sub-stream)
+
+// Philox stream ids (shared with oracle/physics.py)
+#define FWG_STREAM_TURB 1u
+#define FWG_STREAM_RESET_STATE 2u
+#define FWG_STREAM_RESET_TARGET 3u
+#define FWG_STREAM_OBS_NOISE 4u
+#define FWG_STREAM_INIT_NOISE 5u
+
+struct DevObs { int type, src, window, norm; float mean, inv_var; };
+struct DevTarget {
+    int var, cls, wrap, has_delta, has_bound;
+    float low, high, delta, bound, slope_low, slope_high, amp_low, amp_high, period_low, period_high;
+};
+struct DevFactor { int cls, type, src, fclass, shaping, window, has_max, value_is_timesteps; float sign, inv_scaling, max, value; };
+
+struct DevCfg {
+    // ---- simulator, pre-combined in double on the host
+    float dt, h, half_h, h_sixth;
+    int nsub, turbulence;
+    float half_rho_S, mg, inv_mass, inv_Jy;
+    float G1, G2, G3, G4, G5, G6, G7, G8;
+    float M, Ma0;
+    float CL0, CLa, cLq, CLde;
+    float CDp, kInd, CDb1, CDb2, cDq, CDde;
+    float Cm0, Cma, cmq, Cmde, Cmfp, chord, span;
+    float CY0, CYb, cYp, cYr, CYda;
+    float Cl0, Clb, clp, clr, Clda;
+    float Cn0, Cnb, cnp, cnr, Cnda;
+    float kprop, kmotor, ktp;
+    float con_min[FWG_N_VARS], con_max[FWG_N_VARS];
+    float val_min[FWG_N_VARS], val_max[FWG_N_VARS];
+    float init_min[FWG_N_VARS], init_max[FWG_N_VARS];
+    unsigned con_mask;  // bit v set when variable v has a constraint
+    float w0sq[2], two_zeta_w0[2], dot_max[2], inv_tau;
+    float dryA[FWG_N_DRYDEN * FWG_N_DRYDEN], dryB[FWG_N_DRYDEN * 4], dryC[6 * FWG_N_DRYDEN];
+    // ---- gym side
+    int steps_max, obs_length, obs_step, n_obs, obs_dim, obs_noise;
+    float obs_noise_mean, obs_noise_std;
+    DevObs obs[FWG_MAX_OBS];
+    int scale_actions;
+    float scale_low, scale_high, inv_scale_span;
+    float act_to_low[3], act_to_high[3], inv_act_span[3];
+    int has_action_bounds;
+    float act_bound_min[3], act_bound_max[3];
+    int n_targets, resample_every, streak_req, streak_min_count, on_success, goal_enabled, any_dynamic_target;
+    DevTarget target[FWG_MAX_TARGETS];
+    int reward_potential, step_fail_timesteps;
+    float step_fail_value;
+    int term_present[3];
+    float term_weight[3];
+    int n_factors;
+    DevFactor factor[FWG_MAX_FACTORS];
+    int metrics, auto_reset, use_cmd_ring;
+    float rise_low, rise_high;
+    fwg_layout L;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// math helpers (fp32, gfx950)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fclampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ float fsignf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+#define FWG_PI 3.14159265358979323846f
+#define FWG_TWO_PI 6.28318530717958647692f
+#define FWG_INV_TWO_PI 0.15915494309189533577f
+
+// Python's float modulo by 2*pi followed by the fold of fixed_wing.py:910-912 (value - target for wrap states)
+__device__ __forceinline__ float angle_dist(float target, float value) {
+    float x = value - target + FWG_PI;
+    float m = x - FWG_TWO_PI * floorf(x * FWG_INV_TWO_PI);
+    // guard the fp32 edge where rounding leaves m outside [0, 2pi)
+    m = m < 0.f ? m + FWG_TWO_PI : (m >= FWG_TWO_PI ? m - FWG_TWO_PI : m);
+    float d = m - FWG_PI;
+    return d < -FWG_PI ? d + FWG_TWO_PI : d;
+}
+
+// sign(x)*(|x| % pi - pi) for |x| > pi (fixed_wing.py:988-989)
+__device__ __forceinline__ float wrap_target(float x) {
+    float ax = fabsf(x);
+    if (ax > FWG_PI) {
+        float m = ax - FWG_PI * floorf(ax * (1.0f / FWG_PI));
+        x = fsignf(x) * (m - FWG_PI);
+    }
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al.), ctr = (env_id, counter, sub, stream), key = seed
+// ---------------------------------------------------------------------------------------------------------------------
+struct u4 { unsigned x, y, z, w; };
+__device__ __forceinline__ u4 philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }

@@ -1,0 +1,248 @@
+// fwgym_physics.h -- 6-DOF rigid-body + actuator right-hand side, RK4 sub-stepping, Dryden filter (device, fp32).
+// Specification: oracle/physics.py (float64).  One lane = one aircraft; every value below lives in VGPRs, the constants
+// of DevCfg are wave-uniform scalar loads.
+#pragma once
+#include "fwgym_dev.h"
+
+#define NY 18  // e0 e1 e2 e3 | p q r | pn pe pd | u v w | elevon_r elevon_l throttle | elevon_r_dot elevon_l_dot
+
+struct Air { float Va, alpha, beta, ua, va, wa; };
+
+// v_ned = R v_body
+struct Rot { float r00, r01, r02, r10, r11, r12, r20, r21, r22; };
+__device__ __forceinline__ Rot rot_from_quat(float e0, float e1, float e2, float e3) {
+    Rot R;
+    const float e00 = e0 * e0, e11 = e1 * e1, e22 = e2 * e2, e33 = e3 * e3;
+    R.r00 = e00 + e11 - e22 - e33; R.r01 = 2.f * (e1 * e2 - e0 * e3); R.r02 = 2.f * (e1 * e3 + e0 * e2);
+    R.r10 = 2.f * (e1 * e2 + e0 * e3); R.r11 = e00 - e11 + e22 - e33; R.r12 = 2.f * (e2 * e3 - e0 * e1);
+    R.r20 = 2.f * (e1 * e3 - e0 * e2); R.r21 = 2.f * (e2 * e3 + e0 * e1); R.r22 = e00 - e11 - e22 + e33;
+    return R;
+}
+
+template <bool TURB>
+__device__ __forceinline__ Air airspeed(const Rot& R, float u, float v, float w, const float* wind, const float* gust) {
+    Air a;
+    a.ua = u - (R.r00 * wind[0] + R.r10 * wind[1] + R.r20 * wind[2]);
+    a.va = v - (R.r01 * wind[0] + R.r11 * wind[1] + R.r21 * wind[2]);
+    a.wa = w - (R.r02 * wind[0] + R.r12 * wind[1] + R.r22 * wind[2]);
+    if (TURB) { a.ua -= gust[0]; a.va -= gust[1]; a.wa -= gust[2]; }
+    const float v2 = fmaxf(a.ua * a.ua + a.va * a.va + a.wa * a.wa, 1e-30f);
+    const float rv = frsq(v2);
+    a.Va = v2 * rv;
+    a.alpha = atan2f(a.wa, a.ua);
+    a.beta = asinf(fclampf(a.va * rv, -1.f, 1.f));
+    return a;
+}
+
+__device__ __forceinline__ void check_var(const DevCfg& c, int& fail, int var, float x) {
+    if (c.con_mask & (1u << var)) {
+        const bool bad = (x < c.con_min[var]) | (x > c.con_max[var]);
+        fail = (fail == 0 && bad) ? var + 1 : fail;
+    }
+}
+
+template <bool TURB>
+__device__ __forceinline__ void rhs(const DevCfg& c, const float (&y)[NY], const float (&sp)[3], const float (&wind)[3],
+                                    const float (&gust)[6], float (&dy)[NY], int& fail) {
+    const float e0 = y[0], e1 = y[1], e2 = y[2], e3 = y[3];
+    const float p = y[4], q = y[5], r = y[6];
+    const float u = y[10], v = y[11], w = y[12];
+    if (c.con_mask & 0xFF8u) {  // omega_p .. velocity_w
+#pragma unroll
+        for (int k = 0; k < 9; ++k) check_var(c, fail, FWG_V_OMEGA_P + k, y[4 + k]);
+    }
+    // actuator states as the model sees them: value and rate limits applied on read
+    const float er = fclampf(y[13], c.val_min[FWG_V_ELEVON_RIGHT], c.val_max[FWG_V_ELEVON_RIGHT]);
+    const float el = fclampf(y[14], c.val_min[FWG_V_ELEVON_LEFT], c.val_max[FWG_V_ELEVON_LEFT]);
+    const float th = fclampf(y[15], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
+    const float erd = fclampf(y[16], -c.dot_max[0], c.dot_max[0]);
+    const float eld = fclampf(y[17], -c.dot_max[1], c.dot_max[1]);
+    const float elev = 0.5f * (er + el), ail = 0.5f * (el - er);
+
+    const Rot R = rot_from_quat(e0, e1, e2, e3);
+    const Air a = airspeed<TURB>(R, u, v, w, wind, gust);
+    if (c.con_mask & 0x7000u) {
+        check_var(c, fail, FWG_V_VA, a.Va);
+        check_var(c, fail, FWG_V_ALPHA, a.alpha);
+        check_var(c, fail, FWG_V_BETA, a.beta);
+    }
+    const float Va = fclampf(a.Va, c.val_min[FWG_V_VA], c.val_max[FWG_V_VA]);
+    float pa = p, qa = q, ra = r;
+    if (TURB) { pa -= gust[3]; qa -= gust[4]; ra -= gust[5]; }
+
+    // direction cosines of the airspeed vector (no trigonometry needed)
+    const float v2 = fmaxf(a.ua * a.ua + a.va * a.va + a.wa * a.wa, 1e-30f);
+    const float xz2 = fmaxf(a.ua * a.ua + a.wa * a.wa, 1e-30f);
+    const float rv = frsq(v2), rxz = frsq(xz2);
+    const float ca = a.ua * rxz, sa = a.wa * rxz, sb = a.va * rv, cb = xz2 * rxz * rv;
+
+    const float pre = c.half_rho_S * Va * Va;
+    const float i2v = 0.5f * frcp(Va);
+    // stall blend: 1 - sigma = 1/((1+exp(M(a-a0)))(1+exp(-M(a+a0))))  (overflow-safe form of the published sigma)
+    const float ex1 = __expf(c.M * a.alpha - c.Ma0), ex2 = __expf(-c.M * a.alpha - c.Ma0);
+    const float oms = frcp((1.f + ex1) * (1.f + ex2));
+    const float sig = 1.f - oms;
+    const float sgn = fsignf(a.alpha);
+    const float sa2 = sa * sa;
+    const float CLlin = c.CL0 + c.CLa * a.alpha;
+    const float CL = oms * CLlin + sig * (2.f * sgn * sa2 * ca);
+    const float lift = pre * (CL + c.cLq * i2v * qa + c.CLde * elev);
+    const float CD = c.CDp + oms * CLlin * CLlin * c.kInd + sig * (2.f * sgn * sa2 * sa);
+    const float CDb = (c.CDb1 + c.CDb2 * a.beta) * a.beta;
+    const float drag = pre * (CD + CDb + c.cDq * i2v * qa + c.CDde * elev * elev);
+    const float Cm = oms * (c.Cm0 + c.Cma * a.alpha) + sig * (c.Cmfp * sgn * sa2);
+    const float m_ = pre * c.chord * (Cm + c.cmq * i2v * qa + c.Cmde * elev);
+    const float fy_s = pre * (c.CY0 + c.CYb * a.beta + i2v * (c.cYp * pa + c.cYr * ra) + c.CYda * ail);
+    const float l_ = pre * c.span * (c.Cl0 + c.Clb * a.beta + i2v * (c.clp * pa + c.clr * ra) + c.Clda * ail)
+                     - c.ktp * th * th;
+    const float n_ = pre * c.span * (c.Cn0 + c.Cnb * a.beta + i2v * (c.cnp * pa + c.cnr * ra) + c.Cnda * ail);
+
+    // wind axes -> body axes
+    const float fxa = -ca * cb * drag - ca * sb * fy_s + sa * lift;
+    const float fya = -sb * drag + cb * fy_s;
+    const float fza = -sa * cb * drag - sa * sb * fy_s - ca * lift;
+    const float Vd = Va + th * (c.kmotor - Va);
+    const float fprop = c.kprop * Vd * (Vd - Va);
+    const float fx = fprop + c.mg * 2.f * (e1 * e3 - e2 * e0) + fxa;
+    const float fy = c.mg * 2.f * (e2 * e3 + e1 * e0) + fya;
+    const float fz = c.mg * (e3 * e3 + e0 * e0 - e1 * e1 - e2 * e2) + fza;
+
+    dy[0] = 0.5f * (-p * e1 - q * e2 - r * e3);
+    dy[1] = 0.5f * (p * e0 + r * e2 - q * e3);
+    dy[2] = 0.5f * (q * e0 - r * e1 + p * e3);
+    dy[3] = 0.5f * (r * e0 + q * e1 - p * e2);
+    dy[4] = c.G1 * p * q - c.G2 * q * r + c.G3 * l_ + c.G4 * n_;
+    dy[5] = c.G5 * p * r - c.G6 * (p * p - r * r) + m_ * c.inv_Jy;
+    dy[6] = c.G7 * p * q - c.G1 * q * r + c.G4 * l_ + c.G8 * n_;
+    dy[7] = R.r00 * u + R.r01 * v + R.r02 * w;
+    dy[8] = R.r10 * u + R.r11 * v + R.r12 * w;
+    dy[9] = R.r20 * u + R.r21 * v + R.r22 * w;
+    dy[10] = r * v - q * w + fx * c.inv_mass;
+    dy[11] = p * w - r * u + fy * c.inv_mass;
+    dy[12] = q * u - p * v + fz * c.inv_mass;
+    dy[13] = erd;
+    dy[14] = eld;
+    dy[15] = (sp[2] - th) * c.inv_tau;
+    dy[16] = c.w0sq[0] * (sp[0] - er) - c.two_zeta_w0[0] * erd;
+    dy[17] = c.w0sq[1] * (sp[1] - el) - c.two_zeta_w0[1] * eld;
+}
+
+__device__ __forceinline__ void sanitize_actuators(const DevCfg& c, float (&y)[NY]) {
+    y[13] = fclampf(y[13], c.val_min[FWG_V_ELEVON_RIGHT], c.val_max[FWG_V_ELEVON_RIGHT]);
+    y[14] = fclampf(y[14], c.val_min[FWG_V_ELEVON_LEFT], c.val_max[FWG_V_ELEVON_LEFT]);
+    y[15] = fclampf(y[15], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
+    y[16] = fclampf(y[16], -c.dot_max[0], c.dot_max[0]);
+    y[17] = fclampf(y[17], -c.dot_max[1], c.dot_max[1]);
+}
+
+// elevator/aileron/throttle commands -> constrained inputs (the "command" history of the reference,
+// fixed_wing.py:828,1110) and the elevon/throttle set-points of the actuator dynamics
+__device__ __forceinline__ void constrain_commands(const DevCfg& c, const float (&cmd)[3], float (&cmd_c)[3], float (&sp)[3]) {
+    const float e = fclampf(cmd[0], c.val_min[FWG_V_ELEVATOR], c.val_max[FWG_V_ELEVATOR]);
+    const float a = fclampf(cmd[1], c.val_min[FWG_V_AILERON], c.val_max[FWG_V_AILERON]);
+    const float t = fclampf(cmd[2], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
+    const float er = fclampf(e - a, c.val_min[FWG_V_ELEVON_RIGHT], c.val_max[FWG_V_ELEVON_RIGHT]);
+    const float el = fclampf(e + a, c.val_min[FWG_V_ELEVON_LEFT], c.val_max[FWG_V_ELEVON_LEFT]);
+    cmd_c[0] = 0.5f * (er + el); cmd_c[1] = 0.5f * (el - er); cmd_c[2] = t;
+    sp[0] = er; sp[1] = el; sp[2] = t;
+}
+
+struct Derived { float roll, pitch, yaw, Va, alpha, beta; };
+
+template <bool TURB>
+__device__ __forceinline__ Derived derive(const float (&y)[NY], const float (&wind)[3], const float (&gust)[6]) {
+    Derived d;
+    const float e0 = y[0], e1 = y[1], e2 = y[2], e3 = y[3];
+    d.roll = atan2f(2.f * (e0 * e1 + e2 * e3), e0 * e0 + e3 * e3 - e1 * e1 - e2 * e2);
+    d.pitch = asinf(fclampf(2.f * (e0 * e2 - e1 * e3), -1.f, 1.f));
+    d.yaw = atan2f(2.f * (e0 * e3 + e1 * e2), e0 * e0 + e1 * e1 - e2 * e2 - e3 * e3);
+    const Rot R = rot_from_quat(e0, e1, e2, e3);
+    const Air a = airspeed<TURB>(R, y[10], y[11], y[12], wind, gust);
+    d.Va = a.Va; d.alpha = a.alpha; d.beta = a.beta;
+    return d;
+}
+
+#ifndef FWG_STAGE_UNROLL
+#define FWG_STAGE_UNROLL 1
+#endif
+
+// One env step (dt): classical RK4 with c.nsub sub-steps; on success y holds the new state, otherwise y is
+// untouched.  Returns the failure code (0 = ok, var+1 = violated constraint, FWG_TERM_NAN+1 = non-finite).
+template <bool TURB>
+__device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const float (&sp)[3], const float (&wind)[3],
+                                        const float (&gust)[6], Derived& d) {
+    float yy[NY];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) yy[i] = y[i];
+    int fail = 0;
+    for (int s = 0; s < c.nsub; ++s) {
+        float acc[NY], ys[NY], k[NY];
+#pragma unroll
+        for (int i = 0; i < NY; ++i) { acc[i] = 0.f; ys[i] = yy[i]; }
+#pragma unroll FWG_STAGE_UNROLL
+        for (int st = 0; st < 4; ++st) {
+            rhs<TURB>(c, ys, sp, wind, gust, k, fail);
+            const float bw = (st == 0 || st == 3) ? c.h_sixth : 2.f * c.h_sixth;
+            const float aw = (st == 2) ? c.h : c.half_h;
+#pragma unroll
+            for (int i = 0; i < NY; ++i) { acc[i] += bw * k[i]; ys[i] = yy[i] + aw * k[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NY; ++i) yy[i] += acc[i];
+        sanitize_actuators(c, yy);
+    }
+    const float rn = frsq(yy[0] * yy[0] + yy[1] * yy[1] + yy[2] * yy[2] + yy[3] * yy[3]);
+    yy[0] *= rn; yy[1] *= rn; yy[2] *= rn; yy[3] *= rn;
+    if (c.con_mask & 0xFF8u) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) check_var(c, fail, FWG_V_OMEGA_P + k, yy[4 + k]);
+    }
+    const Derived dn = derive<TURB>(yy, wind, gust);
+    if (c.con_mask & 0x7007u) {
+        check_var(c, fail, FWG_V_ROLL, dn.roll); check_var(c, fail, FWG_V_PITCH, dn.pitch);
+        check_var(c, fail, FWG_V_YAW, dn.yaw); check_var(c, fail, FWG_V_VA, dn.Va);
+        check_var(c, fail, FWG_V_ALPHA, dn.alpha); check_var(c, fail, FWG_V_BETA, dn.beta);
+    }
+    float chk = 0.f;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) chk += yy[i] * 0.f;  // NaN/Inf propagate into chk
+    if (fail == 0 && !(chk == 0.f)) fail = FWG_TERM_NAN - FWG_TERM_VAR0 + 1;
+    if (fail == 0) {
+#pragma unroll
+        for (int i = 0; i < NY; ++i) y[i] = yy[i];
+        d = dn;
+    }
+    return fail;
+}
+
+// Dryden: gust sample of the current step = C x ; advance x' = A x + B n with 4 standard normals
+__device__ __forceinline__ void dryden_output(const DevCfg& c, const float (&x)[FWG_N_DRYDEN], float (&gust)[6]) {
+#pragma unroll
+    for (int o = 0; o < 6; ++o) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < FWG_N_DRYDEN; ++j) s += c.dryC[o * FWG_N_DRYDEN + j] * x[j];
+        gust[o] = s;
+    }
+}
+__device__ __forceinline__ void dryden_advance(const DevCfg& c, float (&x)[FWG_N_DRYDEN], const float (&n)[4]) {
+    float xn[FWG_N_DRYDEN];
+#pragma unroll
+    for (int i = 0; i < FWG_N_DRYDEN; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < FWG_N_DRYDEN; ++j) s += c.dryA[i * FWG_N_DRYDEN + j] * x[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += c.dryB[i * 4 + j] * n[j];
+        xn[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < FWG_N_DRYDEN; ++i) x[i] = xn[i];
+}
+__device__ __forceinline__ void box_muller(const u4& b, float (&n)[4]) {
+    const float r0 = sqrtf(-2.f * logf(u01(b.x))), r1 = sqrtf(-2.f * logf(u01(b.z)));
+    float s0, c0, s1, c1;
+    sincosf(FWG_TWO_PI * u01(b.y), &s0, &c0);
+    sincosf(FWG_TWO_PI * u01(b.w), &s1, &c1);
+    n[0] = r0 * c0; n[1] = r0 * s0; n[2] = r1 * c1; n[3] = r1 * s1;
+}

@@ -1,0 +1,356 @@
+"""FixedWingVecEnv -- N fixed-wing environments stepped by ONE fused HIP kernel launch on one MI355X.
+
+This is the batched replacement for what the reference runs as `SubprocVecEnv([make_env(...) for i in range(n)])`
+(examples/train_rl_controller.py:223, examples/evaluate_controller.py:80): every env is still the reference's
+FixedWingAircraft (same config schema, same step/reset semantics), but all of them live in one SoA state arena in HBM
+and one `fwg_step` call advances them all.  The class honours the stable-baselines VecEnv contract the example scripts
+rely on (reset/step/step_async/step_wait/seed/get_attr/set_attr/env_method/close, auto-reset with
+info["terminal_observation"], per-episode metric entries in info at done).
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _native as nat
+from .config import EnvConfig
+from .spaces import Box
+
+
+class _TorchBackend(object):
+    """Device memory and streams come from PyTorch-ROCm (plumbing only)."""
+
+    def __init__(self, device):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise nat.NativeError("no ROCm device visible to PyTorch: FixedWingVecEnv needs an MI355X (no CPU fallback)")
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._dt = {"f32": torch.float32, "u8": torch.uint8, "i32": torch.int32}
+
+    def zeros(self, shape, kind="f32"):
+        return self.torch.zeros(shape, dtype=self._dt[kind], device=self.device)
+
+    def full(self, shape, value, kind="f32"):
+        return self.torch.full(shape, value, dtype=self._dt[kind], device=self.device)
+
+    def ptr(self, t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def sync(self):
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+    def to_host(self, t):
+        return t.detach().cpu().numpy()
+
+    def from_host(self, a, kind="f32"):
+        return self.torch.as_tensor(np.ascontiguousarray(a), dtype=self._dt[kind]).to(self.device)
+
+    def as_device(self, x, kind="f32"):
+        if isinstance(x, self.torch.Tensor):
+            if x.device != self.device or x.dtype != self._dt[kind] or not x.is_contiguous():
+                x = x.to(device=self.device, dtype=self._dt[kind]).contiguous()
+            return x
+        return self.from_host(np.asarray(x, dtype=np.float32), kind)
+
+    def view_i32(self, t):
+        return t.view(self.torch.int32)
+
+
+class LazyInfos(object):
+    """The `infos` list of VecEnv.step_wait: dicts are materialised on first access (65 536 Python dicts per step would
+    cost more than the simulation).  infos[i] has "target" always (fixed_wing.py:435) and, for finished episodes,
+    "termination", the configured metrics (fixed_wing.py:419-421) and "terminal_observation"."""
+
+    def __init__(self, env, done, term, target, metrics, term_obs):
+        self._env, self._done, self._term, self._target, self._metrics, self._term_obs = env, done, term, target, metrics, term_obs
+        self._cache = {}
+
+    def __len__(self):
+        return self._env.num_envs
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if i not in self._cache:
+            self._cache[i] = self._env._build_info(i, self._done, self._term, self._target, self._metrics, self._term_obs)
+        return self._cache[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class FixedWingVecEnv(object):
+    def __init__(self, config_path=None, num_envs=1, device=0, sim_config_path=None, sim_parameter_path=None,
+                 config_kw=None, sim_config_kw=None, auto_reset=True, as_numpy=False, env_id_base=0, seed=0,
+                 _backend=None, _lib_path=None):
+        self.env_config = EnvConfig(config_path, sim_config_path, sim_parameter_path, config_kw, sim_config_kw)
+        self.cfg = self.env_config.cfg
+        self.num_envs = int(num_envs)
+        self.as_numpy = as_numpy
+        self.auto_reset = auto_reset
+        self.training = True
+        self._lib = nat.load_library(_lib_path)
+        self._mem = _backend if _backend is not None else _TorchBackend(device)
+        ec = self.env_config
+        self.observation_space = Box(low=ec.obs_low, high=ec.obs_high, dtype=np.float32)
+        self.action_space = Box(low=ec.action_space_low, high=ec.action_space_high, dtype=np.float32)
+        self.obs_shape = tuple(ec.obs_shape)
+        self.obs_dim = int(np.prod(self.obs_shape))
+        self.target_names = list(ec.target_names)
+        self.dt = ec.dt
+
+        self._c = ec.compile(auto_reset=auto_reset)
+        self.layout = nat.Layout()
+        nat.check(self._lib, self._lib.fwg_get_layout(ctypes.byref(self._c), ctypes.byref(self.layout)))
+        N, m = self.num_envs, self._mem
+        self.state = m.zeros((self.layout.rows, N))           # SoA state arena [field][env], zero = "never reset"
+        self._obs = m.zeros((N, self.obs_dim))
+        self._rew = m.zeros((N,))
+        self._done = m.zeros((N,), "u8")
+        self._term = m.zeros((N,), "u8")
+        self._term_obs = m.zeros((N, self.obs_dim))
+        self._metrics = m.full((nat.N_METRICS, N), math.nan)
+        self._target = m.zeros((N, len(self.target_names)))
+        self._handle = ctypes.c_void_p()
+        nat.check(self._lib, self._lib.fwg_create(ctypes.byref(self._c), N, getattr(m, "index", 0), m.ptr(self.state),
+                                                  int(env_id_base), ctypes.byref(self._handle)))
+        self.check_actions = False
+        self._pending = None
+        self.seed(seed)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.fwg_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def seed(self, seed=None):
+        """FixedWingAircraft.seed (fixed_wing.py:214-222): env i of a VecEnv gets stream (seed, env_id_base + i)."""
+        seed = 0 if seed is None else int(seed)
+        self._seed = seed
+        nat.check(self._lib, self._lib.fwg_seed(self._handle, ctypes.c_uint64(seed & (2 ** 64 - 1))))
+        return [seed + i for i in range(min(self.num_envs, 1))] if self.num_envs == 1 else [seed]
+
+    def set_curriculum_level(self, level):
+        """fixed_wing.py:224-285 for every env (the reference broadcasts it with env_method,
+        examples/train_rl_controller.py:84)."""
+        self.env_config.set_curriculum_level(level)
+        self._upload()
+
+    def _upload(self):
+        self._c = self.env_config.compile(auto_reset=self.auto_reset)
+        nat.check(self._lib, self._lib.fwg_update_config(self._handle, ctypes.byref(self._c)))
+
+    def set_simulator_attr(self, key, value):
+        """setattr(simulator, key, val) (fixed_wing.py:570), e.g. turbulence_intensity."""
+        if key == "turbulence_intensity":
+            self.env_config.turbulence_intensity = value
+        elif key == "turbulence":
+            if bool(value) != self.env_config.turbulence:
+                raise ValueError("turbulence on/off changes the state layout: construct the env with sim_config_kw")
+        else:
+            raise NotImplementedError("simulator attribute {}".format(key))
+        self._upload()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _out(self, t, shape=None):
+        if shape is not None:
+            t = t.reshape(shape)
+        return self._mem.to_host(t) if self.as_numpy else t
+
+    def reset(self, indices=None, states=None, targets=None):
+        """Resets all envs (or those in `indices`).  `states`: dict var name -> value(s) as in the reference's
+        reset(state=...) (fixed_wing.py:287,308); `targets`: dict target name -> value(s) (fixed_wing.py:311-315).
+        Returns the observations of ALL envs (rows of untouched envs are their latest observations)."""
+        N, m = self.num_envs, self._mem
+        mask_t = None
+        idx = None
+        if indices is not None:
+            idx = np.atleast_1d(np.asarray(indices, dtype=np.int64))
+            mask = np.zeros(N, dtype=np.uint8)
+            mask[idx] = 1
+            mask_t = m.from_host(mask, "u8")
+        n_sel = N if idx is None else len(idx)
+
+        def expand(rows, names, values):
+            arr = np.full((rows, N), np.nan, dtype=np.float32)
+            for name, val in values.items():
+                if val is None:
+                    continue
+                r = names.index(name)
+                val = np.asarray(val, dtype=np.float32)
+                if idx is None:
+                    arr[r, :] = val
+                else:
+                    arr[r, idx] = val
+            return m.from_host(arr)
+
+        st = expand(nat.N_RESET_VARS, nat.VARS[:nat.N_RESET_VARS], states) if states else None
+        tg = expand(len(self.target_names), self.target_names, targets) if targets else None
+        null = ctypes.c_void_p()
+        nat.check(self._lib, self._lib.fwg_reset(self._handle, m.ptr(mask_t) if mask_t is not None else null,
+                                                 m.ptr(st) if st is not None else null,
+                                                 m.ptr(tg) if tg is not None else null, m.ptr(self._obs), m.stream()))
+        if st is not None or tg is not None or mask_t is not None:
+            m.sync()  # the temporaries above must outlive the launch
+        del n_sel
+        return self._out(self._obs, (N,) + self.obs_shape)
+
+    def step_async(self, actions):
+        m = self._mem
+        act = m.as_device(actions).reshape(self.num_envs, 3)
+        if self.check_actions:
+            nat.check(self._lib, self._lib.fwg_check_actions(self._handle, m.ptr(act), m.stream()))
+        nat.check(self._lib, self._lib.fwg_step(self._handle, m.ptr(act), m.ptr(self._obs), m.ptr(self._rew), m.ptr(self._done),
+                                                m.ptr(self._term), m.ptr(self._term_obs), m.ptr(self._metrics),
+                                                m.ptr(self._target), m.stream()))
+        self._pending = act  # keeps the action buffer alive until the kernel has consumed it
+
+    def step_wait(self):
+        N = self.num_envs
+        infos = LazyInfos(self, self._done, self._term, self._target, self._metrics, self._term_obs)
+        return (self._out(self._obs, (N,) + self.obs_shape), self._out(self._rew), self._out(self._done), infos)
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def step_device(self, actions):
+        """Fast path for on-device rollouts: no info objects; returns the (obs, reward, done) device tensors."""
+        m = self._mem
+        nat.check(self._lib, self._lib.fwg_step(self._handle, m.ptr(actions), m.ptr(self._obs), m.ptr(self._rew), m.ptr(self._done),
+                                                m.ptr(self._term), m.ptr(self._term_obs), m.ptr(self._metrics),
+                                                m.ptr(self._target), m.stream()))
+        return self._obs, self._rew, self._done
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _host(self, name, t):
+        cache = self.__dict__.setdefault("_host_cache", {})
+        key = (name, int(self._lib.fwg_global_step(self._handle)))
+        if cache.get("key") != key:
+            cache.clear()
+            cache["key"] = key
+        if name not in cache:
+            cache[name] = self._mem.to_host(t)
+        return cache[name]
+
+    def _build_info(self, i, done, term, target, metrics, term_obs):
+        info = {}
+        d = self._host("done", done)
+        tg = self._host("target", target)
+        if d[i]:
+            info["termination"] = nat.term_name(self._host("term", term)[i])
+            mt = self._host("metrics", metrics)[:, i]
+            info.update(self.metrics_dict(mt))
+            if self.auto_reset:
+                info["terminal_observation"] = self._host("term_obs", term_obs)[i].reshape(self.obs_shape)
+                info["TimeLimit.truncated"] = info["termination"] == "steps"
+        info["target"] = {n: float(tg[i, k]) for k, n in enumerate(self.target_names)}
+        return info
+
+    def metrics_dict(self, mt):
+        """Column of the metrics block -> the info entries of the reference (get_metric, fixed_wing.py:1095-1162)."""
+        names = self.target_names
+        with_all = names + ["all"]
+        has_bound = [t.get("bound", None) is not None for t in self.cfg["target"]["states"]]
+        out = {}
+        for metric in self.cfg.get("metrics", []):
+            n = metric["name"]
+            if n == "rise_time":
+                out[n] = {s: float(mt[nat.M_RISE_TIME + k]) for k, s in enumerate(names)}
+            elif n == "settling_time":
+                out[n] = {s: float(mt[nat.M_SETTLING_TIME + (k if s != "all" else 3)]) for k, s in enumerate(with_all)
+                          if s == "all" or has_bound[k]}
+            elif n == "success":
+                out[n] = {s: bool(mt[nat.M_SUCCESS + (k if s != "all" else 3)] == 1.0) for k, s in enumerate(with_all)
+                          if s == "all" or has_bound[k]}
+            elif n == "success_time_frac":
+                out[n] = {s: float(mt[nat.M_SUCCESS_TIME_FRAC + (k if s != "all" else 3)]) for k, s in enumerate(with_all)
+                          if s == "all" or has_bound[k]}
+            elif n == "overshoot":
+                out[n] = {s: float(mt[nat.M_OVERSHOOT + k]) for k, s in enumerate(names)}
+            elif n == "total_error":
+                out[n] = {s: float(mt[nat.M_TOTAL_ERROR + k]) for k, s in enumerate(names)}
+            elif n == "avg_error":
+                out[n] = {s: float(mt[nat.M_AVG_ERROR + k]) for k, s in enumerate(names)}
+            elif n == "end_error":
+                out[n] = {s: float(mt[nat.M_END_ERROR + k]) for k, s in enumerate(names)}
+            elif n == "control_variation":
+                out[n] = {"all": float(mt[nat.M_CONTROL_VARIATION])}
+            else:
+                out[n] = {}
+        return out
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def field(self, name):
+        """Device view [N] of one simulator variable or bookkeeping field of the state arena (no copy)."""
+        L, S = self.layout, self.state
+        phys = {"e0": 0, "e1": 1, "e2": 2, "e3": 3, "omega_p": 4, "omega_q": 5, "omega_r": 6, "position_n": 7,
+                "position_e": 8, "position_d": 9, "velocity_u": 10, "velocity_v": 11, "velocity_w": 12,
+                "elevon_right": 13, "elevon_left": 14, "throttle": 15, "elevon_right_dot": 16, "elevon_left_dot": 17}
+        derived = {"roll": 0, "pitch": 1, "yaw": 2, "Va": 3, "alpha": 4, "beta": 5}
+        if name in phys:
+            return S[L.phys + phys[name]]
+        if name in derived:
+            return S[L.derived + derived[name]]
+        if name in ("wind_n", "wind_e", "wind_d"):
+            return S[L.wind + ("wind_n", "wind_e", "wind_d").index(name)]
+        if name == "elevator":
+            return 0.5 * (S[L.phys + 13] + S[L.phys + 14])
+        if name == "aileron":
+            return 0.5 * (S[L.phys + 14] - S[L.phys + 13])
+        if name.startswith("target_"):
+            return S[L.target + self.target_names.index(name[7:])]
+        if name in ("steps_count", "steps_for_target", "flags", "episode"):
+            row = L.counters + ("steps_count", "steps_for_target", "flags", "episode").index(name)
+            return self._mem.view_i32(S[row])
+        raise KeyError(name)
+
+    def get_state(self, names):
+        """Host copy {name: array[N]} of simulator variables (render, tests, checkpoints)."""
+        return {n: np.array(self._mem.to_host(self.field(n))) for n in names}
+
+    def reduce_success(self):
+        """Local sums over the episodes finished since the last call (see fwg_reduce_success)."""
+        out = (ctypes.c_float * nat.N_REDUCE)()
+        nat.check(self._lib, self._lib.fwg_reduce_success(self._handle, out, self._mem.stream()))
+        return np.array(out[:], dtype=np.float64)
+
+    # stable-baselines VecEnv surface used by the example scripts ---------------------------------------------------
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        if attr_name == "simulator":
+            return [self.env_config] * n
+        return [getattr(self, attr_name)] * n
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        if method_name == "set_curriculum_level":
+            self.set_curriculum_level(*args, **kwargs)
+            return [None] * self.num_envs
+        if method_name == "reset":
+            state, target = kwargs.pop("state", None), kwargs.pop("target", None)
+            obs = self.reset(indices=indices, states=state, targets=target)
+            idx = range(self.num_envs) if indices is None else np.atleast_1d(indices)
+            return [obs[i] for i in idx]
+        if method_name == "render":
+            return [None]
+        raise NotImplementedError(method_name)
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.num_envs

@@ -1,0 +1,279 @@
+/*
+ * fwgym.h -- C ABI of libfwgym.so, the MI355X-native batched replacement for the hot path
+ *            FixedWingAircraft.step()/reset() of eivindeb/fixed-wing-gym.
+ *
+ * The reference has no FFI: its hot path is Python calling Python (gym_fixed_wing/fixed_wing.py calling
+ * pyfly.pyfly.PyFly).  Each entry point below names the reference interface it replaces for a whole batch of
+ * N independent environments ("one wavefront lane = one aircraft").  All pointers are DEVICE pointers unless the
+ * parameter name ends in _host.  No torch types cross this boundary; `stream` is a hipStream_t passed as void*.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative fwg_status; fwg_last_error() gives the message
+ *     (thread-local); nothing throws across the ABI.
+ *   - per-environment SIMULATION failures are data, not API errors: done=1 and term_code=FWG_TERM_VAR0+var_id,
+ *     mirroring fixed_wing.py:409-416.
+ *   - the caller owns every buffer, including the persistent state arena (rows x N 32-bit words, SoA
+ *     [field][env]); the library allocates only its small device-side constant block and reduction scratch in
+ *     fwg_create.  No allocation and no synchronisation happens in fwg_step/fwg_reset.
+ *   - a handle is not thread-safe; use one handle per GPU/stream.
+ */
+#ifndef FWGYM_H
+#define FWGYM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FWG_ABI_VERSION 3
+
+#define FWG_N_VARS 23        /* simulator variables, see fwg_var */
+#define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
+#define FWG_N_PARAMS 49      /* aircraft parameters, see fwg_param */
+#define FWG_MAX_OBS 32       /* observation.states entries per row (fixed_wing.py:796) */
+#define FWG_MAX_ROWS 8       /* observation.length (fixed_wing.py:790) */
+#define FWG_MAX_FACTORS 16   /* reward.factors (fixed_wing.py:683) */
+#define FWG_MAX_TARGETS 3    /* target.states (fixed_wing.py:471) */
+#define FWG_MAX_WINDOW 8     /* action window_size (fixed_wing.py:689,822) */
+#define FWG_MAX_STREAK 128   /* target.success_streak_req (fixed_wing.py:377) */
+#define FWG_END_WINDOW 50    /* end_error window (fixed_wing.py:1107) */
+#define FWG_N_DRYDEN 8       /* Dryden filter states (joint realisation u | v,r | w,q | p) */
+#define FWG_N_METRICS 28     /* rows of the metrics block written by fwg_step, see fwg_metric_row */
+#define FWG_N_REDUCE 16      /* floats accumulated for fwg_reduce_success */
+
+typedef enum fwg_status {
+    FWG_OK = 0,
+    FWG_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+    FWG_ERR_ABI = -2,         /* struct size or version mismatch */
+    FWG_ERR_HIP = -3,         /* a HIP runtime call failed */
+    FWG_ERR_NAN_ACTION = -4   /* fwg_check_actions found NaN (reference: AssertionError, fixed_wing.py:347) */
+} fwg_status;
+
+/* simulator variable ids; 0..20 are exactly the keys of the reference's test-set "state" records */
+typedef enum fwg_var {
+    FWG_V_ROLL = 0, FWG_V_PITCH, FWG_V_YAW, FWG_V_OMEGA_P, FWG_V_OMEGA_Q, FWG_V_OMEGA_R,
+    FWG_V_POS_N, FWG_V_POS_E, FWG_V_POS_D, FWG_V_VEL_U, FWG_V_VEL_V, FWG_V_VEL_W,
+    FWG_V_VA, FWG_V_ALPHA, FWG_V_BETA, FWG_V_ELEVATOR, FWG_V_AILERON, FWG_V_THROTTLE,
+    FWG_V_WIND_N, FWG_V_WIND_E, FWG_V_WIND_D, FWG_V_ELEVON_RIGHT, FWG_V_ELEVON_LEFT
+} fwg_var;
+
+/* aircraft parameter ids (names of the X8 parameter table, simulator.params[name] at fixed_wing.py:539) */
+typedef enum fwg_param {
+    FWG_P_MASS = 0, FWG_P_JX, FWG_P_JY, FWG_P_JZ, FWG_P_JXZ, FWG_P_S_WING, FWG_P_B, FWG_P_C, FWG_P_S_PROP,
+    FWG_P_C_PROP, FWG_P_K_MOTOR, FWG_P_K_T_P, FWG_P_K_OMEGA, FWG_P_E, FWG_P_AR, FWG_P_M, FWG_P_A_0,
+    FWG_P_C_LIFT_0, FWG_P_C_LIFT_ALPHA, FWG_P_C_LIFT_Q, FWG_P_C_LIFT_DELTA_E, FWG_P_C_D_P, FWG_P_C_D_BETA1, FWG_P_C_D_BETA2,
+    FWG_P_C_D_Q, FWG_P_C_D_DELTA_E, FWG_P_C_M_0, FWG_P_C_M_ALPHA, FWG_P_C_M_Q, FWG_P_C_M_DELTA_E, FWG_P_C_M_FP,
+    FWG_P_C_Y_0, FWG_P_C_Y_BETA, FWG_P_C_Y_P, FWG_P_C_Y_R, FWG_P_C_Y_DELTA_A, FWG_P_C_Y_DELTA_R,
+    FWG_P_C_ROLL_0, FWG_P_C_ROLL_BETA, FWG_P_C_ROLL_P, FWG_P_C_ROLL_R, FWG_P_C_ROLL_DELTA_A, FWG_P_C_ROLL_DELTA_R,
+    FWG_P_C_N_0, FWG_P_C_N_BETA, FWG_P_C_N_P, FWG_P_C_N_R, FWG_P_C_N_DELTA_A, FWG_P_C_N_DELTA_R
+} fwg_param;
+
+/* termination codes written to term_code_out (info["termination"], fixed_wing.py:368,385,416) */
+enum {
+    FWG_TERM_NONE = 0,
+    FWG_TERM_STEPS = 1,      /* "steps"   */
+    FWG_TERM_SUCCESS = 2,    /* "success" */
+    FWG_TERM_VAR0 = 16,      /* FWG_TERM_VAR0 + fwg_var = name of the violated simulator variable */
+    FWG_TERM_NAN = 255       /* a state became non-finite */
+};
+
+/* observation.states[i] (fixed_wing.py:796-838) */
+enum { FWG_OBS_STATE = 0, FWG_OBS_TARGET_RELATIVE = 1, FWG_OBS_TARGET_ABSOLUTE = 2, FWG_OBS_ACTION = 3 };
+typedef struct fwg_obs_desc {
+    int32_t type;      /* FWG_OBS_* */
+    int32_t src;       /* STATE: fwg_var; TARGET_*: index into target.states; ACTION: index into action.states */
+    int32_t window;    /* ACTION: window_size (fixed_wing.py:822) */
+    int32_t norm;      /* apply (val-mean)/var (fixed_wing.py:833-835) */
+    double mean;
+    double var;        /* the reference divides by "var" itself */
+} fwg_obs_desc;
+
+/* target.states[i] (fixed_wing.py:461-521, 933-991) */
+enum { FWG_TGT_CONSTANT = 0, FWG_TGT_COMPENSATE = 1, FWG_TGT_LINEAR = 2, FWG_TGT_SINUSOIDAL = 3 };
+typedef struct fwg_target_desc {
+    int32_t var;       /* fwg_var */
+    int32_t cls;       /* FWG_TGT_* */
+    int32_t wrap;      /* simulator.state[name].wrap (fixed_wing.py:897,988) */
+    int32_t has_delta;
+    int32_t has_bound;
+    int32_t pad_;
+    double low, high;  /* radians where convert_to_radians; AFTER curriculum scaling (fixed_wing.py:256-265) */
+    double delta;
+    double bound;
+    double slope_low, slope_high;          /* LINEAR (radians/s where flagged) */
+    double amplitude_low, amplitude_high;  /* SINUSOIDAL */
+    double period_low, period_high;
+} fwg_target_desc;
+
+/* reward.factors[i] (fixed_wing.py:683-751) */
+enum { FWG_RC_STATE = 0, FWG_RC_ACTION = 1, FWG_RC_SUCCESS = 2, FWG_RC_STEP = 3, FWG_RC_GOAL = 4 };
+enum { FWG_RT_VALUE = 0, FWG_RT_ERROR = 1, FWG_RT_DELTA = 2, FWG_RT_BOUND = 3, FWG_RT_PER_STATE = 4, FWG_RT_ALL = 5 };
+enum { FWG_FC_LINEAR = 0, FWG_FC_QUADRATIC = 1, FWG_FC_EXPONENTIAL = 2 };
+typedef struct fwg_factor_desc {
+    int32_t cls;       /* FWG_RC_* */
+    int32_t type;      /* FWG_RT_* */
+    int32_t src;       /* STATE/VALUE: fwg_var; STATE/ERROR: target index */
+    int32_t fclass;    /* FWG_FC_* */
+    int32_t shaping;
+    int32_t window;    /* ACTION/DELTA */
+    int32_t has_max;
+    int32_t value_is_timesteps;  /* SUCCESS with value "timesteps" (fixed_wing.py:716) */
+    double sign;       /* np.sign(sign) */
+    double scaling;
+    double max;
+    double value;
+} fwg_factor_desc;
+
+enum { FWG_ON_SUCCESS_NONE = 0, FWG_ON_SUCCESS_DONE = 1, FWG_ON_SUCCESS_NEW = 2 };
+
+/* Flat, host-side "compiled" form of fixed_wing_config.json + the simulator config + the aircraft parameter table.
+ * Angles are radians.  +-INFINITY encodes an absent min/max. */
+typedef struct fwg_config {
+    uint32_t abi_version;   /* FWG_ABI_VERSION */
+    uint32_t struct_bytes;  /* sizeof(fwg_config) as seen by the caller */
+
+    /* ---- simulator (replaces the PyFly object built at fixed_wing.py:41-46) */
+    double dt, rho, g;
+    int32_t n_substeps;     /* RK4 sub-steps per env step */
+    int32_t turbulence;     /* sim_config_kw["turbulence"] (examples/evaluate_controller.py:78) */
+    double param[FWG_N_PARAMS];
+    double con_min[FWG_N_VARS], con_max[FWG_N_VARS];    /* Variable.constraint_min/max  */
+    double val_min[FWG_N_VARS], val_max[FWG_N_VARS];    /* Variable.value_min/max       */
+    double init_min[FWG_N_VARS], init_max[FWG_N_VARS];  /* Variable.init_min/max AFTER curriculum (fixed_wing.py:233-245) */
+    double elevon_omega0[2], elevon_zeta[2], elevon_dot_max[2];  /* [right, left] */
+    double throttle_tau;
+    double dryden_A[FWG_N_DRYDEN * FWG_N_DRYDEN];  /* discrete x' = A x + B n, row-major */
+    double dryden_B[FWG_N_DRYDEN * 4];             /* includes the sqrt(pi/dt) white-noise scaling */
+    double dryden_C[6 * FWG_N_DRYDEN];             /* gust (u,v,w,p,q,r) = C x */
+
+    /* ---- gym side */
+    int32_t steps_max;                  /* fixed_wing.py:49 */
+    int32_t obs_length, obs_step;       /* fixed_wing.py:786-790 */
+    int32_t n_obs;                      /* len(observation.states) */
+    int32_t obs_normalize;              /* fixed_wing.py:59 */
+    int32_t obs_noise;                  /* observation.noise present with var != 0 or mean != 0 */
+    double obs_noise_mean, obs_noise_std;
+    fwg_obs_desc obs[FWG_MAX_OBS];
+
+    int32_t n_actions;                  /* must be 3: elevator, aileron, throttle */
+    int32_t scale_actions;              /* action.scale_space (fixed_wing.py:185,349) */
+    double scale_low, scale_high;
+    double act_to_low[3], act_to_high[3];      /* action_scale_to_low/high (fixed_wing.py:177-178) */
+    int32_t has_action_bounds, pad0_;
+    double act_bound_min[3], act_bound_max[3]; /* fixed_wing.py:187-191 */
+
+    int32_t n_targets, resample_every, streak_req, on_success;  /* fixed_wing.py:377-398 */
+    double streak_fraction;
+    fwg_target_desc target[FWG_MAX_TARGETS];
+
+    int32_t reward_potential;           /* reward.form == "potential" */
+    int32_t step_fail_timesteps;        /* reward.step_fail == "timesteps" (fixed_wing.py:411-415) */
+    double step_fail_value;
+    int32_t term_present[3];            /* reward.terms by FWG_FC_* */
+    int32_t n_factors;
+    double term_weight[3];
+    fwg_factor_desc factor[FWG_MAX_FACTORS];
+
+    int32_t metrics;                    /* any entry in cfg["metrics"] (fixed_wing.py:419-421) */
+    int32_t auto_reset;                 /* VecEnv semantics: a done env restarts inside the same fwg_step */
+    double rise_low, rise_high;         /* metrics[rise_time].low/high (fixed_wing.py:1131) */
+} fwg_config;
+
+/* Row offsets (in units of N words) of the SoA state arena the caller must allocate: float32/uint32 [rows][N]. */
+typedef struct fwg_layout {
+    int32_t rows;        /* total */
+    int32_t phys;        /* 18: e0 e1 e2 e3 | p q r | pn pe pd | u v w | elevon_r elevon_l throttle | elevon_r_dot elevon_l_dot */
+    int32_t wind;        /* 3: steady wind n,e,d */
+    int32_t dryden;      /* 8 (present only when turbulence) */
+    int32_t derived;     /* 6: roll pitch yaw Va alpha beta of the committed state */
+    int32_t target;      /* 3 values + 4 property words per target (slope|amplitude, period, phase, bias) */
+    int32_t counters;    /* 4 x uint32: steps_count, steps_for_target, flags, episode */
+    int32_t prev_shaping;/* 3 */
+    int32_t act_ring;    /* window*3 raw actions, slot = global_step % window */
+    int32_t cmd_ring;    /* window*3 constrained commands (only when observations need them) */
+    int32_t prev_cmd;    /* 3 */
+    int32_t goal_ring;   /* 4 rings (target0..2, all) x 4 uint32 */
+    int32_t goal_count;  /* 4 x uint32 cumulative */
+    int32_t met;         /* e0 3 | sum 3 | sum_abs 3 | min 3 | max 3 | rise 3 (u32 lo16=low idx, hi16=high idx) | settle 2 (u32 packed 4x16) | prev_err 3 | sum_dcmd 1 | n_cmd 1 */
+    int32_t end_ring;    /* 50*3, slot = global_step % 50 */
+    int32_t lag_ring;    /* ((length-1)*step+1) * n_obs un-normalised rows, slot = global_step % depth */
+    int32_t window;      /* action window depth */
+    int32_t lag_depth;
+} fwg_layout;
+
+/* rows of the metrics block (float32 [FWG_N_METRICS][N], valid where done) -- get_metric, fixed_wing.py:1095-1162 */
+typedef enum fwg_metric_row {
+    FWG_M_RISE_TIME = 0,          /* 3 */
+    FWG_M_SETTLING_TIME = 3,      /* 4: target0..2, all */
+    FWG_M_OVERSHOOT = 7,          /* 3 */
+    FWG_M_TOTAL_ERROR = 10,       /* 3 */
+    FWG_M_AVG_ERROR = 13,         /* 3 */
+    FWG_M_CONTROL_VARIATION = 16, /* 1 */
+    FWG_M_SUCCESS = 17,           /* 4 */
+    FWG_M_SUCCESS_TIME_FRAC = 21, /* 4 */
+    FWG_M_END_ERROR = 25          /* 3 */
+} fwg_metric_row;
+
+typedef struct fwg_handle fwg_handle;
+
+/* Library/ABI version check. */
+int fwg_abi_version(void);
+
+/* Computes the arena layout for a configuration (pure host function). */
+int fwg_get_layout(const fwg_config* cfg_host, fwg_layout* out_host);
+
+/* Replaces FixedWingAircraft.__init__ (fixed_wing.py:14-212) for n_envs environments on HIP device `device`.
+ * `state_arena` must hold layout.rows * n_envs 32-bit words and stay alive until fwg_destroy.
+ * `env_id_base` is the global index of this handle's first env (multi-GPU sharding: RNG streams depend only on the
+ * global env index, so results do not depend on how envs are split over GPUs). */
+int fwg_create(const fwg_config* cfg_host, int64_t n_envs, int device, void* state_arena, int64_t env_id_base,
+               fwg_handle** out);
+int fwg_destroy(fwg_handle* h);
+
+/* Re-uploads the constants after a host-side change that keeps the layout (set_curriculum_level, fixed_wing.py:224-285;
+ * setattr(simulator, key, val), fixed_wing.py:570). */
+int fwg_update_config(fwg_handle* h, const fwg_config* cfg_host);
+
+/* FixedWingAircraft.seed (fixed_wing.py:214-222): key of the counter-based device RNG. */
+int fwg_seed(fwg_handle* h, uint64_t seed);
+
+/* FixedWingAircraft.reset (fixed_wing.py:287-336) for the envs selected by `mask` (NULL = all).
+ *   init_state : NULL or float32 [FWG_N_RESET_VARS][N]; NaN entries are sampled from init_min/init_max
+ *                (reset(state=...) semantics, fixed_wing.py:308)
+ *   init_target: NULL or float32 [n_targets][N]; NaN entries are sampled (reset(target=...), fixed_wing.py:311-315)
+ *   obs_out    : float32 [N][obs_length*n_obs]; rows of unselected envs are left untouched */
+int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const float* init_target,
+              float* obs_out, void* stream);
+
+/* FixedWingAircraft.step (fixed_wing.py:338-437) for all N envs, one fused launch.
+ *   actions          : float32 [N][3] raw policy actions
+ *   obs_out          : float32 [N][obs_length*n_obs]
+ *   reward_out       : float32 [N]
+ *   done_out         : uint8 [N]
+ *   term_code_out    : uint8 [N]  FWG_TERM_*
+ *   terminal_obs_out : NULL or float32 [N][obs_dim]; written for done envs only (VecEnv "terminal_observation")
+ *   metrics_out      : NULL or float32 [FWG_N_METRICS][N]; written for done envs only
+ *   target_out       : NULL or float32 [N][n_targets] = info["target"] (fixed_wing.py:435) after the step */
+int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_out, uint8_t* done_out,
+             uint8_t* term_code_out, float* terminal_obs_out, float* metrics_out, float* target_out, void* stream);
+
+/* Debug-mode check for NaN actions (fixed_wing.py:347); synchronises the stream. */
+int fwg_check_actions(fwg_handle* h, const float* actions, void* stream);
+
+/* Local sums over the episodes finished since the last call: out_host[0]=episodes, [1..4]=success target0..2/all,
+ * [5]=sum control_variation, [6..8]=sum end_error, [9..11]=sum total_error, [12..15]=sum success_time_frac.
+ * These are the per-GPU contributions to the curriculum/logging reduction of
+ * examples/train_rl_controller.py:51-66,80-85; the caller all-gathers them over RCCL.  Synchronises the stream and
+ * clears the accumulators. */
+int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream);
+
+/* Global step counter driving the ring slots (diagnostics/tests). */
+int64_t fwg_global_step(const fwg_handle* h);
+
+const char* fwg_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FWGYM_H */

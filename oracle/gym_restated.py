@@ -60,6 +60,61 @@ class MTStream:
     def begin_target(self):
         pass
 
+    def begin_episode(self, episode):
+        pass
+
+
+class PhiloxStream:
+    """Draw source mirroring the DEVICE's counter-based streams (csrc/fwgym_env.h: reset_env, sample_targets,
+    fix_padded_rows, add_obs_noise), so that sampled initial states/targets and noise can be compared exactly.
+    ctr = (env_id, counter, sub, stream + 256*block), key = seed -- see oracle/physics.py rng_bits."""
+
+    def __init__(self, seed, env_id):
+        from . import physics as ph
+        self.ph, self.seed, self.env_id = ph, int(seed), int(env_id)
+        self.episode, self.resample, self.steps = 0, 0, 0
+        self._tblock, self._tfield = None, 0
+
+    def _bits(self, counter, sub, stream, block=0):
+        return self.ph.rng_bits(self.seed, [self.env_id], counter, stream + 256 * block, sub=sub)[0]
+
+    def begin_episode(self, episode):
+        self.episode, self.resample = int(episode), 0
+
+    def init_state_uniform(self, var_index, low, high):
+        b = self._bits(self.episode, var_index // 4, self.ph.STREAM_RESET_STATE)
+        return low + (high - low) * self.ph.u01(b[var_index % 4])
+
+    def begin_target(self):
+        self._resample_now = self.resample
+        self.resample += 1
+
+    def target_uniform(self, k, low, high):
+        self._tblock = self._bits(self.episode, self._resample_now, self.ph.STREAM_RESET_TARGET, block=k)
+        self._tfield = 1
+        return low + (high - low) * self.ph.u01(self._tblock[0])
+
+    def uniform(self, low=0.0, high=1.0):
+        u = self.ph.u01(self._tblock[self._tfield])
+        self._tfield += 1
+        return low + (high - low) * u
+
+    def begin_obs(self, steps_count):
+        self.steps = int(steps_count)
+
+    def init_noise(self, row):
+        b = self._bits(self.steps, self.episode, self.ph.STREAM_INIT_NOISE, block=row // 4)
+        return 2.0 * self.ph.u01(b[row % 4]) - 1.0
+
+    def obs_normal(self, idx, mean, std):
+        if std == 0 and mean == 0:
+            return 0.0  # the device skips the noise pass entirely in this case
+        key = (self.steps, self.episode, idx // 4)
+        if getattr(self, "_nkey", None) != key:
+            b = self._bits(self.steps, self.episode, self.ph.STREAM_OBS_NOISE, block=idx // 4)
+            self._nkey, self._nval = key, self.ph.box_muller(b[None, :])[0]
+        return mean + std * self._nval[idx % 4]
+
 
 class FixedWingOracle:
     def __init__(self, config, sim_config_kw=None, config_kw=None, sim_config_path=None, sim_parameter_path=None):
@@ -288,6 +343,9 @@ class FixedWingOracle:
         """fixed_wing.py:287-336."""
         cfg = self.cfg
         self.steps_count = 0
+        self.rng.begin_episode(self.simulator.episode + 1)
+        if isinstance(self.rng, PhiloxStream):
+            sim_reset_kw = dict(sim_reset_kw, draw=self.rng.init_state_uniform)
         self.simulator.reset(state, **sim_reset_kw)
         self._sample_sim_attrs()
         self.sample_target()

@@ -111,23 +111,24 @@ class PyFly:
     def inject_turbulence_noise(self, normals):
         self._normals = None if normals is None else np.asarray(normals, dtype=np.float64)
 
-    def reset(self, state=None, turbulence_noise=None):
+    def reset(self, state=None, turbulence_noise=None, draw=None):
         spec = self._spec()
         self.cur_sim_step = 0
         self.episode += 1
         if turbulence_noise is not None:
             self.inject_turbulence_noise(turbulence_noise)
         vals = {}
-        for name in ph.VARS[:21]:
+        for vi, name in enumerate(ph.VARS[:21]):
             if name in ("Va", "alpha", "beta"):
                 continue
             var = self.state[name]
-            if state is not None and name in state and state[name] is not None:
+            if state is not None and name in state and state[name] is not None and not np.isnan(state[name]):
                 v = float(state[name])
             else:
                 if var.init_min is None or var.init_max is None:
                     raise Exception("Variable init_min and init_max can not be None if no value is provided on reset")
-                v = self.np_random.uniform(var.init_min, var.init_max)
+                v = draw(vi, var.init_min, var.init_max) if draw is not None else \
+                    self.np_random.uniform(var.init_min, var.init_max)
             vals[name] = np.array([v])
         self._y, self._wind = ph.initial_state(spec, vals)
         self._dry_x = np.zeros((1, ph.N_DRY))

@@ -1,0 +1,158 @@
+"""Shared parity harness: drives a FixedWingVecEnv (real HIP library on the GPU box, or the host-emulation build in a
+GPU-less container) next to N float64 oracle environments on identical seeds/inputs and compares everything the
+reference's step()/reset() return."""
+import copy
+import math
+
+import numpy as np
+
+from oracle import physics as ph
+from oracle.gym_restated import FixedWingOracle, PhiloxStream
+
+
+def make_oracles(config, n, seed, config_kw=None, sim_config_kw=None, env_id_base=0):
+    envs = []
+    for i in range(n):
+        o = FixedWingOracle(copy.deepcopy(config), config_kw=copy.deepcopy(config_kw),
+                            sim_config_kw=copy.deepcopy(sim_config_kw))
+        o.seed(seed)
+        o.rng = PhiloxStream(seed, env_id_base + i)
+        o.simulator.env_id = env_id_base + i
+        envs.append(o)
+    return envs
+
+
+def _np(x):
+    try:
+        import torch
+        if isinstance(x, torch.Tensor):
+            return x.detach().cpu().numpy()
+    except ImportError:
+        pass
+    return np.asarray(x)
+
+
+class Mismatch(AssertionError):
+    pass
+
+
+def close(a, b, rtol, atol, what):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        raise Mismatch("{}: shape {} vs {}".format(what, a.shape, b.shape))
+    na, nb = np.isnan(a), np.isnan(b)
+    if not np.array_equal(na, nb):
+        raise Mismatch("{}: NaN pattern differs\n got {}\n want {}".format(what, a, b))
+    err = np.abs(np.where(na, 0, a - b))
+    tol = atol + rtol * np.abs(np.where(nb, 0, b))
+    if np.any(err > tol):
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise Mismatch("{}: max violation at {}: got {!r} want {!r} (err {:.3e}, tol {:.3e})".format(
+            what, i, a[i], b[i], err[i], tol[i]))
+    return float(err.max()) if err.size else 0.0
+
+
+def run_gym_parity(vec, oracles, n_steps, action_fn, rtol=2e-3, atol=2e-3, check_metrics=True, reset_kw=None,
+                   metric_rtol=None, log=None):
+    """Free-running comparison over n_steps.  `action_fn(t) -> float32 [N,3]`.  Oracle envs are reset by hand when
+    done (the VecEnv auto-resets).  Returns summary statistics."""
+    N = vec.num_envs
+    names = vec.target_names
+    reset_kw = reset_kw or {}
+    obs = _np(vec.reset(**({} if not reset_kw else reset_kw["vec"])))
+    want = np.stack([o.reset(**({} if not reset_kw else reset_kw["oracle"][i])) for i, o in enumerate(oracles)])
+    worst = {"obs": 0.0, "reward": 0.0, "target": 0.0}
+    worst["obs"] = max(worst["obs"], close(obs.reshape(N, -1), want.reshape(N, -1), rtol, atol, "reset obs"))
+    episodes = 0
+    terms = {}
+    for t in range(n_steps):
+        a = np.asarray(action_fn(t), dtype=np.float32)
+        obs, rew, done, infos = vec.step(a)
+        obs, rew, done = _np(obs), _np(rew), _np(done).astype(bool)
+        w_obs, w_rew, w_done, w_info = [], [], [], []
+        for i, o in enumerate(oracles):
+            ob, r, d, info = o.step(a[i].astype(np.float64))
+            w_obs.append(ob), w_rew.append(r), w_done.append(d), w_info.append(info)
+        w_done = np.array(w_done)
+        if not np.array_equal(done, w_done):
+            bad = np.nonzero(done != w_done)[0]
+            raise Mismatch("step {}: done differs at envs {} (got {}, want {}; oracle info {})".format(
+                t, bad[:8], done[bad[:8]], w_done[bad[:8]], [w_info[b].get("termination") for b in bad[:8]]))
+        worst["reward"] = max(worst["reward"], close(rew, np.array(w_rew, dtype=np.float64), rtol, atol, "step {} reward".format(t)))
+        tgt = np.array([[infos[i]["target"][n] for n in names] for i in range(N)]) if N <= 512 else None
+        for i in np.nonzero(done)[0]:
+            info = infos[int(i)]
+            episodes += 1
+            terms[info["termination"]] = terms.get(info["termination"], 0) + 1
+            if info["termination"] != w_info[i]["termination"]:
+                raise Mismatch("step {} env {}: termination {} vs {}".format(t, i, info["termination"], w_info[i]["termination"]))
+            if vec.auto_reset:
+                close(info["terminal_observation"].reshape(-1), np.asarray(w_obs[i]).reshape(-1), rtol, atol,
+                      "step {} env {} terminal obs".format(t, i))
+            if check_metrics:
+                for m in vec.cfg.get("metrics", []):
+                    got, exp = info[m["name"]], w_info[i][m["name"]]
+                    if set(got.keys()) != set(exp.keys()):
+                        raise Mismatch("metric {} keys {} vs {}".format(m["name"], got.keys(), exp.keys()))
+                    for k in got:
+                        mr = metric_rtol if metric_rtol is not None else max(rtol, 5e-3)
+                        if m["name"] in ("rise_time", "settling_time"):
+                            # integer step indices: a threshold crossing may move by a step under fp32 rounding
+                            g, e_ = float(got[k]), float(exp[k])
+                            if (math.isnan(g) != math.isnan(e_)) or (not math.isnan(g) and abs(g - e_) > 1.0):
+                                raise Mismatch("step {} env {} metric {}[{}]: {} vs {}".format(t, i, m["name"], k, g, e_))
+                        else:
+                            close(float(got[k]), float(exp[k]), mr, max(atol, 1e-3), "step {} env {} metric {}[{}]".format(t, i, m["name"], k))
+            if vec.auto_reset:
+                w_obs[i] = oracles[i].reset()
+        if tgt is not None:
+            w_tgt = np.array([[o.target[n] for n in names] for o in oracles])
+            worst["target"] = max(worst["target"], close(tgt, w_tgt, rtol, atol, "step {} target".format(t)))
+        worst["obs"] = max(worst["obs"], close(obs.reshape(N, -1), np.stack(w_obs).reshape(N, -1), rtol, atol, "step {} obs".format(t)))
+        if log is not None and t % 20 == 0:
+            log("step {} worst {}".format(t, worst))
+    worst["episodes"] = episodes
+    worst["terminations"] = terms
+    return worst
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# single-step physics parity on arbitrary batch sizes (the 1e-5 bar on the 13 rigid-body states)
+# ----------------------------------------------------------------------------------------------------------------------
+STATE_SCALE = np.array([1, 1, 1, 1, 1, 1, 1, 100, 100, 100, 20, 5, 5, 0.5, 0.5, 1, 3.5, 3.5])
+
+
+def oracle_spec_from_env_config(ec):
+    """SimSpec of the oracle for the same simulator configuration as a product EnvConfig (constraints after the gym
+    config's overrides)."""
+    sim_cfg = copy.deepcopy(ec.sim_cfg)
+    sim_cfg["turbulence"] = ec.turbulence
+    sim_cfg["turbulence_intensity"] = ec.turbulence_intensity
+    spec = ph.SimSpec(sim_cfg, ec.params)
+    for name, var in ec.state.items():
+        i = ph.VAR_ID[name]
+        for prop, arr in (("constraint_min", spec.con_min), ("constraint_max", spec.con_max),
+                          ("value_min", spec.val_min), ("value_max", spec.val_max)):
+            v = getattr(var, prop)
+            arr[i] = np.nan if v is None else v
+    return spec
+
+
+def physics_state(vec):
+    """(y[N,18], wind[N,3], dryden[N,8]) float64 copies of the device state."""
+    L = vec.layout
+    S = _np(vec.state)
+    y = S[L.phys:L.phys + 18].T.astype(np.float64)
+    wind = S[L.wind:L.wind + 3].T.astype(np.float64)
+    dry = S[L.dryden:L.dryden + 8].T.astype(np.float64) if vec.env_config.turbulence else np.zeros((y.shape[0], 8))
+    return y, wind, dry
+
+
+def scaled_actions(vec, raw):
+    """What the device feeds the simulator for raw actions (fixed_wing.py:349-354,439-459), float64."""
+    ec = vec.env_config
+    raw = np.asarray(raw, dtype=np.float64)
+    if not ec.scale_actions:
+        return raw
+    lo, hi = ec.cfg["action"]["scale_low"], ec.cfg["action"]["scale_high"]
+    return (ec.action_scale_to_high - ec.action_scale_to_low) * (np.clip(raw, lo, hi) - lo) / (hi - lo) + ec.action_scale_to_low
