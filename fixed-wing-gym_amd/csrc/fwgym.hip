@@ -462,6 +462,28 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
 }
 
 static float f32(double x) { return (float)x; }
+// exp(t * [[a, b], [c, d]]) by scaling-and-squaring with a Taylor series (double)
+static void expm2(double a, double b, double c, double d, double t, double out[4]) {
+    double m[4] = {a * t, b * t, c * t, d * t};
+    double nrm = fabs(m[0]) + fabs(m[1]) + fabs(m[2]) + fabs(m[3]);
+    int s = 0;
+    while (nrm > 0.25) { nrm *= 0.5; ++s; }
+    const double sc = ldexp(1.0, -s);
+    for (int i = 0; i < 4; ++i) m[i] *= sc;
+    double e[4] = {1, 0, 0, 1}, term[4] = {1, 0, 0, 1};
+    for (int k = 1; k < 20; ++k) {
+        const double t0 = (term[0] * m[0] + term[1] * m[2]) / k, t1 = (term[0] * m[1] + term[1] * m[3]) / k;
+        const double t2 = (term[2] * m[0] + term[3] * m[2]) / k, t3 = (term[2] * m[1] + term[3] * m[3]) / k;
+        term[0] = t0; term[1] = t1; term[2] = t2; term[3] = t3;
+        for (int i = 0; i < 4; ++i) e[i] += term[i];
+    }
+    for (int q = 0; q < s; ++q) {
+        const double r0 = e[0] * e[0] + e[1] * e[2], r1 = e[0] * e[1] + e[1] * e[3];
+        const double r2 = e[2] * e[0] + e[3] * e[2], r3 = e[2] * e[1] + e[3] * e[3];
+        e[0] = r0; e[1] = r1; e[2] = r2; e[3] = r3;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = e[i];
+}
 static float lim32(double x, bool is_min) {
     if (std::isnan(x)) return is_min ? -INFINITY : INFINITY;
     return (float)x;
@@ -514,12 +536,19 @@ static int lower_config(const fwg_config& c, DevCfg* d, std::string* why) {
         d->init_max[v] = std::isnan(c.init_max[v]) ? 0.f : f32(c.init_max[v]);
         if (std::isfinite(c.con_min[v]) || std::isfinite(c.con_max[v])) d->con_mask |= 1u << v;
     }
-    for (int i = 0; i < 2; ++i) {
-        d->w0sq[i] = f32(c.elevon_omega0[i] * c.elevon_omega0[i]);
-        d->two_zeta_w0[i] = f32(2.0 * c.elevon_zeta[i] * c.elevon_omega0[i]);
-        d->dot_max[i] = std::isfinite(c.elevon_dot_max[i]) ? f32(c.elevon_dot_max[i]) : INFINITY;
+    if (c.actuator_microsteps < 2 * c.n_substeps || c.actuator_microsteps % (2 * c.n_substeps) != 0) {
+        *why = "actuator_microsteps must be a positive multiple of 2*n_substeps"; return -1;
     }
-    d->inv_tau = f32(1.0 / c.throttle_tau);
+    d->act_per_half = c.actuator_microsteps / (2 * c.n_substeps);
+    const double hm = c.dt / c.actuator_microsteps;
+    for (int i = 0; i < 2; ++i) {
+        double phi[4];
+        expm2(0.0, 1.0, -c.elevon_omega0[i] * c.elevon_omega0[i], -2.0 * c.elevon_zeta[i] * c.elevon_omega0[i], hm, phi);
+        for (int j = 0; j < 4; ++j) d->act_phi[i][j] = f32(phi[j]);
+        d->dot_max[i] = std::isfinite(c.elevon_dot_max[i]) ? f32(c.elevon_dot_max[i]) : INFINITY;
+        d->act_travel[i] = std::isfinite(c.elevon_dot_max[i]) ? f32(c.elevon_dot_max[i] * hm) : INFINITY;
+    }
+    d->act_ethr = f32(exp(-hm / c.throttle_tau));
     for (int i = 0; i < FWG_N_DRYDEN * FWG_N_DRYDEN; ++i) d->dryA[i] = f32(c.dryden_A[i]);
     for (int i = 0; i < FWG_N_DRYDEN * 4; ++i) d->dryB[i] = f32(c.dryden_B[i]);
     for (int i = 0; i < 6 * FWG_N_DRYDEN; ++i) d->dryC[i] = f32(c.dryden_C[i]);

@@ -44,7 +44,8 @@ struct DevCfg {
     float val_min[FWG_N_VARS], val_max[FWG_N_VARS];
     float init_min[FWG_N_VARS], init_max[FWG_N_VARS];
     unsigned con_mask;  // bit v set when variable v has a constraint
-    float w0sq[2], two_zeta_w0[2], dot_max[2], inv_tau;
+    float act_phi[2][4], act_travel[2], dot_max[2], act_ethr;  // exact actuator transition over one micro-step
+    int act_per_half;
     float dryA[FWG_N_DRYDEN * FWG_N_DRYDEN], dryB[FWG_N_DRYDEN * 4], dryC[6 * FWG_N_DRYDEN];
     // ---- gym side
     int steps_max, obs_length, obs_step, n_obs, obs_dim, obs_noise;

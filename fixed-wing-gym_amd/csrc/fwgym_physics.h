@@ -41,9 +41,13 @@ __device__ __forceinline__ void check_var(const DevCfg& c, int& fail, int var, f
     }
 }
 
+#define NB 13  // rigid-body part of the state vector (quaternion, omega, position, body velocity)
+
+// d/dt of the 13 rigid-body states for the actuator deflections act = (elevon_right, elevon_left, throttle) at the
+// stage time (oracle/physics.py rhs)
 template <bool TURB>
-__device__ __forceinline__ void rhs(const DevCfg& c, const float (&y)[NY], const float (&sp)[3], const float (&wind)[3],
-                                    const float (&gust)[6], float (&dy)[NY], int& fail) {
+__device__ __forceinline__ void rhs(const DevCfg& c, const float (&y)[NB], const float (&act)[3], const float (&wind)[3],
+                                    const float (&gust)[6], float (&dy)[NB], int& fail) {
     const float e0 = y[0], e1 = y[1], e2 = y[2], e3 = y[3];
     const float p = y[4], q = y[5], r = y[6];
     const float u = y[10], v = y[11], w = y[12];
@@ -51,12 +55,7 @@ __device__ __forceinline__ void rhs(const DevCfg& c, const float (&y)[NY], const
 #pragma unroll
         for (int k = 0; k < 9; ++k) check_var(c, fail, FWG_V_OMEGA_P + k, y[4 + k]);
     }
-    // actuator states as the model sees them: value and rate limits applied on read
-    const float er = fclampf(y[13], c.val_min[FWG_V_ELEVON_RIGHT], c.val_max[FWG_V_ELEVON_RIGHT]);
-    const float el = fclampf(y[14], c.val_min[FWG_V_ELEVON_LEFT], c.val_max[FWG_V_ELEVON_LEFT]);
-    const float th = fclampf(y[15], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
-    const float erd = fclampf(y[16], -c.dot_max[0], c.dot_max[0]);
-    const float eld = fclampf(y[17], -c.dot_max[1], c.dot_max[1]);
+    const float er = act[0], el = act[1], th = act[2];
     const float elev = 0.5f * (er + el), ail = 0.5f * (el - er);
 
     const Rot R = rot_from_quat(e0, e1, e2, e3);
@@ -120,19 +119,31 @@ __device__ __forceinline__ void rhs(const DevCfg& c, const float (&y)[NY], const
     dy[10] = r * v - q * w + fx * c.inv_mass;
     dy[11] = p * w - r * u + fy * c.inv_mass;
     dy[12] = q * u - p * v + fz * c.inv_mass;
-    dy[13] = erd;
-    dy[14] = eld;
-    dy[15] = (sp[2] - th) * c.inv_tau;
-    dy[16] = c.w0sq[0] * (sp[0] - er) - c.two_zeta_w0[0] * erd;
-    dy[17] = c.w0sq[1] * (sp[1] - el) - c.two_zeta_w0[1] * eld;
 }
 
-__device__ __forceinline__ void sanitize_actuators(const DevCfg& c, float (&y)[NY]) {
-    y[13] = fclampf(y[13], c.val_min[FWG_V_ELEVON_RIGHT], c.val_max[FWG_V_ELEVON_RIGHT]);
-    y[14] = fclampf(y[14], c.val_min[FWG_V_ELEVON_LEFT], c.val_max[FWG_V_ELEVON_LEFT]);
-    y[15] = fclampf(y[15], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
-    y[16] = fclampf(y[16], -c.dot_max[0], c.dot_max[0]);
-    y[17] = fclampf(y[17], -c.dot_max[1], c.dot_max[1]);
+// one actuator micro-step with the command held: exact linear response (2x2 transition per elevon, exponential for
+// the throttle), then the rate limit -- on the rate and on the travel over the micro-step -- and the value limits
+// (oracle/physics.py advance_actuators).  a = (elevon_r, elevon_l, throttle, elevon_r_rate, elevon_l_rate)
+__device__ __forceinline__ void advance_actuators(const DevCfg& c, float (&a)[5], const float (&sp)[3]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float x0 = a[k] - sp[k], x1 = a[3 + k];
+        float v = sp[k] + c.act_phi[k][0] * x0 + c.act_phi[k][1] * x1;
+        float d = c.act_phi[k][2] * x0 + c.act_phi[k][3] * x1;
+        d = fclampf(d, -c.dot_max[k], c.dot_max[k]);
+        v = fclampf(v, a[k] - c.act_travel[k], a[k] + c.act_travel[k]);
+        a[k] = fclampf(v, c.val_min[FWG_V_ELEVON_RIGHT + k], c.val_max[FWG_V_ELEVON_RIGHT + k]);
+        a[3 + k] = d;
+    }
+    a[2] = fclampf(sp[2] + c.act_ethr * (a[2] - sp[2]), c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
+}
+
+__device__ __forceinline__ void sanitize_actuators(const DevCfg& c, float (&a)[5]) {
+    a[0] = fclampf(a[0], c.val_min[FWG_V_ELEVON_RIGHT], c.val_max[FWG_V_ELEVON_RIGHT]);
+    a[1] = fclampf(a[1], c.val_min[FWG_V_ELEVON_LEFT], c.val_max[FWG_V_ELEVON_LEFT]);
+    a[2] = fclampf(a[2], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
+    a[3] = fclampf(a[3], -c.dot_max[0], c.dot_max[0]);
+    a[4] = fclampf(a[4], -c.dot_max[1], c.dot_max[1]);
 }
 
 // elevator/aileron/throttle commands -> constrained inputs (the "command" history of the reference,
@@ -166,33 +177,53 @@ __device__ __forceinline__ Derived derive(const float (&y)[NY], const float (&wi
 #define FWG_STAGE_UNROLL 1
 #endif
 
-// One env step (dt): classical RK4 with c.nsub sub-steps; on success y holds the new state, otherwise y is
-// untouched.  Returns the failure code (0 = ok, var+1 = violated constraint, FWG_TERM_NAN+1 = non-finite).
+// One env step (dt) -- the scheme of oracle/physics.py sim_step: actuators advanced exactly over c.act_micro
+// micro-steps, rigid body by c.nsub classical RK4 steps whose stages see the actuator deflections at t, t+h/2,
+// t+h/2, t+h.  On success y holds the new state, otherwise y is untouched.  Returns the failure code (0 = ok,
+// var+1 = violated constraint, FWG_TERM_NAN - FWG_TERM_VAR0 + 1 = non-finite).
 template <bool TURB>
 __device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const float (&sp)[3], const float (&wind)[3],
                                         const float (&gust)[6], Derived& d) {
-    float yy[NY];
+    float yb[NB], a[5];
 #pragma unroll
-    for (int i = 0; i < NY; ++i) yy[i] = y[i];
+    for (int i = 0; i < NB; ++i) yb[i] = y[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) a[i] = y[NB + i];
+    sanitize_actuators(c, a);
     int fail = 0;
     for (int s = 0; s < c.nsub; ++s) {
-        float acc[NY], ys[NY], k[NY];
+        float a_half[5], a_full[5];
 #pragma unroll
-        for (int i = 0; i < NY; ++i) { acc[i] = 0.f; ys[i] = yy[i]; }
+        for (int i = 0; i < 5; ++i) a_half[i] = a[i];
+        for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_half, sp);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a_full[i] = a_half[i];
+        for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_full, sp);
+        float acc[NB], ys[NB], k[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { acc[i] = 0.f; ys[i] = yb[i]; }
 #pragma unroll FWG_STAGE_UNROLL
         for (int st = 0; st < 4; ++st) {
-            rhs<TURB>(c, ys, sp, wind, gust, k, fail);
+            float act[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) act[i] = (st == 0) ? a[i] : ((st == 3) ? a_full[i] : a_half[i]);
+            rhs<TURB>(c, ys, act, wind, gust, k, fail);
             const float bw = (st == 0 || st == 3) ? c.h_sixth : 2.f * c.h_sixth;
             const float aw = (st == 2) ? c.h : c.half_h;
 #pragma unroll
-            for (int i = 0; i < NY; ++i) { acc[i] += bw * k[i]; ys[i] = yy[i] + aw * k[i]; }
+            for (int i = 0; i < NB; ++i) { acc[i] += bw * k[i]; ys[i] = yb[i] + aw * k[i]; }
         }
 #pragma unroll
-        for (int i = 0; i < NY; ++i) yy[i] += acc[i];
-        sanitize_actuators(c, yy);
+        for (int i = 0; i < NB; ++i) yb[i] += acc[i];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a[i] = a_full[i];
     }
-    const float rn = frsq(yy[0] * yy[0] + yy[1] * yy[1] + yy[2] * yy[2] + yy[3] * yy[3]);
-    yy[0] *= rn; yy[1] *= rn; yy[2] *= rn; yy[3] *= rn;
+    float yy[NY];
+    const float rn = frsq(yb[0] * yb[0] + yb[1] * yb[1] + yb[2] * yb[2] + yb[3] * yb[3]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) yy[i] = (i < 4) ? yb[i] * rn : yb[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) yy[NB + i] = a[i];
     if (c.con_mask & 0xFF8u) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) check_var(c, fail, FWG_V_OMEGA_P + k, yy[4 + k]);
@@ -203,10 +234,10 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const f
         check_var(c, fail, FWG_V_YAW, dn.yaw); check_var(c, fail, FWG_V_VA, dn.Va);
         check_var(c, fail, FWG_V_ALPHA, dn.alpha); check_var(c, fail, FWG_V_BETA, dn.beta);
     }
-    float chk = 0.f;
+    bool finite = true;
 #pragma unroll
-    for (int i = 0; i < NY; ++i) chk += yy[i] * 0.f;  // NaN/Inf propagate into chk
-    if (fail == 0 && !(chk == 0.f)) fail = FWG_TERM_NAN - FWG_TERM_VAR0 + 1;
+    for (int i = 0; i < NY; ++i) finite = finite && (fabsf(yy[i]) <= 3.0e38f);
+    if (fail == 0 && !finite) fail = FWG_TERM_NAN - FWG_TERM_VAR0 + 1;
     if (fail == 0) {
 #pragma unroll
         for (int i = 0; i < NY; ++i) y[i] = yy[i];

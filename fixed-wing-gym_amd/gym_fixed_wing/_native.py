@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 3
+FWG_ABI_VERSION = 4
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -81,7 +81,7 @@ class Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("struct_bytes", C.c_uint32),
         ("dt", C.c_double), ("rho", C.c_double), ("g", C.c_double),
-        ("n_substeps", C.c_int32), ("turbulence", C.c_int32),
+        ("n_substeps", C.c_int32), ("actuator_microsteps", C.c_int32), ("turbulence", C.c_int32), ("pad_sim_", C.c_int32),
         ("param", C.c_double * N_PARAMS),
         ("con_min", C.c_double * N_VARS), ("con_max", C.c_double * N_VARS),
         ("val_min", C.c_double * N_VARS), ("val_max", C.c_double * N_VARS),
@@ -139,6 +139,12 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise NativeError("HIP library {} not found: build it first (python -c 'import __graft_entry__ as g; "
                           "g.build()'); there is no CPU fallback".format(path))
+    try:
+        # PyTorch-ROCm bundles its own HIP runtime; it must be the one already mapped when libfwgym.so resolves
+        # libamdhip64, otherwise the process ends up with two runtimes and no visible device
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name in EXPORTS:
         if not hasattr(lib, name):

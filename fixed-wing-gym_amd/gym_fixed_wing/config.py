@@ -316,7 +316,8 @@ class EnvConfig(object):
         integ = self.sim_cfg.get("integrator", {})
         if integ.get("method", "rk4") != "rk4":
             raise NotImplementedError("integrator method {}".format(integ.get("method")))
-        c.n_substeps = int(integ.get("substeps", 4))
+        c.n_substeps = int(integ.get("substeps", 1))
+        c.actuator_microsteps = int(integ.get("actuator_microsteps", 16))
         c.turbulence = int(self.turbulence)
         for i, p in enumerate(nat.PARAMS):
             c.param[i] = float(self.params[p])

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 3
+#define FWG_ABI_VERSION 4
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -135,8 +135,10 @@ typedef struct fwg_config {
 
     /* ---- simulator (replaces the PyFly object built at fixed_wing.py:41-46) */
     double dt, rho, g;
-    int32_t n_substeps;     /* RK4 sub-steps per env step */
+    int32_t n_substeps;     /* RK4 steps of the 13 rigid-body states per env step */
+    int32_t actuator_microsteps; /* exact actuator micro-steps per env step (multiple of 2*n_substeps) */
     int32_t turbulence;     /* sim_config_kw["turbulence"] (examples/evaluate_controller.py:78) */
+    int32_t pad_sim_;
     double param[FWG_N_PARAMS];
     double con_min[FWG_N_VARS], con_max[FWG_N_VARS];    /* Variable.constraint_min/max  */
     double val_min[FWG_N_VARS], val_max[FWG_N_VARS];    /* Variable.value_min/max       */

@@ -49,7 +49,9 @@ class SimSpec:
         self.g = float(sim_cfg["g"])
         integ = sim_cfg.get("integrator", {})
         assert integ.get("method", "rk4") == "rk4"
-        self.nsub = int(integ.get("substeps", 4))
+        self.nsub = int(integ.get("substeps", 1))
+        self.act_micro = int(integ.get("actuator_microsteps", 16))
+        assert self.act_micro % (2 * self.nsub) == 0, "actuator_microsteps must be a multiple of 2*substeps"
         self.params = {k: float(params[k]) for k in AERO_KEYS}
         self.turbulence = bool(sim_cfg.get("turbulence", False))
         self.turbulence_intensity = sim_cfg.get("turbulence_intensity", "light")
@@ -200,29 +202,24 @@ def _check(spec, fail, name, x):
     return np.where((fail == 0) & bad, i + 1, fail)
 
 
-def rhs(spec, y, setpoint, wind_ned, gust, fail):
-    """dy/dt for y[N,18]; setpoint[N,3] = constrained (elevon_right, elevon_left, throttle) commands;
-    gust[N,6] = body-frame Dryden sample (u,v,w linear, p,q,r angular) held over the env step.
+def rhs(spec, yb, act, wind_ned, gust, fail):
+    """d/dt of the 13 rigid-body states yb[N,13] (quaternion, omega, position, body velocity) for actuator deflections
+    act[N,3] = (elevon_right, elevon_left, throttle) at the stage time; gust[N,6] = body-frame Dryden sample
+    (u,v,w linear, p,q,r angular) held over the env step.
     `fail` is the sticky per-env failure code (0 = ok, var_id+1 = first violated constraint)."""
     P = spec.params
-    q4, om, vel = y[:, IQ], y[:, IW], y[:, IV]
+    q4, om, vel = yb[:, IQ], yb[:, IW], yb[:, IV]
     p, q, r = om[:, 0], om[:, 1], om[:, 2]
     u, v, w = vel[:, 0], vel[:, 1], vel[:, 2]
 
     # constraint checks on the stage state (PyFly applies Variable constraints whenever states are set from the
     # ODE solution, also at intermediate stages -- SURVEY.md App. B.2 "Constraints")
-    stage_vals = {"omega_p": p, "omega_q": q, "omega_r": r, "position_n": y[:, 7], "position_e": y[:, 8],
-                  "position_d": y[:, 9], "velocity_u": u, "velocity_v": v, "velocity_w": w}
+    stage_vals = {"omega_p": p, "omega_q": q, "omega_r": r, "position_n": yb[:, 7], "position_e": yb[:, 8],
+                  "position_d": yb[:, 9], "velocity_u": u, "velocity_v": v, "velocity_w": w}
     for name in _STAGE_CHECK:
         fail = _check(spec, fail, name, stage_vals[name])
 
-    # actuator states as seen by the model: clipped value and rate
-    er = _lim(y[:, 13], spec.val_min[VAR_ID["elevon_right"]], spec.val_max[VAR_ID["elevon_right"]])
-    el = _lim(y[:, 14], spec.val_min[VAR_ID["elevon_left"]], spec.val_max[VAR_ID["elevon_left"]])
-    th = _lim(y[:, 15], spec.val_min[VAR_ID["throttle"]], spec.val_max[VAR_ID["throttle"]])
-    aR, aL, aT = spec.act["elevon_right"], spec.act["elevon_left"], spec.act["throttle"]
-    erd = np.clip(y[:, 16], -aR["dot_max"], aR["dot_max"])
-    eld = np.clip(y[:, 17], -aL["dot_max"], aL["dot_max"])
+    er, el, th = act[:, 0], act[:, 1], act[:, 2]
     elevator, aileron = 0.5 * (er + el), 0.5 * (el - er)
     rudder = 0.0
 
@@ -276,7 +273,7 @@ def rhs(spec, y, setpoint, wind_ned, gust, fail):
     n_ = pre * P["b"] * (P["C_n_0"] + P["C_n_beta"] * beta + P["C_n_p"] * bv * pa + P["C_n_r"] * bv * ra
                          + P["C_n_delta_a"] * aileron + P["C_n_delta_r"] * rudder)
 
-    # wind -> body: R_y(alpha)^T-style rotation of (-D, Y, -L) through (alpha, beta)
+    # wind -> body: rotation of (-D, Y, -L) through (alpha, beta)
     fx_a = ca * cb * (-f_drag) - ca * sb * f_y - sa * (-f_lift)
     fy_a = sb * (-f_drag) + cb * f_y
     fz_a = sa * cb * (-f_drag) - sa * sb * f_y + ca * (-f_lift)
@@ -288,7 +285,7 @@ def rhs(spec, y, setpoint, wind_ned, gust, fail):
     fx, fy, fz = f_prop + fgx + fx_a, fgy + fy_a, fgz + fz_a
     l_ = l_ + tau_prop
 
-    dy = np.empty_like(y)
+    dy = np.empty_like(yb)
     # quaternion kinematics
     dy[:, 0] = 0.5 * (-p * e1 - q * e2 - r * e3)
     dy[:, 1] = 0.5 * (p * e0 + r * e2 - q * e3)
@@ -306,13 +303,41 @@ def rhs(spec, y, setpoint, wind_ned, gust, fail):
     dy[:, 10] = r * v - q * w + fx * im
     dy[:, 11] = p * w - r * u + fy * im
     dy[:, 12] = q * u - p * v + fz * im
-    # actuators
-    dy[:, 13] = erd
-    dy[:, 14] = eld
-    dy[:, 15] = (setpoint[:, 2] - th) / aT["tau"]
-    dy[:, 16] = aR["omega_0"] ** 2 * (setpoint[:, 0] - er) - 2 * aR["zeta"] * aR["omega_0"] * erd
-    dy[:, 17] = aL["omega_0"] ** 2 * (setpoint[:, 1] - el) - 2 * aL["zeta"] * aL["omega_0"] * eld
     return dy, fail
+
+
+def actuator_transition(spec, hh):
+    """Exact discretisation of the actuator models over one micro-step hh: per elevon the 2x2 matrix exponential of
+    x' = [[0, 1], [-w0^2, -2 zeta w0]] x with x = (value - command, rate); throttle exp(-hh/tau)."""
+    from scipy.linalg import expm
+    phis = []
+    for name in ("elevon_right", "elevon_left"):
+        a = spec.act[name]
+        A = np.array([[0.0, 1.0], [-a["omega_0"] ** 2, -2.0 * a["zeta"] * a["omega_0"]]])
+        phis.append(expm(A * hh))
+    return phis, float(np.exp(-hh / spec.act["throttle"]["tau"]))
+
+
+def advance_actuators(spec, a, setpoint, hh, trans):
+    """a[N,5] = (elevon_right, elevon_left, throttle, elevon_right_rate, elevon_left_rate) advanced by hh with the
+    command held: exact linear response, then the rate limit (on the rate AND on the travel over hh) and the value
+    limits."""
+    phis, ethr = trans
+    out = a.copy()
+    for k, name in enumerate(("elevon_right", "elevon_left")):
+        P_ = phis[k]
+        x0, x1 = a[:, k] - setpoint[:, k], a[:, 3 + k]
+        v = setpoint[:, k] + P_[0, 0] * x0 + P_[0, 1] * x1
+        d = P_[1, 0] * x0 + P_[1, 1] * x1
+        dm = spec.act[name]["dot_max"]
+        if np.isfinite(dm):
+            d = np.clip(d, -dm, dm)
+            v = np.clip(v, a[:, k] - dm * hh, a[:, k] + dm * hh)
+        out[:, k] = _lim(v, spec.val_min[VAR_ID[name]], spec.val_max[VAR_ID[name]])
+        out[:, 3 + k] = d
+    th = setpoint[:, 2] + ethr * (a[:, 2] - setpoint[:, 2])
+    out[:, 2] = _lim(th, spec.val_min[VAR_ID["throttle"]], spec.val_max[VAR_ID["throttle"]])
+    return out
 
 
 def sanitize_actuators(spec, y):
@@ -338,21 +363,35 @@ def sim_step(spec, y, cmd_inputs, wind_ned, gust):
 
     Returns (y_new, ok[N], fail_code[N], commands_constrained[N,3], derived dict).  Where ok is False y_new keeps the
     last valid state (SURVEY.md section 5 'Failure detection').
-    Integration: classical RK4 with `spec.nsub` equal sub-steps; actuator value/rate limits are applied inside the
-    right-hand side and to the state after every sub-step; the quaternion is re-normalised once per env step.
+    Integration scheme (identical in the HIP kernels): the actuators (stiff: fastest elevon pole ~ -310 1/s, and
+    piecewise-linear because of the rate limit) are advanced EXACTLY over `spec.act_micro` equal micro-steps of their
+    linear dynamics, with the rate/value limits applied after every micro-step; the 13 rigid-body states take
+    `spec.nsub` classical RK4 steps of h = dt/nsub whose stages see the actuator deflections at t, t+h/2, t+h/2, t+h
+    (micro-step boundaries).  The quaternion is re-normalised once per env step.
     """
     N = y.shape[0]
     cmd_c, setpoint = constrain_commands(spec, cmd_inputs)
     fail = np.zeros(N, dtype=np.int64)
     h = spec.dt / spec.nsub
-    yy = y.copy()
+    hm = spec.dt / spec.act_micro
+    per_half = spec.act_micro // (2 * spec.nsub)
+    trans = actuator_transition(spec, hm)
+    yb = y[:, 0:13].copy()
+    a = sanitize_actuators(spec, y)[:, 13:18]
     for _ in range(spec.nsub):
-        k1, fail = rhs(spec, yy, setpoint, wind_ned, gust, fail)
-        k2, fail = rhs(spec, yy + 0.5 * h * k1, setpoint, wind_ned, gust, fail)
-        k3, fail = rhs(spec, yy + 0.5 * h * k2, setpoint, wind_ned, gust, fail)
-        k4, fail = rhs(spec, yy + h * k3, setpoint, wind_ned, gust, fail)
-        yy = yy + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
-        yy = sanitize_actuators(spec, yy)
+        a_half = a
+        for _m in range(per_half):
+            a_half = advance_actuators(spec, a_half, setpoint, hm, trans)
+        a_full = a_half
+        for _m in range(per_half):
+            a_full = advance_actuators(spec, a_full, setpoint, hm, trans)
+        k1, fail = rhs(spec, yb, a[:, 0:3], wind_ned, gust, fail)
+        k2, fail = rhs(spec, yb + 0.5 * h * k1, a_half[:, 0:3], wind_ned, gust, fail)
+        k3, fail = rhs(spec, yb + 0.5 * h * k2, a_half[:, 0:3], wind_ned, gust, fail)
+        k4, fail = rhs(spec, yb + h * k3, a_full[:, 0:3], wind_ned, gust, fail)
+        yb = yb + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        a = a_full
+    yy = np.concatenate([yb, a], axis=1)
     qn = np.sqrt(np.sum(yy[:, IQ] ** 2, axis=1, keepdims=True))
     yy[:, IQ] = yy[:, IQ] / qn
     # end-of-step checks: rigid-body constraints, Euler-angle constraints, airspeed factors

@@ -90,6 +90,16 @@ class PyFly:
 
     # ------------------------------------------------------------------------------------------------------------------
     def _spec(self):
+        key = (bool(self.turbulence), self.turbulence_intensity,
+               tuple(getattr(v, p) for v in self.state.values()
+                     for p in ("constraint_min", "constraint_max", "value_min", "value_max", "init_min", "init_max")),
+               tuple(sorted((k, v) for k, v in self.params.items() if not isinstance(v, str))))
+        if getattr(self, "_spec_key", None) == key:
+            return self._spec_cache
+        self._spec_key, self._spec_cache = key, self._build_spec()
+        return self._spec_cache
+
+    def _build_spec(self):
         cfg = dict(self.cfg)
         cfg["turbulence"] = bool(self.turbulence)
         cfg["turbulence_intensity"] = self.turbulence_intensity
