@@ -40,12 +40,40 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Specialisation.  The static configuration of an environment (DevCfg: observation layout, reward factors, aircraft
+// constants, integrator setup ...) never changes after construction, so the build freezes the configurations it knows
+// about (csrc/generated/specs.inc, written by fwg_dump_spec through __graft_entry__.build()) into constexpr objects;
+// a kernel instantiated with SPEC >= 0 reads its configuration from that object and the compiler folds every
+// config-driven loop, branch and constant (no scalar loads, no descriptor interpretation).  SPEC = -1 is the generic
+// kernel reading the same structure from memory; fwg_create picks the specialised instance when the lowered
+// configuration is bit-identical to a frozen one.  Both run the same source.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SpecWords { unsigned w[sizeof(DevCfg) / 4]; };
+static_assert(sizeof(SpecWords) == sizeof(DevCfg), "DevCfg must be made of 32-bit members only");
+#if defined(FWG_WITH_SPECS)
+#include "generated/specs.inc"
+#else
+#define FWG_SPEC_LIST(X)
+#endif
+#define FWG_DEFINE_SPEC(i) static constexpr DevCfg kSpec##i = __builtin_bit_cast(DevCfg, kSpecWords##i);
+FWG_SPEC_LIST(FWG_DEFINE_SPEC)
+template <int SPEC> struct SpecCfg {
+    static __device__ __forceinline__ const DevCfg& get(const DevCfg* cp) { return *cp; }
+};
+#define FWG_SPEC_GETTER(i)                                                                                \
+    template <> struct SpecCfg<i> {                                                                       \
+        static __device__ __forceinline__ const DevCfg& get(const DevCfg*) { return kSpec##i; }           \
+    };
+FWG_SPEC_LIST(FWG_SPEC_GETTER)
+
+// ---------------------------------------------------------------------------------------------------------------------
 // step kernel
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool TURB>
-__global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp, const KArgs A) {
+template <bool TURB, int SPEC>
+__global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const DevCfg& c = *cp;
+    const DevCfg& c = SpecCfg<SPEC>::get(cp);
+    const DynCfg& dc = *dp;
     const int lane = threadIdx.x;
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
@@ -225,7 +253,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
         }
         // ---- target resampling / propagation (fixed_wing.py:397-404)
         if (resample || (c.resample_every > 0 && E.sft >= (unsigned)c.resample_every))
-            sample_targets(c, A, e, E, lds + M.vars, lane, nullptr);
+            sample_targets(c, dc, A, e, E, lds + M.vars, lane, nullptr);
         next_targets(c, E);
 #pragma unroll
         for (int k = 0; k < FWG_MAX_TARGETS; ++k)
@@ -338,7 +366,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
         __syncthreads();
         if (A.term_obs != nullptr) write_tile(lds + M.tile, A.term_obs, env0, A.N, c.obs_dim, lane, done_mask);
         __syncthreads();
-        if (c.auto_reset && done && valid) reset_env<TURB>(c, A, e, lane, E, lds, M, A.slot_end, A.slot_lag, A.bit_goal);
+        if (c.auto_reset && done && valid) reset_env<TURB>(c, dc, A, e, lane, E, lds, M, A.slot_end, A.slot_lag, A.bit_goal);
     }
     __syncthreads();
 
@@ -360,10 +388,11 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
 // ---------------------------------------------------------------------------------------------------------------------
 // reset kernel
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool TURB>
-__global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ cp, const KArgs A) {
+template <bool TURB, int SPEC>
+__global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const DevCfg& c = *cp;
+    const DevCfg& c = SpecCfg<SPEC>::get(cp);
+    const DynCfg& dc = *dp;
     const int lane = threadIdx.x;
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
@@ -374,7 +403,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     if (sel_mask == 0ull) return;
     Env E;
     load_env<TURB>(c, A.S, A.N, e, E);
-    if (sel) reset_env<TURB>(c, A, e, lane, E, lds, M, A.slot_end, A.slot_lag, A.bit_goal);
+    if (sel) reset_env<TURB>(c, dc, A, e, lane, E, lds, M, A.slot_end, A.slot_lag, A.bit_goal);
     __syncthreads();
     write_tile(lds + M.tile, A.obs, env0, A.N, c.obs_dim, lane, sel_mask);
     if (sel) {
@@ -406,7 +435,10 @@ static int fail_with(int code, const std::string& msg) { g_err = msg; return cod
 struct fwg_handle {
     fwg_config cfg;
     DevCfg h;
+    DynCfg hd;
+    int spec;  // index of the frozen configuration the lowered DevCfg equals, or -1
     DevCfg* d_cfg;
+    DynCfg* d_dyn;
     float* d_reduce;
     int* d_flag;
     float* arena;
@@ -489,8 +521,9 @@ static float lim32(double x, bool is_min) {
     return (float)x;
 }
 
-static int lower_config(const fwg_config& c, DevCfg* d, std::string* why) {
+static int lower_config(const fwg_config& c, DevCfg* d, DynCfg* dy, std::string* why) {
     memset(d, 0, sizeof(DevCfg));
+    memset(dy, 0, sizeof(DynCfg));
     const int use_cmd = compute_layout(c, &d->L, why);
     if (use_cmd < 0) return -1;
     const double* P = c.param;
@@ -532,8 +565,8 @@ static int lower_config(const fwg_config& c, DevCfg* d, std::string* why) {
     for (int v = 0; v < FWG_N_VARS; ++v) {
         d->con_min[v] = lim32(c.con_min[v], true); d->con_max[v] = lim32(c.con_max[v], false);
         d->val_min[v] = lim32(c.val_min[v], true); d->val_max[v] = lim32(c.val_max[v], false);
-        d->init_min[v] = std::isnan(c.init_min[v]) ? 0.f : f32(c.init_min[v]);
-        d->init_max[v] = std::isnan(c.init_max[v]) ? 0.f : f32(c.init_max[v]);
+        dy->init_min[v] = std::isnan(c.init_min[v]) ? 0.f : f32(c.init_min[v]);
+        dy->init_max[v] = std::isnan(c.init_max[v]) ? 0.f : f32(c.init_max[v]);
         if (std::isfinite(c.con_min[v]) || std::isfinite(c.con_max[v])) d->con_mask |= 1u << v;
     }
     if (c.actuator_microsteps < 2 * c.n_substeps || c.actuator_microsteps % (2 * c.n_substeps) != 0) {
@@ -587,9 +620,9 @@ static int lower_config(const fwg_config& c, DevCfg* d, std::string* why) {
         if (t.var < 0 || t.var >= FWG_N_VARS) { *why = "target variable"; return -1; }
         if (t.cls >= FWG_TGT_LINEAR) d->any_dynamic_target = 1;
         if (t.cls == FWG_TGT_COMPENSATE && t.var != FWG_V_VA) { *why = "class compensate is only defined for Va"; return -1; }
-        d->target[k] = DevTarget{t.var, t.cls, t.wrap, t.has_delta, t.has_bound, f32(t.low), f32(t.high), f32(t.delta), f32(t.bound),
-                                 f32(t.slope_low), f32(t.slope_high), f32(t.amplitude_low), f32(t.amplitude_high),
-                                 f32(t.period_low), f32(t.period_high)};
+        d->target[k] = DevTarget{t.var, t.cls, t.wrap, t.has_delta, t.has_bound, f32(t.bound)};
+        dy->target[k] = DynTarget{f32(t.low), f32(t.high), f32(t.delta), f32(t.slope_low), f32(t.slope_high),
+                                  f32(t.amplitude_low), f32(t.amplitude_high), f32(t.period_low), f32(t.period_high)};
     }
     d->reward_potential = c.reward_potential; d->step_fail_timesteps = c.step_fail_timesteps;
     d->step_fail_value = f32(c.step_fail_value);
@@ -607,6 +640,18 @@ static int lower_config(const fwg_config& c, DevCfg* d, std::string* why) {
     d->rise_low = f32(c.rise_low); d->rise_high = f32(c.rise_high);
     return 0;
 }
+
+// frozen configurations compiled into this library (host copies for matching)
+#define FWG_SPEC_HOST(i) &kSpecWords##i,
+static const SpecWords* const kSpecTable[] = {FWG_SPEC_LIST(FWG_SPEC_HOST) nullptr};
+static int match_spec(const DevCfg& d) {
+    for (int i = 0; kSpecTable[i] != nullptr; ++i)
+        if (memcmp(kSpecTable[i], &d, sizeof(DevCfg)) == 0) return i;
+    return -1;
+}
+
+template <bool IS_STEP>
+static void launch(const fwg_handle* h, const KArgs& A, hipStream_t stream);
 
 extern "C" {
 
@@ -629,7 +674,8 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     fwg_handle* h = new fwg_handle();
     h->cfg = *cfg;
     std::string why;
-    if (lower_config(*cfg, &h->h, &why) != 0) { delete h; return fail_with(FWG_ERR_INVALID, why); }
+    if (lower_config(*cfg, &h->h, &h->hd, &why) != 0) { delete h; return fail_with(FWG_ERR_INVALID, why); }
+    h->spec = match_spec(h->h);
     h->n_envs = n_envs; h->env_base = env_id_base; h->device = device; h->seed = 0; h->gstep = 0;
     h->arena = (float*)state_arena;
     const LdsMap M = lds_map(h->h.obs_dim, h->h.L.window, h->h.use_cmd_ring);
@@ -637,6 +683,8 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     if (h->lds_bytes > 64 * 1024) { delete h; return fail_with(FWG_ERR_INVALID, "observation too large for the LDS tile"); }
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipMalloc((void**)&h->d_cfg, sizeof(DevCfg)));
+    HIP_TRY(hipMalloc((void**)&h->d_dyn, sizeof(DynCfg)));
+    HIP_TRY(hipMemcpy(h->d_dyn, &h->hd, sizeof(DynCfg), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->d_reduce, sizeof(float) * FWG_N_REDUCE));
     HIP_TRY(hipMalloc((void**)&h->d_flag, sizeof(int)));
     HIP_TRY(hipMemcpy(h->d_cfg, &h->h, sizeof(DevCfg), hipMemcpyHostToDevice));
@@ -649,7 +697,7 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
 int fwg_destroy(fwg_handle* h) {
     if (!h) return FWG_OK;
     (void)hipSetDevice(h->device);
-    (void)hipFree(h->d_cfg); (void)hipFree(h->d_reduce); (void)hipFree(h->d_flag);
+    (void)hipFree(h->d_cfg); (void)hipFree(h->d_dyn); (void)hipFree(h->d_reduce); (void)hipFree(h->d_flag);
     delete h;
     return FWG_OK;
 }
@@ -659,13 +707,16 @@ int fwg_update_config(fwg_handle* h, const fwg_config* cfg) {
     if (cfg->abi_version != FWG_ABI_VERSION || cfg->struct_bytes != sizeof(fwg_config))
         return fail_with(FWG_ERR_ABI, "fwg_config version/size mismatch");
     DevCfg d;
+    DynCfg dy;
     std::string why;
-    if (lower_config(*cfg, &d, &why) != 0) return fail_with(FWG_ERR_INVALID, why);
+    if (lower_config(*cfg, &d, &dy, &why) != 0) return fail_with(FWG_ERR_INVALID, why);
     if (memcmp(&d.L, &h->h.L, sizeof(fwg_layout)) != 0 || d.obs_dim != h->h.obs_dim)
         return fail_with(FWG_ERR_INVALID, "fwg_update_config must not change the state layout");
-    h->cfg = *cfg; h->h = d;
+    h->cfg = *cfg; h->h = d; h->hd = dy;
+    h->spec = match_spec(h->h);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpy(h->d_cfg, &h->h, sizeof(DevCfg), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_dyn, &h->hd, sizeof(DynCfg), hipMemcpyHostToDevice));
     return FWG_OK;
 }
 
@@ -700,9 +751,7 @@ int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const
     base_args(h, &A);
     A.mask = mask; A.init_state = init_state; A.init_target = init_target; A.obs = obs_out;
     fill_slots(h, h->gstep - 1, &A);  // initial records take the ring position of the last completed step
-    const dim3 grid((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), block(FWG_WAVE);
-    if (h->h.turbulence) hipLaunchKernelGGL(k_reset<true>, grid, block, h->lds_bytes, (hipStream_t)stream, h->d_cfg, A);
-    else hipLaunchKernelGGL(k_reset<false>, grid, block, h->lds_bytes, (hipStream_t)stream, h->d_cfg, A);
+    launch<false>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return FWG_OK;
 }
@@ -715,9 +764,7 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
     A.actions = actions; A.obs = obs_out; A.rew = reward_out; A.done = done_out; A.term = term_code_out;
     A.term_obs = terminal_obs_out; A.metrics = metrics_out; A.tgt_out = target_out;
     fill_slots(h, h->gstep, &A);
-    const dim3 grid((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), block(FWG_WAVE);
-    if (h->h.turbulence) hipLaunchKernelGGL(k_step<true>, grid, block, h->lds_bytes, (hipStream_t)stream, h->d_cfg, A);
-    else hipLaunchKernelGGL(k_step<false>, grid, block, h->lds_bytes, (hipStream_t)stream, h->d_cfg, A);
+    launch<true>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     h->gstep += 1;
     return FWG_OK;
@@ -743,4 +790,44 @@ int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream) {
     return FWG_OK;
 }
 
+int fwg_spec_index(const fwg_handle* h) { return h ? h->spec : -1; }
+int fwg_num_specs(void) {
+    int n = 0;
+    while (kSpecTable[n] != nullptr) ++n;
+    return n;
+}
+
+int fwg_dump_spec(const fwg_config* cfg, uint32_t* words_out, int64_t capacity) {
+    if (!cfg || !words_out) return fail_with(FWG_ERR_INVALID, "null argument");
+    if (cfg->abi_version != FWG_ABI_VERSION || cfg->struct_bytes != sizeof(fwg_config))
+        return fail_with(FWG_ERR_ABI, "fwg_config version/size mismatch");
+    DevCfg d;
+    DynCfg dy;
+    std::string why;
+    if (lower_config(*cfg, &d, &dy, &why) != 0) return fail_with(FWG_ERR_INVALID, why);
+    const int64_t n = (int64_t)(sizeof(DevCfg) / 4);
+    if (capacity < n) return fail_with(FWG_ERR_INVALID, "fwg_dump_spec: buffer too small");
+    memcpy(words_out, &d, sizeof(DevCfg));
+    return (int)n;
+}
+
 }  // extern "C"
+
+template <bool IS_STEP, bool TURB, int SPEC>
+static void launch_one(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
+    const dim3 grid((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), block(FWG_WAVE);
+    if (IS_STEP) hipLaunchKernelGGL((k_step<TURB, SPEC>), grid, block, h->lds_bytes, stream, h->d_cfg, h->d_dyn, A);
+    else hipLaunchKernelGGL((k_reset<TURB, SPEC>), grid, block, h->lds_bytes, stream, h->d_cfg, h->d_dyn, A);
+}
+
+template <bool IS_STEP>
+static void launch(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
+    switch (h->spec) {
+#define FWG_SPEC_CASE(i) \
+    case i: launch_one<IS_STEP, (kSpec##i.turbulence != 0), i>(h, A, stream); return;
+        FWG_SPEC_LIST(FWG_SPEC_CASE)
+        default: break;
+    }
+    if (h->h.turbulence) launch_one<IS_STEP, true, -1>(h, A, stream);
+    else launch_one<IS_STEP, false, -1>(h, A, stream);
+}

@@ -20,12 +20,17 @@
 #define FWG_STREAM_INIT_NOISE 5u
 
 struct DevObs { int type, src, window, norm; float mean, inv_var; };
-struct DevTarget {
-    int var, cls, wrap, has_delta, has_bound;
-    float low, high, delta, bound, slope_low, slope_high, amp_low, amp_high, period_low, period_high;
+struct DevTarget { int var, cls, wrap, has_delta, has_bound; float bound; };
+// ranges that set_curriculum_level rescales (fixed_wing.py:224-285): kept OUT of the compile-time-specialisable block
+struct DynTarget { float low, high, delta, slope_low, slope_high, amp_low, amp_high, period_low, period_high; };
+struct DynCfg {
+    float init_min[FWG_N_VARS], init_max[FWG_N_VARS];
+    DynTarget target[FWG_MAX_TARGETS];
 };
 struct DevFactor { int cls, type, src, fclass, shaping, window, has_max, value_is_timesteps; float sign, inv_scaling, max, value; };
 
+// Static configuration.  Every member is a 32-bit int/float (no padding), so that a lowered instance can be frozen into
+// a constexpr object (see "specialisation" in fwgym.hip) and the compiler folds every branch/constant driven by it.
 struct DevCfg {
     // ---- simulator, pre-combined in double on the host
     float dt, h, half_h, h_sixth;
@@ -42,7 +47,6 @@ struct DevCfg {
     float kprop, kmotor, ktp;
     float con_min[FWG_N_VARS], con_max[FWG_N_VARS];
     float val_min[FWG_N_VARS], val_max[FWG_N_VARS];
-    float init_min[FWG_N_VARS], init_max[FWG_N_VARS];
     unsigned con_mask;  // bit v set when variable v has a constraint
     float act_phi[2][4], act_travel[2], dot_max[2], act_ethr;  // exact actuator transition over one micro-step
     int act_per_half;

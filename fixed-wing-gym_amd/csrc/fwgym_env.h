@@ -233,8 +233,8 @@ __device__ __forceinline__ void goal_push(const DevCfg& c, Env& E, unsigned g, i
 }
 
 // sample_target (fixed_wing.py:461-521); `given` (nullable) holds explicit targets for reset(target=...)
-__device__ __forceinline__ void sample_targets(const DevCfg& c, const KArgs& A, long e, Env& E, const float* vars, int lane,
-                                               const float* given) {
+__device__ __forceinline__ void sample_targets(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, Env& E,
+                                               const float* vars, int lane, const float* given) {
     const unsigned env_id = (unsigned)(A.env_base + e);
     const unsigned resample = E.flags >> FWG_FLAG_RESAMPLE_SHIFT;
     E.sft = 0;
@@ -242,12 +242,13 @@ __device__ __forceinline__ void sample_targets(const DevCfg& c, const KArgs& A, 
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
         if (k >= c.n_targets) continue;
         const DevTarget& t = c.target[k];
+        const DynTarget& r = dc.target[k];
         const u4 b = philox4x32(env_id, E.episode, resample, FWG_STREAM_RESET_TARGET + 256u * k, A.seed_lo, A.seed_hi);
-        float low = t.low, high = t.high;
+        float low = r.low, high = r.high;
         if (t.has_delta) {
             const float x = vars[t.var * FWG_WAVE + lane];
-            low = fmaxf(low, x - t.delta);
-            high = fmaxf(fminf(high, x + t.delta), low);
+            low = fmaxf(low, x - r.delta);
+            high = fmaxf(fminf(high, x + r.delta), low);
         }
         float v = low + (high - low) * u01(b.x);
         int cls = t.cls;
@@ -261,11 +262,11 @@ __device__ __forceinline__ void sample_targets(const DevCfg& c, const KArgs& A, 
         if (c.any_dynamic_target) {
             float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
             if (cls == FWG_TGT_LINEAR) {
-                p0 = t.slope_low + (t.slope_high - t.slope_low) * u01(b.y);
+                p0 = r.slope_low + (r.slope_high - r.slope_low) * u01(b.y);
                 if (u01(b.z) < 0.5f) p0 = -p0;
             } else if (cls == FWG_TGT_SINUSOIDAL) {
-                p0 = t.amp_low + (t.amp_high - t.amp_low) * u01(b.y);
-                p1 = t.period_low + (t.period_high - t.period_low) * u01(b.z);
+                p0 = r.amp_low + (r.amp_high - r.amp_low) * u01(b.y);
+                p1 = r.period_low + (r.period_high - r.period_low) * u01(b.z);
                 p2 = (FWG_TWO_PI * u01(b.w)) / (FWG_TWO_PI / p1);
                 p3 = v - p0 * sinf(FWG_TWO_PI / p1 * ((float)E.steps + p2));
             } else if (t.cls >= FWG_TGT_LINEAR) {
@@ -418,8 +419,8 @@ __device__ __forceinline__ void add_obs_noise(const DevCfg& c, const KArgs& A, l
 // FixedWingAircraft.reset (fixed_wing.py:287-336) for one lane; `g_*` are the ring positions of the LAST completed
 // global step.  Fills E, the tile column of this lane (all rows) and the ring slots that hold initial records.
 template <bool TURB>
-__device__ __forceinline__ void reset_env(const DevCfg& c, const KArgs& A, long e, int lane, Env& E, float* lds,
-                                          const LdsMap& M, int g_end, int g_lag, int g_bit) {
+__device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, int lane, Env& E,
+                                          float* lds, const LdsMap& M, int g_end, int g_lag, int g_bit) {
     const unsigned env_id = (unsigned)(A.env_base + e);
     E.episode += 1u;
     E.steps = 0u;
@@ -434,7 +435,7 @@ __device__ __forceinline__ void reset_env(const DevCfg& c, const KArgs& A, long 
         for (int i = 0; i < 4; ++i) {
             const int v = blk * 4 + i;
             if (v < FWG_N_RESET_VARS) {
-                float x = c.init_min[v] + (c.init_max[v] - c.init_min[v]) * u01(bits[i]);
+                float x = dc.init_min[v] + (dc.init_max[v] - dc.init_min[v]) * u01(bits[i]);
                 if (A.init_state != nullptr) {
                     const float gx = A.init_state[(long)v * A.N + e];
                     if (gx == gx) x = gx;
@@ -468,7 +469,7 @@ __device__ __forceinline__ void reset_env(const DevCfg& c, const KArgs& A, long 
     E.d = derive<false>(E.y, E.wind, gust0);
     fill_vars(E, lds + M.vars, lane);
     // ---- targets
-    sample_targets(c, A, e, E, lds + M.vars, lane, A.init_target);
+    sample_targets(c, dc, A, e, E, lds + M.vars, lane, A.init_target);
     float err[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {

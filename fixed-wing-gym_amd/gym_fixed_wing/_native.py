@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 4
+FWG_ABI_VERSION = 5
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -126,7 +126,8 @@ class NativeError(RuntimeError):
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libfwgym.so")
 EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fwg_update_config", "fwg_seed",
-           "fwg_reset", "fwg_step", "fwg_check_actions", "fwg_reduce_success", "fwg_global_step", "fwg_last_error"]
+           "fwg_reset", "fwg_step", "fwg_check_actions", "fwg_reduce_success", "fwg_global_step", "fwg_last_error",
+           "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index"]
 _libs = {}
 
 
@@ -163,6 +164,11 @@ def load_library(path=None):
     lib.fwg_global_step.argtypes = [vp]
     lib.fwg_global_step.restype = i64
     lib.fwg_last_error.restype = C.c_char_p
+    lib.fwg_dump_spec.argtypes = [C.POINTER(Config), C.POINTER(C.c_uint32), i64]
+    lib.fwg_dump_spec.restype = C.c_int
+    lib.fwg_num_specs.restype = C.c_int
+    lib.fwg_spec_index.argtypes = [vp]
+    lib.fwg_spec_index.restype = C.c_int
     for name in ("fwg_get_layout", "fwg_create", "fwg_destroy", "fwg_update_config", "fwg_seed", "fwg_reset",
                  "fwg_step", "fwg_check_actions", "fwg_reduce_success"):
         getattr(lib, name).restype = C.c_int

@@ -1,0 +1,99 @@
+"""Named configuration presets: the feature mixes of the reference's shipped config variants expressed as edits of the
+package default (reference files: gym_fixed_wing/fixed_wing_config.json, fixed_wing_config_dev.json,
+examples/fixed_wing_config.json, examples/models/{mlp,cnn}_controller/fixed_wing_config.json), plus the two benchmark
+workloads of BASELINE.json.  Used by the build to freeze kernel specialisations and by tests/bench."""
+import copy
+import json
+
+from .config import DEFAULT_ENV_CONFIG
+
+
+def default():
+    with open(DEFAULT_ENV_CONFIG) as f:
+        return json.load(f)
+
+
+def preset(kind):
+    cfg = default()
+    if kind == "default":
+        return cfg
+    if kind in ("examples", "mlp", "cnn"):
+        obs = cfg["observation"]
+        del obs["noise"]
+        states = []
+        for ov in obs["states"]:
+            if ov["name"] in ("alpha", "beta"):
+                continue
+            ov = {k: v for k, v in ov.items() if k not in ("mean", "var")}
+            if ov["type"] == "target":
+                ov["value"] = "relative"
+            states.append(ov)
+        obs["states"] = states
+        for f in cfg["reward"]["factors"]:
+            if f["class"] == "state":
+                f.pop("max", None)
+            if f["class"] == "action" and f["type"] == "delta":
+                f["scaling"] = 45
+        for st in cfg["simulator"]["states"]:
+            if st["name"].startswith("omega"):
+                st["constraint_min"], st["constraint_max"] = -360, 360
+        if kind == "mlp":
+            cfg["action"]["scale_space"] = False
+            cfg["target"]["states"][0]["bound"] = 3
+            cfg["target"]["states"][1]["bound"] = 3
+        if kind in ("mlp", "cnn"):
+            for f in cfg["reward"]["factors"]:
+                if f["class"] == "state":
+                    f["max"] = 0.3
+                if f["class"] == "action" and f["type"] == "delta":
+                    f["scaling"] = 60
+        if kind == "cnn":
+            cfg.pop("integration_window", None)
+            obs["length"], obs["shape"] = 5, "matrix"
+            obs.pop("normalize", None)
+            for ov in obs["states"]:
+                if ov["name"] == "Va" and ov["type"] == "state":
+                    ov.pop("low", None)
+                    ov["high"] = 60
+                if ov["type"] == "action":
+                    ov.pop("norm", None)
+            for a in cfg["action"]["states"]:
+                a["low"], a["high"] = None, None
+            for st in cfg["simulator"]["states"]:
+                if st["name"].startswith("omega"):
+                    st["constraint_min"], st["constraint_max"] = -720, 720
+        return cfg
+    if kind == "dev":
+        cfg["observation"]["noise"]["var"] = 0.1
+        cfg["action"]["scale_space"] = False
+        cfg["target"]["states"][0]["bound"] = 3
+        cfg["target"]["states"][1]["bound"] = 3
+        cfg["simulator"]["states"] = [s for s in cfg["simulator"]["states"] if s["name"] != "Va"]
+        for st in cfg["simulator"]["states"]:
+            if st["name"].startswith("omega"):
+                st["constraint_min"], st["constraint_max"] = None, None
+        return cfg
+    raise KeyError(kind)
+
+
+# (name, preset kind, config_kw, sim_config_kw): configurations whose kernels are frozen at build time
+TURB_MODERATE = {"turbulence": True, "turbulence_intensity": "moderate"}
+SPECIALISED = [
+    ("c2_default", "default", None, None),                                   # BASELINE configs[1]
+    ("c3_cnn_step2_dryden", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),  # BASELINE configs[2]/[3]
+    ("c5_examples", "examples", None, None),                                 # BASELINE configs[4]
+]
+
+
+def workload(name):
+    """BASELINE.json workloads -> (config dict, config_kw, sim_config_kw, envs per GPU, description)."""
+    if name == "c3":
+        return (preset("cnn"), {"observation": {"step": 2}}, copy.deepcopy(TURB_MODERATE), 65536,
+                "C3: 65536 envs/GPU, Dryden turbulence moderate, obs 5x12 lag step 2, auto-reset, metrics on")
+    if name == "c2":
+        return (preset("default"), None, None, 4096,
+                "C2: 4096 envs/GPU, turbulence off, obs 14-vector, auto-reset, metrics on")
+    if name == "c5":
+        return (preset("examples"), None, None, 65536,
+                "C5: 65536 envs/GPU, examples config (obs 12-vector), turbulence off")
+    raise KeyError(name)

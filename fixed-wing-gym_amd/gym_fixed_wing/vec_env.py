@@ -150,6 +150,11 @@ class FixedWingVecEnv(object):
         self.env_config.set_curriculum_level(level)
         self._upload()
 
+    @property
+    def spec_index(self):
+        """Index of the build-time specialised kernel this env runs, -1 = generic kernel."""
+        return int(self._lib.fwg_spec_index(self._handle))
+
     def _upload(self):
         self._c = self.env_config.compile(auto_reset=self.auto_reset)
         nat.check(self._lib, self._lib.fwg_update_config(self._handle, ctypes.byref(self._c)))

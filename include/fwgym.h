@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 4
+#define FWG_ABI_VERSION 5
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -269,6 +269,14 @@ int fwg_check_actions(fwg_handle* h, const float* actions, void* stream);
  * examples/train_rl_controller.py:51-66,80-85; the caller all-gathers them over RCCL.  Synchronises the stream and
  * clears the accumulators. */
 int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream);
+
+/* Build-time specialisation support: writes the lowered STATIC configuration as 32-bit words (pure host function; the
+ * build freezes such word lists into constexpr objects, see csrc/fwgym.hip "Specialisation").  Returns the number of
+ * words, or a negative fwg_status. */
+int fwg_dump_spec(const fwg_config* cfg_host, uint32_t* words_out_host, int64_t capacity);
+/* Number of frozen configurations compiled into this library, and the one a handle runs (-1 = generic kernel). */
+int fwg_num_specs(void);
+int fwg_spec_index(const fwg_handle* h);
 
 /* Global step counter driving the ring slots (diagnostics/tests). */
 int64_t fwg_global_step(const fwg_handle* h);

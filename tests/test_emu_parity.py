@@ -33,6 +33,7 @@ def test_emulated_kernel_matches_oracle(emu_lib, case):
     n, steps = 5, 130
     vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True,
                           _backend=HostBackend(), _lib_path=emu_lib)
+    assert (vec.spec_index >= 0) == (name in configs.SPECIALISED_CASES), (name, vec.spec_index)
     orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
     acts = _actions(5, steps, n, scale=1.8 if name == "fail_prone" else 1.3)
     tol = 5e-2 if name == "dev_noise" else 4e-3

@@ -48,6 +48,7 @@ def test_gym_rollout_matches_oracle(case):
     cfg = configs.reference_like(kind)
     n, steps = 6, 130
     vec = _vec(cfg, n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True)
+    assert (vec.spec_index >= 0) == (name in configs.SPECIALISED_CASES), (name, vec.spec_index)
     orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
     acts = _actions(5, steps, n, scale=1.8 if name == "fail_prone" else 1.3)
     tol = 5e-2 if name == "dev_noise" else 4e-3
