@@ -69,47 +69,58 @@ FWG_SPEC_LIST(FWG_SPEC_GETTER)
 // ---------------------------------------------------------------------------------------------------------------------
 // step kernel
 // ---------------------------------------------------------------------------------------------------------------------
+template <int SPEC> struct KernelTypes {  // generic kernel: lane-private LDS columns addressed by run-time indices
+    typedef LdsTable Tab;
+    typedef LdsTable Obs;
+    static constexpr bool generic = true;
+    static __device__ __forceinline__ Tab tab(float* lds, const LdsMap& M, int lane) { return Tab{lds + M.tab + lane}; }
+    static __device__ __forceinline__ Obs obs(float* lds, const LdsMap& M, int lane) { return Obs{lds + M.obs + lane}; }
+};
+#define FWG_SPEC_TYPES(i)                                                                                     \
+    template <> struct KernelTypes<i> { /* specialised kernel: everything in registers */                     \
+        typedef RegTable<FWG_TAB_ROWS> Tab;                                                                   \
+        typedef RegTable<kSpec##i.obs_dim> Obs;                                                               \
+        static constexpr bool generic = false;                                                                \
+        static __device__ __forceinline__ Tab tab(float*, const LdsMap&, int) { return Tab(); }               \
+        static __device__ __forceinline__ Obs obs(float*, const LdsMap&, int) { return Obs(); }               \
+    };
+FWG_SPEC_LIST(FWG_SPEC_TYPES)
+
 template <bool TURB, int SPEC>
-__global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A) {
+__global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef KernelTypes<SPEC> KT;
     const DevCfg& c = SpecCfg<SPEC>::get(cp);
     const DynCfg& dc = *dp;
     const int lane = threadIdx.x;
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
     const long e = valid ? env0 + lane : A.N - 1;
-    const LdsMap M = lds_map(c.obs_dim, c.L.window, c.use_cmd_ring);
+    const LdsMap M = lds_map(c.obs_dim, c.L.window, c.use_cmd_ring, KT::generic);
     const fwg_layout& L = c.L;
     const int W = L.window;
+    typename KT::Tab T = KT::tab(lds, M, lane);
+    typename KT::Obs ob = KT::obs(lds, M, lane);
+    float* aring = lds + M.aring + lane;   // this lane's column of the raw-action window [slot*3 + actuator][lane]
+    float* cring = lds + M.cring + lane;   // ... of the constrained-command window (only when observations need it)
 
-    // ---- phase A: start the HBM -> LDS streams (lagged observation rows, action windows)
-    for (int r = 1; r < c.obs_length; ++r)
-        for (int j = 0; j < c.n_obs; ++j)
-            dma_row(&ROW(A.S, A.N, L.lag_ring + A.lag_slots[r] * c.n_obs + j, e), lds + M.tile + (r * c.n_obs + j) * FWG_TILE_STRIDE);
+    // ---- phase A: issue every load up front.  The action windows stream HBM -> LDS (global_load_lds, no VGPRs, they
+    // are addressed by the run-time ring slot); everything else goes to registers.
     for (int s = 0; s < W * 3; ++s) dma_row(&ROW(A.S, A.N, L.act_ring + s, e), lds + M.aring + s * FWG_WAVE);
     if (c.use_cmd_ring)
         for (int s = 0; s < W * 3; ++s) dma_row(&ROW(A.S, A.N, L.cmd_ring + s, e), lds + M.cring + s * FWG_WAVE);
-    // raw actions [N][3]: three coalesced row segments, de-interleaved below (stride-3 LDS reads are conflict-free)
-    {
-        const long base = env0 * 3;
-        const long lim = A.N * 3 - 1;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const long idx = base + i * FWG_WAVE + lane;
-            dma_row(A.actions + (idx < lim ? idx : lim), lds + M.ain + i * FWG_WAVE);
-        }
-    }
-    Env E;
-    load_env<TURB>(c, A.S, A.N, e, E);
-    dma_wait();
-
     float raw[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) raw[i] = lds[M.ain + lane * 3 + i];
+    for (int i = 0; i < 3; ++i) raw[i] = A.actions[e * 3 + i];   // [N][3]: a wave reads 768 contiguous bytes
+    Env E;
+    load_env<TURB>(c, A.S, A.N, e, E);
+    if (!KT::generic) load_lag_rows(c, A, e, ob);
+    dma_wait();
+
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        lds[M.aring + (A.slot_act * 3 + i) * FWG_WAVE + lane] = raw[i];
+        aring[(A.slot_act * 3 + i) * FWG_WAVE] = raw[i];
         if (valid) ROW(A.S, A.N, L.act_ring + A.slot_act * 3 + i, e) = raw[i];
     }
 
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
     if (c.use_cmd_ring) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            lds[M.cring + (A.slot_act * 3 + i) * FWG_WAVE + lane] = cmd_c[i];
+            cring[(A.slot_act * 3 + i) * FWG_WAVE] = cmd_c[i];
             if (valid) ROW(A.S, A.N, L.cmd_ring + A.slot_act * 3 + i, e) = cmd_c[i];
         }
     }
@@ -140,6 +151,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
     if (TURB) dryden_output(c, E.dry, gust);
     const int fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
     const bool ok = fail == 0;
+    if (!ok) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
     if (TURB && ok) {
         const u4 b = philox4x32((unsigned)(A.env_base + e), E.steps, E.episode, FWG_STREAM_TURB, A.seed_lo, A.seed_hi);
         float n[4];
@@ -153,11 +165,11 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
     bool done = false;
     unsigned term = FWG_TERM_NONE;
     if (c.steps_max > 0 && E.steps >= (unsigned)c.steps_max) { done = true; term = FWG_TERM_STEPS; }
-    fill_vars(E, lds + M.vars, lane);
+    fill_vars(E, T);
     float err[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k)
-        if (k < c.n_targets) err[k] = target_error(c.target[k], E.tgt[k], lds[M.vars + c.target[k].var * FWG_WAVE + lane]);
+        if (k < c.n_targets) err[k] = target_error(c.target[k], E.tgt[k], T.get(c.target[k].var));
     float reward = 0.f;
     const unsigned rec = E.steps;  // index of the record this step appends to the episode histories
     if (ok) {
@@ -175,7 +187,9 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
         }
         // ---- reward (fixed_wing.py:674-774)
         float nv[3] = {0.f, 0.f, 0.f}, sh[3] = {0.f, 0.f, 0.f};
-        for (int f = 0; f < c.n_factors; ++f) {
+#pragma unroll
+        for (int f = 0; f < FWG_MAX_FACTORS; ++f) {
+            if (f >= c.n_factors) continue;
             const DevFactor& F = c.factor[f];
             float val = 0.f;
             if (F.cls == FWG_RC_ACTION) {
@@ -183,14 +197,14 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
                 else if (F.type == FWG_RT_DELTA) {
                     if (E.steps > 1u) {
                         const int m = (int)min(E.steps, (unsigned)F.window);
-                        for (int k = W - 2; k >= 0; --k) {
-                            if (k <= m - 2) {
+#pragma unroll
+                        for (int k = FWG_MAX_WINDOW - 2; k >= 0; --k) {
+                            if (k <= W - 2 && k <= m - 2) {
                                 int s_new = A.slot_act - k; s_new += (s_new < 0) ? W : 0;
                                 int s_old = A.slot_act - k - 1; s_old += (s_old < 0) ? W : 0;
 #pragma unroll
                                 for (int i = 0; i < 3; ++i)
-                                    val += fabsf(lds[M.aring + (s_new * 3 + i) * FWG_WAVE + lane] -
-                                                 lds[M.aring + (s_old * 3 + i) * FWG_WAVE + lane]);
+                                    val += fabsf(aring[(s_new * 3 + i) * FWG_WAVE] - aring[(s_old * 3 + i) * FWG_WAVE]);
                             }
                         }
                     }
@@ -202,8 +216,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
                     }
                 }
             } else if (F.cls == FWG_RC_STATE) {
-                val = (F.type == FWG_RT_VALUE) ? lds[M.vars + F.src * FWG_WAVE + lane]
-                                               : (F.src == 0 ? err[0] : (F.src == 1 ? err[1] : err[2]));
+                val = (F.type == FWG_RT_VALUE) ? T.get(F.src) : (F.src == 0 ? err[0] : (F.src == 1 ? err[1] : err[2]));
             } else if (F.cls == FWG_RC_SUCCESS) {
                 val = achieved_now ? (F.value_is_timesteps ? (float)(c.steps_max - (int)E.steps) : F.value) : 0.f;
             } else if (F.cls == FWG_RC_STEP) {
@@ -253,11 +266,11 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
         }
         // ---- target resampling / propagation (fixed_wing.py:397-404)
         if (resample || (c.resample_every > 0 && E.sft >= (unsigned)c.resample_every))
-            sample_targets(c, dc, A, e, E, lds + M.vars, lane, nullptr);
+            sample_targets(c, dc, A, e, E, T, nullptr);
         next_targets(c, E);
 #pragma unroll
         for (int k = 0; k < FWG_MAX_TARGETS; ++k)
-            if (k < c.n_targets) err[k] = target_error(c.target[k], E.tgt[k], lds[M.vars + c.target[k].var * FWG_WAVE + lane]);
+            if (k < c.n_targets) err[k] = target_error(c.target[k], E.tgt[k], T.get(c.target[k].var));
         if (c.metrics) {  // streaming form of history["error"] (fixed_wing.py:1095-1157)
 #pragma unroll
             for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
@@ -280,16 +293,17 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
         if (k < c.n_targets) {
-            lds[M.tgt + k * FWG_WAVE + lane] = E.tgt[k];
-            lds[M.err + k * FWG_WAVE + lane] = err[k];
+            T.put(FWG_TAB_TGT + k, E.tgt[k]);
+            T.put(FWG_TAB_ERR + k, err[k]);
         }
     }
 
     // ---- phase D: observation (fixed_wing.py:776-846)
-    build_row0(c, A, e, lane, E, lds, M, A.slot_lag, ok, A.slot_act, valid);
+    if (KT::generic) load_lag_rows(c, A, e, ob);
+    build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid, A.slot_act);
     if (c.obs_length > 1 && (!ok || (int)E.steps <= (c.obs_length - 1) * c.obs_step))
-        fix_lagged_rows(c, A, e, lane, E, lds, M, ok);
-    if (c.obs_noise) add_obs_noise(c, A, e, lane, E, lds, M);
+        fix_lagged_rows(c, A, e, E, T, ob, ok);
+    if (c.obs_noise) add_obs_noise(c, A, e, E, ob);
 
     // ---- phase E: episode end -- metrics block, success reduction, terminal observation, auto-reset
     const unsigned long long done_mask = __ballot(done && valid);
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
                 if (c.goal_enabled) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool present = (r == 3) || (r < c.n_targets && c.target[r].has_bound);
+                        const bool present = (r == 3) || (r < c.n_targets && c.target[r < 3 ? r : 0].has_bound);
                         if (present) {
                             const unsigned st = pack16_get(E.settle, r);
                             mt[FWG_M_SETTLING_TIME + r] = st == 0xFFFFu ? NAN : (float)st;
@@ -355,6 +369,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
             } else {
                 red[0] = 1.f;
             }
+            if (A.term_obs != nullptr) write_obs(c, A.term_obs + e * c.obs_dim, ob, A.vec4 != 0);
         }
         // per-wave reduction by shuffles, one atomic per value per wave (the per-GPU part of the success reduction of
         // examples/train_rl_controller.py:51-66,80-85)
@@ -363,16 +378,13 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
             const float s = wave_sum(red[i]);
             if (lane == 0 && s != 0.f) atomicAdd(A.reduce + i, s);
         }
-        __syncthreads();
-        if (A.term_obs != nullptr) write_tile(lds + M.tile, A.term_obs, env0, A.N, c.obs_dim, lane, done_mask);
-        __syncthreads();
-        if (c.auto_reset && done && valid) reset_env<TURB>(c, dc, A, e, lane, E, lds, M, A.slot_end, A.slot_lag, A.bit_goal);
+        if (c.auto_reset && done && valid)
+            reset_env<TURB>(c, dc, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal);
     }
-    __syncthreads();
 
-    // ---- phase F: coalesced outputs and the state write-back
-    write_tile(lds + M.tile, A.obs, env0, A.N, c.obs_dim, lane, ~0ull);
+    // ---- phase F: outputs and the state write-back
     if (valid) {
+        write_obs(c, A.obs + e * c.obs_dim, ob, A.vec4 != 0);
         A.rew[e] = reward;
         A.done[e] = done ? 1 : 0;
         A.term[e] = (uint8_t)term;
@@ -391,28 +403,27 @@ __global__ __launch_bounds__(FWG_WAVE) void k_step(const DevCfg* __restrict__ cp
 template <bool TURB, int SPEC>
 __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef KernelTypes<SPEC> KT;
     const DevCfg& c = SpecCfg<SPEC>::get(cp);
     const DynCfg& dc = *dp;
     const int lane = threadIdx.x;
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
     const long e = valid ? env0 + lane : A.N - 1;
-    const LdsMap M = lds_map(c.obs_dim, c.L.window, c.use_cmd_ring);
+    const LdsMap M = lds_map(c.obs_dim, c.L.window, c.use_cmd_ring, KT::generic);
     const bool sel = valid && (A.mask == nullptr || A.mask[e] != 0);
-    const unsigned long long sel_mask = __ballot(sel);
-    if (sel_mask == 0ull) return;
+    if (!sel) return;
+    typename KT::Tab T = KT::tab(lds, M, lane);
+    typename KT::Obs ob = KT::obs(lds, M, lane);
     Env E;
     load_env<TURB>(c, A.S, A.N, e, E);
-    if (sel) reset_env<TURB>(c, dc, A, e, lane, E, lds, M, A.slot_end, A.slot_lag, A.bit_goal);
-    __syncthreads();
-    write_tile(lds + M.tile, A.obs, env0, A.N, c.obs_dim, lane, sel_mask);
-    if (sel) {
-        store_env<TURB>(c, A.S, A.N, e, E);
-        if (A.tgt_out != nullptr) {
+    reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane, A.slot_end, A.slot_lag, A.bit_goal);
+    write_obs(c, A.obs + e * c.obs_dim, ob, A.vec4 != 0);
+    store_env<TURB>(c, A.S, A.N, e, E);
+    if (A.tgt_out != nullptr) {
 #pragma unroll
-            for (int k = 0; k < FWG_MAX_TARGETS; ++k)
-                if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
-        }
+        for (int k = 0; k < FWG_MAX_TARGETS; ++k)
+            if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
     }
 }
 
@@ -678,9 +689,10 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     h->spec = match_spec(h->h);
     h->n_envs = n_envs; h->env_base = env_id_base; h->device = device; h->seed = 0; h->gstep = 0;
     h->arena = (float*)state_arena;
-    const LdsMap M = lds_map(h->h.obs_dim, h->h.L.window, h->h.use_cmd_ring);
-    h->lds_bytes = (size_t)M.total * sizeof(float);
-    if (h->lds_bytes > 64 * 1024) { delete h; return fail_with(FWG_ERR_INVALID, "observation too large for the LDS tile"); }
+    if ((int64_t)h->h.L.rows * n_envs >= (int64_t)1 << 31) { delete h; return fail_with(FWG_ERR_INVALID, "rows*n_envs must be < 2^31"); }
+    if (lds_map(h->h.obs_dim, h->h.L.window, h->h.use_cmd_ring, true).total * sizeof(float) > 64 * 1024) {
+        delete h; return fail_with(FWG_ERR_INVALID, "observation too large for the LDS scratch");
+    }
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipMalloc((void**)&h->d_cfg, sizeof(DevCfg)));
     HIP_TRY(hipMalloc((void**)&h->d_dyn, sizeof(DynCfg)));
@@ -741,6 +753,7 @@ static void fill_slots(const fwg_handle* h, int64_t g, KArgs* A) {
 
 static void base_args(const fwg_handle* h, KArgs* A) {
     memset(A, 0, sizeof(KArgs));
+    A->vec4 = (h->h.obs_dim % 4 == 0) ? 1 : 0;  // 16-byte stores of the observation records (torch buffers are 256-B aligned)
     A->S = h->arena; A->N = h->n_envs; A->env_base = h->env_base; A->reduce = h->d_reduce;
     A->seed_lo = (unsigned)(h->seed & 0xFFFFFFFFull); A->seed_hi = (unsigned)(h->seed >> 32);
 }
@@ -816,8 +829,9 @@ int fwg_dump_spec(const fwg_config* cfg, uint32_t* words_out, int64_t capacity) 
 template <bool IS_STEP, bool TURB, int SPEC>
 static void launch_one(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
     const dim3 grid((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), block(FWG_WAVE);
-    if (IS_STEP) hipLaunchKernelGGL((k_step<TURB, SPEC>), grid, block, h->lds_bytes, stream, h->d_cfg, h->d_dyn, A);
-    else hipLaunchKernelGGL((k_reset<TURB, SPEC>), grid, block, h->lds_bytes, stream, h->d_cfg, h->d_dyn, A);
+    const size_t lds_bytes = (size_t)lds_map(h->h.obs_dim, h->h.L.window, h->h.use_cmd_ring, SPEC < 0).total * sizeof(float);
+    if (IS_STEP) hipLaunchKernelGGL((k_step<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
+    else hipLaunchKernelGGL((k_reset<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
 }
 
 template <bool IS_STEP>

@@ -24,23 +24,39 @@ struct KArgs {
     unsigned seed_lo, seed_hi;
     int slot_act, slot_end, slot_lag, bit_goal;  // ring positions of the CURRENT global step
     int lag_slots[FWG_MAX_ROWS];                 // ring slot holding the row pushed r*obs_step steps ago
+    int vec4;                                    // observation records may be written with 16-byte stores
 };
 
-// LDS carve (in floats) for one 64-lane block
-struct LdsMap { int tile, vars, tgt, err, aring, cring, ain, total; };
-__host__ __device__ inline LdsMap lds_map(int obs_dim, int window, int use_cmd_ring) {
+// LDS carve (in floats) for one 64-lane block: the action windows (streamed in by global_load_lds) and, for the
+// generic (non-specialised) kernel only, the per-lane scratch tables that config-driven indices address
+struct LdsMap { int aring, cring, tab, obs, total; };
+#define FWG_TAB_TGT FWG_N_VARS               // table rows: simulator variables | targets | target errors
+#define FWG_TAB_ERR (FWG_N_VARS + FWG_MAX_TARGETS)
+#define FWG_TAB_ROWS (FWG_N_VARS + 2 * FWG_MAX_TARGETS)
+__host__ __device__ inline LdsMap lds_map(int obs_dim, int window, int use_cmd_ring, bool generic) {
     LdsMap m;
     int o = 0;
-    m.tile = o; o += obs_dim * FWG_TILE_STRIDE;
-    m.vars = o; o += FWG_N_VARS * FWG_WAVE;
-    m.tgt = o; o += FWG_MAX_TARGETS * FWG_WAVE;
-    m.err = o; o += FWG_MAX_TARGETS * FWG_WAVE;
     m.aring = o; o += window * 3 * FWG_WAVE;
     m.cring = o; o += (use_cmd_ring ? window * 3 * FWG_WAVE : 0);
-    m.ain = o; o += 3 * FWG_WAVE;
+    m.tab = o; o += generic ? FWG_TAB_ROWS * FWG_WAVE : 0;
+    m.obs = o; o += generic ? obs_dim * FWG_WAVE : 0;
     m.total = (o + 3) & ~3;
     return m;
 }
+
+// Per-lane tables behind one interface.  In a specialised kernel every index is a compile-time constant after
+// unrolling, so the register-array flavour costs nothing; the generic kernel indexes lane-private LDS columns
+// ([entry][lane], conflict-free) with wave-uniform run-time indices.
+template <int ROWS> struct RegTable {
+    float v[ROWS];
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void put(int i, float x) { v[i] = x; }
+};
+struct LdsTable {
+    float* p;
+    __device__ __forceinline__ float get(int i) const { return p[i * FWG_WAVE]; }
+    __device__ __forceinline__ void put(int i, float x) { p[i * FWG_WAVE] = x; }
+};
 
 struct Env {
     float y[NY];
@@ -61,7 +77,11 @@ struct Env {
     float sdcmd;
 };
 
-#define ROW(S, N, r, e) ((S)[(long)(r) * (N) + (e)])
+// element (row r, env e) of the SoA arena; 32-bit indices (fwg_create guarantees rows*N < 2^31) keep the address
+// arithmetic to one scalar multiply + one vector add per access
+#define ROW(S, N, r, e) ((S)[(unsigned)(r) * (unsigned)(N) + (unsigned)(e)])
+// element j of the AoS record of env e in ring slot `slot` of a ring that starts at arena row `base`
+#define RING(S, N, base, slot, width, e, j) ((S)[(unsigned)(base) * (unsigned)(N) + ((unsigned)(slot) * (unsigned)(N) + (unsigned)(e)) * (unsigned)(width) + (unsigned)(j)])
 
 template <bool TURB>
 __device__ __forceinline__ void load_env(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
@@ -75,8 +95,8 @@ __device__ __forceinline__ void load_env(const DevCfg& c, const float* __restric
 #pragma unroll
         for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = ROW(S, N, L.dryden + i, e);
     }
-    E.d.roll = ROW(S, N, L.derived + 0, e); E.d.pitch = ROW(S, N, L.derived + 1, e); E.d.yaw = ROW(S, N, L.derived + 2, e);
-    E.d.Va = ROW(S, N, L.derived + 3, e); E.d.alpha = ROW(S, N, L.derived + 4, e); E.d.beta = ROW(S, N, L.derived + 5, e);
+    // the derived rows (roll pitch yaw Va alpha beta) are write-only for the kernels: after a failed step they are
+    // recomputed from the restored state
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) E.tgt[k] = ROW(S, N, L.target + k, e);
     if (c.any_dynamic_target) {
@@ -165,14 +185,15 @@ __device__ __forceinline__ void store_env(const DevCfg& c, float* __restrict__ S
     }
 }
 
-// simulator variable table -> LDS [var][lane] so that config-driven (wave-uniform) indices can address it
-__device__ __forceinline__ void fill_vars(const Env& E, float* vars, int lane) {
+// simulator variable table (index = fwg_var) so that config-driven indices can address it
+template <class TAB>
+__device__ __forceinline__ void fill_vars(const Env& E, TAB& T) {
     const float v[FWG_N_VARS] = {E.d.roll, E.d.pitch, E.d.yaw, E.y[4], E.y[5], E.y[6], E.y[7], E.y[8], E.y[9],
                                  E.y[10], E.y[11], E.y[12], E.d.Va, E.d.alpha, E.d.beta,
                                  0.5f * (E.y[13] + E.y[14]), 0.5f * (E.y[14] - E.y[13]), E.y[15],
                                  E.wind[0], E.wind[1], E.wind[2], E.y[13], E.y[14]};
 #pragma unroll
-    for (int i = 0; i < FWG_N_VARS; ++i) vars[i * FWG_WAVE + lane] = v[i];
+    for (int i = 0; i < FWG_N_VARS; ++i) T.put(i, v[i]);
 }
 
 // _get_error (fixed_wing.py:890-900): wrap states value-target folded, others target-value
@@ -233,8 +254,9 @@ __device__ __forceinline__ void goal_push(const DevCfg& c, Env& E, unsigned g, i
 }
 
 // sample_target (fixed_wing.py:461-521); `given` (nullable) holds explicit targets for reset(target=...)
+template <class TAB>
 __device__ __forceinline__ void sample_targets(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, Env& E,
-                                               const float* vars, int lane, const float* given) {
+                                               const TAB& T, const float* given) {
     const unsigned env_id = (unsigned)(A.env_base + e);
     const unsigned resample = E.flags >> FWG_FLAG_RESAMPLE_SHIFT;
     E.sft = 0;
@@ -246,7 +268,7 @@ __device__ __forceinline__ void sample_targets(const DevCfg& c, const DynCfg& dc
         const u4 b = philox4x32(env_id, E.episode, resample, FWG_STREAM_RESET_TARGET + 256u * k, A.seed_lo, A.seed_hi);
         float low = r.low, high = r.high;
         if (t.has_delta) {
-            const float x = vars[t.var * FWG_WAVE + lane];
+            const float x = T.get(t.var);
             low = fmaxf(low, x - r.delta);
             high = fmaxf(fminf(high, x + r.delta), low);
         }
@@ -320,107 +342,145 @@ __device__ __forceinline__ void next_targets(const DevCfg& c, Env& E) {
 }
 
 // "action" observation entry (fixed_wing.py:813-828) for the newest row: sum of |diff| over the last `w` raw actions
-// (or constrained commands) of actuator ai, or the back-scaled actuator value when no action has been taken yet
-__device__ __forceinline__ float action_obs(const DevCfg& c, const float* ring, int lane, int ai, int w, unsigned n_act,
-                                            int cur_slot, float actuator) {
-    if (n_act < 1u) {
-        if (c.scale_actions)
-            return (c.scale_high - c.scale_low) * (actuator - c.act_to_low[ai]) * c.inv_act_span[ai] + c.scale_low;
-        return actuator;
-    }
+// (or constrained commands) of actuator ai, or the back-scaled actuator value when no action has been taken yet.
+// `ring` = this lane's column of the LDS action window [slot*3 + actuator][lane].
+__device__ __forceinline__ float backscale_action(const DevCfg& c, int ai, float actuator) {
+    if (c.scale_actions)
+        return (c.scale_high - c.scale_low) * (actuator - c.act_to_low[ai]) * c.inv_act_span[ai] + c.scale_low;
+    return actuator;
+}
+__device__ __forceinline__ float action_obs(const DevCfg& c, const float* ring, int ai, int w, unsigned n_act, int cur_slot,
+                                            float actuator) {
+    if (n_act < 1u) return backscale_action(c, ai, actuator);
     const int W = c.L.window;
     const int m = (int)min(n_act, (unsigned)w);
     float s = 0.f;
-    for (int k = W - 2; k >= 0; --k) {
-        if (k <= m - 2) {
+#pragma unroll
+    for (int k = FWG_MAX_WINDOW - 2; k >= 0; --k) {
+        if (k <= W - 2 && k <= m - 2) {
             int s_new = cur_slot - k; s_new += (s_new < 0) ? W : 0;
             int s_old = cur_slot - k - 1; s_old += (s_old < 0) ? W : 0;
-            s += fabsf(ring[(s_new * 3 + ai) * FWG_WAVE + lane] - ring[(s_old * 3 + ai) * FWG_WAVE + lane]);
+            s += fabsf(ring[(s_new * 3 + ai) * FWG_WAVE] - ring[(s_old * 3 + ai) * FWG_WAVE]);
         }
     }
     return s;
 }
 
-// newest observation row (un-noised, normalised) into tile rows [0, n_obs) and, when `push`, into the lag ring
-__device__ __forceinline__ void build_row0(const DevCfg& c, const KArgs& A, long e, int lane, const Env& E, float* lds,
-                                           const LdsMap& M, int ring_slot, bool push, int act_slot, bool valid) {
-    const float* vars = lds + M.vars;
-    const float* ring = lds + (c.use_cmd_ring ? M.cring : M.aring);
-    for (int j = 0; j < c.n_obs; ++j) {
-        const DevObs& o = c.obs[j];
-        float v;
-        if (o.type == FWG_OBS_STATE) v = vars[o.src * FWG_WAVE + lane];
-        else if (o.type == FWG_OBS_TARGET_RELATIVE) v = lds[M.err + o.src * FWG_WAVE + lane];
-        else if (o.type == FWG_OBS_TARGET_ABSOLUTE) v = lds[M.tgt + o.src * FWG_WAVE + lane];
-        else v = action_obs(c, ring, lane, o.src, o.window, E.steps, act_slot, vars[(FWG_V_ELEVATOR + o.src) * FWG_WAVE + lane]);
-        if (o.norm) v = (v - o.mean) * o.inv_var;
-        lds[M.tile + j * FWG_TILE_STRIDE + lane] = v;
-        if (push && valid && c.obs_length > 1) ROW(A.S, A.N, c.L.lag_ring + ring_slot * c.n_obs + j, e) = v;
+// newest observation row (un-noised, normalised) into ob[0, n_obs) and, when `push`, into the lag ring (AoS record)
+template <class TAB, class OB>
+__device__ __forceinline__ void build_row0(const DevCfg& c, const KArgs& A, long e, const Env& E, const TAB& T, OB& ob,
+                                           const float* ring, int ring_slot, bool push, int act_slot) {
+#pragma unroll
+    for (int j = 0; j < FWG_MAX_OBS; ++j) {
+        if (j < c.n_obs) {
+            const DevObs& o = c.obs[j];
+            float v;
+            if (o.type == FWG_OBS_STATE) v = T.get(o.src);
+            else if (o.type == FWG_OBS_TARGET_RELATIVE) v = T.get(FWG_TAB_ERR + o.src);
+            else if (o.type == FWG_OBS_TARGET_ABSOLUTE) v = T.get(FWG_TAB_TGT + o.src);
+            else v = action_obs(c, ring, o.src, o.window, E.steps, act_slot, T.get(FWG_V_ELEVATOR + o.src));
+            if (o.norm) v = (v - o.mean) * o.inv_var;
+            ob.put(j, v);
+            if (push && c.obs_length > 1) RING(A.S, A.N, c.L.lag_ring, ring_slot, c.n_obs, e, j) = v;
+        }
     }
 }
 
-// Fix-ups of the lagged rows r >= 1 that the uniform HBM->LDS stream cannot provide (fixed_wing.py:790-832):
+// lagged rows r >= 1 = the records pushed r*obs_step steps ago, read from the AoS lag ring
+template <class OB>
+__device__ __forceinline__ void load_lag_rows(const DevCfg& c, const KArgs& A, long e, OB& ob) {
+#pragma unroll
+    for (int r = 1; r < FWG_MAX_ROWS; ++r) {
+        if (r < c.obs_length) {
+#pragma unroll
+            for (int j = 0; j < FWG_MAX_OBS; ++j)
+                if (j < c.n_obs) ob.put(r * c.n_obs + j, RING(A.S, A.N, c.L.lag_ring, A.lag_slots[r], c.n_obs, e, j));
+        }
+    }
+}
+
+// Fix-ups of the lagged rows r >= 1 that the plain ring read cannot provide (fixed_wing.py:790-832):
 //  * rows reaching back to (or before) the start of the episode, i = 1 + r*step > steps_count: the INITIAL record plus
 //    a fresh U(-1,1)*dt per row, with "action" entries replaced by the CURRENT actuator value;
 //  * after a failed simulator step the state/target histories are one record shorter than the action history, so
-//    the non-action entries come from one slot further back than the streamed row.
-__device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A, long e, int lane, const Env& E, float* lds,
-                                                const LdsMap& M, bool ok) {
+//    the non-action entries come from one slot further back.
+template <class TAB, class OB>
+__device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A, long e, const Env& E, const TAB& T, OB& ob,
+                                                bool ok) {
     const int depth = c.L.lag_depth;
     const int t = (int)E.steps;
     const unsigned env_id = (unsigned)(A.env_base + e);
-    const float* vars = lds + M.vars;
-    for (int r = 1; r < c.obs_length; ++r) {
+#pragma unroll
+    for (int r = 1; r < FWG_MAX_ROWS; ++r) {
+        if (r >= c.obs_length) continue;
         const int lag = r * c.obs_step;
         if (lag >= t) {
             const u4 b = philox4x32(env_id, E.steps, E.episode, FWG_STREAM_INIT_NOISE + 256u * (r >> 2), A.seed_lo, A.seed_hi);
             const unsigned bits = (r & 3) == 0 ? b.x : ((r & 3) == 1 ? b.y : ((r & 3) == 2 ? b.z : b.w));
             const float noise = (2.f * u01(bits) - 1.f) * c.dt;
             int slot0 = A.slot_lag - t; slot0 += (slot0 < 0) ? depth : 0;  // ring slot of the episode's record 0
-            for (int j = 0; j < c.n_obs; ++j) {
+#pragma unroll
+            for (int j = 0; j < FWG_MAX_OBS; ++j) {
+                if (j >= c.n_obs) continue;
                 const DevObs& o = c.obs[j];
                 float v;
                 if (o.type == FWG_OBS_ACTION) {
-                    float a = vars[(FWG_V_ELEVATOR + o.src) * FWG_WAVE + lane];
-                    if (c.scale_actions)
-                        a = (c.scale_high - c.scale_low) * (a - c.act_to_low[o.src]) * c.inv_act_span[o.src] + c.scale_low;
-                    v = a + noise;
+                    v = backscale_action(c, o.src, T.get(FWG_V_ELEVATOR + o.src)) + noise;
                     if (o.norm) v = (v - o.mean) * o.inv_var;
                 } else {
-                    v = ROW(A.S, A.N, c.L.lag_ring + slot0 * c.n_obs + j, e) + noise * (o.norm ? o.inv_var : 1.f);
+                    v = RING(A.S, A.N, c.L.lag_ring, slot0, c.n_obs, e, j) + noise * (o.norm ? o.inv_var : 1.f);
                 }
-                lds[M.tile + (r * c.n_obs + j) * FWG_TILE_STRIDE + lane] = v;
+                ob.put(r * c.n_obs + j, v);
             }
         } else if (!ok) {
             int slot = A.slot_lag - 1 - lag; slot += (slot < 0) ? depth : 0;
-            for (int j = 0; j < c.n_obs; ++j)
-                if (c.obs[j].type != FWG_OBS_ACTION)
-                    lds[M.tile + (r * c.n_obs + j) * FWG_TILE_STRIDE + lane] = ROW(A.S, A.N, c.L.lag_ring + slot * c.n_obs + j, e);
+#pragma unroll
+            for (int j = 0; j < FWG_MAX_OBS; ++j)
+                if (j < c.n_obs && c.obs[j].type != FWG_OBS_ACTION)
+                    ob.put(r * c.n_obs + j, RING(A.S, A.N, c.L.lag_ring, slot, c.n_obs, e, j));
         }
     }
 }
 
 // optional Gaussian observation noise (fixed_wing.py:836-837), fresh for every entry of every row
-__device__ __forceinline__ void add_obs_noise(const DevCfg& c, const KArgs& A, long e, int lane, const Env& E, float* lds,
-                                              const LdsMap& M) {
+template <class OB>
+__device__ __forceinline__ void add_obs_noise(const DevCfg& c, const KArgs& A, long e, const Env& E, OB& ob) {
     const unsigned env_id = (unsigned)(A.env_base + e);
-    for (int blk = 0; blk * 4 < c.obs_dim; ++blk) {
+#pragma unroll
+    for (int blk = 0; blk < (FWG_MAX_OBS * FWG_MAX_ROWS) / 4; ++blk) {
+        if (blk * 4 >= c.obs_dim) continue;
         const u4 b = philox4x32(env_id, E.steps, E.episode, FWG_STREAM_OBS_NOISE + 256u * blk, A.seed_lo, A.seed_hi);
         float n[4];
         box_muller(b, n);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = blk * 4 + i;
-            if (k < c.obs_dim) lds[M.tile + k * FWG_TILE_STRIDE + lane] += c.obs_noise_mean + c.obs_noise_std * n[i];
+            if (k < c.obs_dim) ob.put(k, ob.get(k) + c.obs_noise_mean + c.obs_noise_std * n[i]);
         }
     }
 }
 
+// this env's observation record -> out[obs_dim] (one contiguous row of the [N][obs_dim] batch; a wave writes 64
+// consecutive rows, and the record is written with 16-byte stores when its size allows)
+template <class OB>
+__device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ out, const OB& ob, bool vec4) {
+    if (vec4) {
+        float4* o4 = reinterpret_cast<float4*>(out);
+#pragma unroll
+        for (int q = 0; q < (FWG_MAX_OBS * FWG_MAX_ROWS) / 4; ++q)
+            if (q * 4 < c.obs_dim) o4[q] = make_float4(ob.get(4 * q), ob.get(4 * q + 1), ob.get(4 * q + 2), ob.get(4 * q + 3));
+    } else {
+#pragma unroll
+        for (int k = 0; k < FWG_MAX_OBS * FWG_MAX_ROWS; ++k)
+            if (k < c.obs_dim) out[k] = ob.get(k);
+    }
+}
+
 // FixedWingAircraft.reset (fixed_wing.py:287-336) for one lane; `g_*` are the ring positions of the LAST completed
-// global step.  Fills E, the tile column of this lane (all rows) and the ring slots that hold initial records.
-template <bool TURB>
-__device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, int lane, Env& E,
-                                          float* lds, const LdsMap& M, int g_end, int g_lag, int g_bit) {
+// global step.  Fills E, the observation record ob (all rows) and the ring slots that hold initial records.
+template <bool TURB, class TAB, class OB>
+__device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, Env& E, TAB& T, OB& ob,
+                                          const float* ring, int g_end, int g_lag, int g_bit) {
     const unsigned env_id = (unsigned)(A.env_base + e);
     E.episode += 1u;
     E.steps = 0u;
@@ -467,16 +527,16 @@ __device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, con
     for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = 0.f;
     const float gust0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     E.d = derive<false>(E.y, E.wind, gust0);
-    fill_vars(E, lds + M.vars, lane);
+    fill_vars(E, T);
     // ---- targets
-    sample_targets(c, dc, A, e, E, lds + M.vars, lane, A.init_target);
+    sample_targets(c, dc, A, e, E, T, A.init_target);
     float err[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
         if (k < c.n_targets) {
-            err[k] = target_error(c.target[k], E.tgt[k], lds[M.vars + c.target[k].var * FWG_WAVE + lane]);
-            lds[M.tgt + k * FWG_WAVE + lane] = E.tgt[k];
-            lds[M.err + k * FWG_WAVE + lane] = err[k];
+            err[k] = target_error(c.target[k], E.tgt[k], T.get(c.target[k].var));
+            T.put(FWG_TAB_TGT + k, E.tgt[k]);
+            T.put(FWG_TAB_ERR + k, err[k]);
         }
     }
     // ---- accumulators of the episodic metrics (record 0 = the reset-time error / goal status, fixed_wing.py:318-325)
@@ -501,31 +561,18 @@ __device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, con
     }
     if (c.goal_enabled) goal_push(c, E, goal_flags(c, err), g_bit, 0u);
     // ---- observation: every row is the initial record (+ per-row init noise when length > 1)
-    build_row0(c, A, e, lane, E, lds, M, g_lag, true, 0, true);
+    build_row0(c, A, e, E, T, ob, ring, g_lag, true, 0);
     if (c.obs_length > 1) {
-        for (int r = c.obs_length - 1; r >= 0; --r) {
+#pragma unroll
+        for (int r = FWG_MAX_ROWS - 1; r >= 0; --r) {
+            if (r >= c.obs_length) continue;
             const u4 b = philox4x32(env_id, 0u, E.episode, FWG_STREAM_INIT_NOISE + 256u * (r >> 2), A.seed_lo, A.seed_hi);
             const unsigned bits = (r & 3) == 0 ? b.x : ((r & 3) == 1 ? b.y : ((r & 3) == 2 ? b.z : b.w));
             const float noise = (2.f * u01(bits) - 1.f) * c.dt;
-            for (int j = 0; j < c.n_obs; ++j) {
-                const DevObs& o = c.obs[j];
-                const float v = lds[M.tile + j * FWG_TILE_STRIDE + lane] + noise * (o.norm ? o.inv_var : 1.f);
-                lds[M.tile + (r * c.n_obs + j) * FWG_TILE_STRIDE + lane] = v;
-            }
+#pragma unroll
+            for (int j = 0; j < FWG_MAX_OBS; ++j)
+                if (j < c.n_obs) ob.put(r * c.n_obs + j, ob.get(j) + noise * (c.obs[j].norm ? c.obs[j].inv_var : 1.f));
         }
     }
-    if (c.obs_noise) add_obs_noise(c, A, e, lane, E, lds, M);
-}
-
-// coalesced [lane][obs_dim] write of the tile columns selected by `lanes`
-__device__ __forceinline__ void write_tile(const float* tile, float* out, long env0, long N, int D, int lane,
-                                           unsigned long long lanes) {
-    const int total = FWG_WAVE * D;
-    int l = lane / D, k = lane - l * D;
-    const int l_inc = FWG_WAVE / D, k_inc = FWG_WAVE - l_inc * D;
-    for (int idx = lane; idx < total; idx += FWG_WAVE) {
-        if (((lanes >> l) & 1ull) && env0 + l < N) out[env0 * D + idx] = tile[k * FWG_TILE_STRIDE + l];
-        k += k_inc; l += l_inc;
-        if (k >= D) { k -= D; ++l; }
-    }
+    if (c.obs_noise) add_obs_noise(c, A, e, E, ob);
 }

@@ -23,6 +23,9 @@ def run(kind, n, ckw, skw, steps=200):
 
 if __name__ == "__main__":
     turb = {"turbulence": True, "turbulence_intensity": "moderate"}
+    if len(sys.argv) > 1 and sys.argv[1] == "c3only":
+        run("cnn", 65536, {"observation": {"step": 2}}, turb, steps=400)
+        sys.exit(0)
     run("default", 4096, None, None)
     run("default", 65536, None, None)
     run("cnn", 65536, {"observation": {"step": 2}}, turb)
