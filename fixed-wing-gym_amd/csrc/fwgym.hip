@@ -17,22 +17,6 @@
 #include <string>
 #include "fwgym_env.h"
 
-typedef __attribute__((address_space(1))) const void* fwg_gptr;
-typedef __attribute__((address_space(3))) void* fwg_lptr;
-
-// async HBM -> LDS copy of one SoA row segment (64 consecutive words) for this wave
-__device__ __forceinline__ void dma_row(const float* src_lane_ptr, float* lds_row) {
-    __builtin_amdgcn_global_load_lds((fwg_gptr)src_lane_ptr, (fwg_lptr)lds_row, 4, 0, 0);
-}
-// the compiler does not order LDS reads behind an in-flight global_load_lds: drain the vector-memory counter by hand
-#ifndef FWG_DMA_DRAIN
-#define FWG_DMA_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#endif
-__device__ __forceinline__ void dma_wait() {
-    FWG_DMA_DRAIN();
-    __syncthreads();
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, FWG_WAVE);
@@ -96,7 +80,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
     const long e = valid ? env0 + lane : A.N - 1;
-    const LdsMap M = lds_map(c.obs_dim, c.L.window, c.use_cmd_ring, KT::generic);
+    const LdsMap M = lds_map(c.obs_dim, c.n_obs, c.L.window, c.use_cmd_ring, KT::generic);
     const fwg_layout& L = c.L;
     const int W = L.window;
     typename KT::Tab T = KT::tab(lds, M, lane);
@@ -112,9 +96,9 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     float raw[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) raw[i] = A.actions[e * 3 + i];   // [N][3]: a wave reads 768 contiguous bytes
+    stream_lag_rows(c, A, e, lds + M.lag);
     Env E;
     load_env<TURB>(c, A.S, A.N, e, E);
-    if (!KT::generic) load_lag_rows(c, A, e, ob);
     dma_wait();
 
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first
@@ -299,7 +283,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     }
 
     // ---- phase D: observation (fixed_wing.py:776-846)
-    if (KT::generic) load_lag_rows(c, A, e, ob);
+    load_lag_rows(c, lds + M.lag + lane, ob);
     build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid, A.slot_act);
     if (c.obs_length > 1 && (!ok || (int)E.steps <= (c.obs_length - 1) * c.obs_step))
         fix_lagged_rows(c, A, e, E, T, ob, ok);
@@ -369,8 +353,8 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
             } else {
                 red[0] = 1.f;
             }
-            if (A.term_obs != nullptr) write_obs(c, A.term_obs + e * c.obs_dim, ob, A.vec4 != 0);
         }
+        if (A.term_obs != nullptr) write_obs(c, A.term_obs, env0, A.N, ob, lds + M.stage, lane, done_mask);
         // per-wave reduction by shuffles, one atomic per value per wave (the per-GPU part of the success reduction of
         // examples/train_rl_controller.py:51-66,80-85)
 #pragma unroll
@@ -383,8 +367,8 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     }
 
     // ---- phase F: outputs and the state write-back
+    write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull);
     if (valid) {
-        write_obs(c, A.obs + e * c.obs_dim, ob, A.vec4 != 0);
         A.rew[e] = reward;
         A.done[e] = done ? 1 : 0;
         A.term[e] = (uint8_t)term;
@@ -410,20 +394,23 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
     const long e = valid ? env0 + lane : A.N - 1;
-    const LdsMap M = lds_map(c.obs_dim, c.L.window, c.use_cmd_ring, KT::generic);
+    const LdsMap M = lds_map(c.obs_dim, c.n_obs, c.L.window, c.use_cmd_ring, KT::generic);
     const bool sel = valid && (A.mask == nullptr || A.mask[e] != 0);
-    if (!sel) return;
+    const unsigned long long sel_mask = __ballot(sel);
+    if (sel_mask == 0ull) return;
     typename KT::Tab T = KT::tab(lds, M, lane);
     typename KT::Obs ob = KT::obs(lds, M, lane);
     Env E;
     load_env<TURB>(c, A.S, A.N, e, E);
-    reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane, A.slot_end, A.slot_lag, A.bit_goal);
-    write_obs(c, A.obs + e * c.obs_dim, ob, A.vec4 != 0);
-    store_env<TURB>(c, A.S, A.N, e, E);
-    if (A.tgt_out != nullptr) {
+    if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane, A.slot_end, A.slot_lag, A.bit_goal);
+    write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
+    if (sel) {
+        store_env<TURB>(c, A.S, A.N, e, E);
+        if (A.tgt_out != nullptr) {
 #pragma unroll
-        for (int k = 0; k < FWG_MAX_TARGETS; ++k)
-            if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
+            for (int k = 0; k < FWG_MAX_TARGETS; ++k)
+                if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
+        }
     }
 }
 
@@ -690,7 +677,7 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     h->n_envs = n_envs; h->env_base = env_id_base; h->device = device; h->seed = 0; h->gstep = 0;
     h->arena = (float*)state_arena;
     if ((int64_t)h->h.L.rows * n_envs >= (int64_t)1 << 31) { delete h; return fail_with(FWG_ERR_INVALID, "rows*n_envs must be < 2^31"); }
-    if (lds_map(h->h.obs_dim, h->h.L.window, h->h.use_cmd_ring, true).total * sizeof(float) > 64 * 1024) {
+    if (lds_map(h->h.obs_dim, h->h.n_obs, h->h.L.window, h->h.use_cmd_ring, true).total * sizeof(float) > 64 * 1024) {
         delete h; return fail_with(FWG_ERR_INVALID, "observation too large for the LDS scratch");
     }
     HIP_TRY(hipSetDevice(device));
@@ -753,7 +740,6 @@ static void fill_slots(const fwg_handle* h, int64_t g, KArgs* A) {
 
 static void base_args(const fwg_handle* h, KArgs* A) {
     memset(A, 0, sizeof(KArgs));
-    A->vec4 = (h->h.obs_dim % 4 == 0) ? 1 : 0;  // 16-byte stores of the observation records (torch buffers are 256-B aligned)
     A->S = h->arena; A->N = h->n_envs; A->env_base = h->env_base; A->reduce = h->d_reduce;
     A->seed_lo = (unsigned)(h->seed & 0xFFFFFFFFull); A->seed_hi = (unsigned)(h->seed >> 32);
 }
@@ -829,7 +815,7 @@ int fwg_dump_spec(const fwg_config* cfg, uint32_t* words_out, int64_t capacity) 
 template <bool IS_STEP, bool TURB, int SPEC>
 static void launch_one(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
     const dim3 grid((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), block(FWG_WAVE);
-    const size_t lds_bytes = (size_t)lds_map(h->h.obs_dim, h->h.L.window, h->h.use_cmd_ring, SPEC < 0).total * sizeof(float);
+    const size_t lds_bytes = (size_t)lds_map(h->h.obs_dim, h->h.n_obs, h->h.L.window, h->h.use_cmd_ring, SPEC < 0).total * sizeof(float);
     if (IS_STEP) hipLaunchKernelGGL((k_step<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
     else hipLaunchKernelGGL((k_reset<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
 }

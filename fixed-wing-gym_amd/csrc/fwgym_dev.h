@@ -121,3 +121,23 @@ __device__ __forceinline__ u4 philox4x32(unsigned c0, unsigned c1, unsigned c2, 
     return u4{c0, c1, c2, c3};
 }
 __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// async HBM -> LDS streaming (global_load_lds)
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* fwg_gptr;
+typedef __attribute__((address_space(3))) void* fwg_lptr;
+
+// async HBM -> LDS copy of one SoA row segment (64 consecutive words) for this wave
+__device__ __forceinline__ void dma_row(const float* src_lane_ptr, float* lds_row) {
+    __builtin_amdgcn_global_load_lds((fwg_gptr)src_lane_ptr, (fwg_lptr)lds_row, 4, 0, 0);
+}
+// the compiler does not order LDS reads behind an in-flight global_load_lds: drain the vector-memory counter by hand
+#ifndef FWG_DMA_DRAIN
+#define FWG_DMA_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+__device__ __forceinline__ void dma_wait() {
+    FWG_DMA_DRAIN();
+    __syncthreads();
+}
+

@@ -24,20 +24,25 @@ struct KArgs {
     unsigned seed_lo, seed_hi;
     int slot_act, slot_end, slot_lag, bit_goal;  // ring positions of the CURRENT global step
     int lag_slots[FWG_MAX_ROWS];                 // ring slot holding the row pushed r*obs_step steps ago
-    int vec4;                                    // observation records may be written with 16-byte stores
 };
 
 // LDS carve (in floats) for one 64-lane block: the action windows (streamed in by global_load_lds) and, for the
 // generic (non-specialised) kernel only, the per-lane scratch tables that config-driven indices address
-struct LdsMap { int aring, cring, tab, obs, total; };
+struct LdsMap { int aring, cring, lag, stage, tab, obs, total; };
 #define FWG_TAB_TGT FWG_N_VARS               // table rows: simulator variables | targets | target errors
 #define FWG_TAB_ERR (FWG_N_VARS + FWG_MAX_TARGETS)
 #define FWG_TAB_ROWS (FWG_N_VARS + 2 * FWG_MAX_TARGETS)
-__host__ __device__ inline LdsMap lds_map(int obs_dim, int window, int use_cmd_ring, bool generic) {
+// row stride (words) of the output staging: records of 4q words with q odd are written/read with conflict-free 16-byte
+// LDS accesses; any other size falls back to an odd stride and 4-byte accesses
+__host__ __device__ inline bool obs_vec4(int obs_dim) { return (obs_dim % 4 == 0) && ((obs_dim / 4) % 2 == 1); }
+__host__ __device__ inline int obs_stage_stride(int obs_dim) { return obs_vec4(obs_dim) ? obs_dim : (obs_dim | 1); }
+__host__ __device__ inline LdsMap lds_map(int obs_dim, int n_obs, int window, int use_cmd_ring, bool generic) {
     LdsMap m;
     int o = 0;
     m.aring = o; o += window * 3 * FWG_WAVE;
     m.cring = o; o += (use_cmd_ring ? window * 3 * FWG_WAVE : 0);
+    m.lag = o; o += (obs_dim - n_obs) * FWG_WAVE;          // lagged rows streamed in as SoA rows [entry][lane]
+    m.stage = o; o += FWG_WAVE * obs_stage_stride(obs_dim);  // [lane][obs_dim] staging of the output records
     m.tab = o; o += generic ? FWG_TAB_ROWS * FWG_WAVE : 0;
     m.obs = o; o += generic ? obs_dim * FWG_WAVE : 0;
     m.total = (o + 3) & ~3;
@@ -80,8 +85,8 @@ struct Env {
 // element (row r, env e) of the SoA arena; 32-bit indices (fwg_create guarantees rows*N < 2^31) keep the address
 // arithmetic to one scalar multiply + one vector add per access
 #define ROW(S, N, r, e) ((S)[(unsigned)(r) * (unsigned)(N) + (unsigned)(e)])
-// element j of the AoS record of env e in ring slot `slot` of a ring that starts at arena row `base`
-#define RING(S, N, base, slot, width, e, j) ((S)[(unsigned)(base) * (unsigned)(N) + ((unsigned)(slot) * (unsigned)(N) + (unsigned)(e)) * (unsigned)(width) + (unsigned)(j)])
+// entry j of the record of env e in slot `slot` of a ring that starts at arena row `base` (SoA rows [slot][entry][env])
+#define RING(S, N, base, slot, width, e, j) ROW(S, N, (base) + (slot) * (width) + (j), e)
 
 template <bool TURB>
 __device__ __forceinline__ void load_env(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
@@ -386,15 +391,21 @@ __device__ __forceinline__ void build_row0(const DevCfg& c, const KArgs& A, long
     }
 }
 
-// lagged rows r >= 1 = the records pushed r*obs_step steps ago, read from the AoS lag ring
+// lagged rows r >= 1 = the records pushed r*obs_step steps ago: streamed HBM -> LDS at kernel start
+// (stream_lag_rows, global_load_lds: no VGPRs while the physics runs), collected into the record here
+__device__ __forceinline__ void stream_lag_rows(const DevCfg& c, const KArgs& A, long e, float* lds_lag) {
+    for (int r = 1; r < c.obs_length; ++r)
+        for (int j = 0; j < c.n_obs; ++j)
+            dma_row(&RING(A.S, A.N, c.L.lag_ring, A.lag_slots[r], c.n_obs, e, j), lds_lag + ((r - 1) * c.n_obs + j) * FWG_WAVE);
+}
 template <class OB>
-__device__ __forceinline__ void load_lag_rows(const DevCfg& c, const KArgs& A, long e, OB& ob) {
+__device__ __forceinline__ void load_lag_rows(const DevCfg& c, const float* lag_col, OB& ob) {
 #pragma unroll
     for (int r = 1; r < FWG_MAX_ROWS; ++r) {
         if (r < c.obs_length) {
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j)
-                if (j < c.n_obs) ob.put(r * c.n_obs + j, RING(A.S, A.N, c.L.lag_ring, A.lag_slots[r], c.n_obs, e, j));
+                if (j < c.n_obs) ob.put(r * c.n_obs + j, lag_col[((r - 1) * c.n_obs + j) * FWG_WAVE]);
         }
     }
 }
@@ -460,19 +471,43 @@ __device__ __forceinline__ void add_obs_noise(const DevCfg& c, const KArgs& A, l
     }
 }
 
-// this env's observation record -> out[obs_dim] (one contiguous row of the [N][obs_dim] batch; a wave writes 64
-// consecutive rows, and the record is written with 16-byte stores when its size allows)
+// The 64 observation records of this wave -> out[env0 .. env0+63][obs_dim], which is one contiguous block of the
+// [N][obs_dim] batch: every lane parks its record in the LDS staging area ([lane][obs_dim]) and the wave then writes
+// the block in linear order, 1 KiB per store instruction (16 B per lane) when the record size allows.  `lanes` selects
+// the records to write (all, or the finished episodes for the terminal observations).  Must be called by all lanes.
 template <class OB>
-__device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ out, const OB& ob, bool vec4) {
-    if (vec4) {
-        float4* o4 = reinterpret_cast<float4*>(out);
+__device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ out, long env0, long N, const OB& ob,
+                                          float* stage, int lane, unsigned long long lanes) {
+    const int D = c.obs_dim;
+    __syncthreads();  // the staging area may still be read by a previous call
+    if (obs_vec4(D)) {
+        float4* mine = reinterpret_cast<float4*>(stage + lane * D);
 #pragma unroll
         for (int q = 0; q < (FWG_MAX_OBS * FWG_MAX_ROWS) / 4; ++q)
-            if (q * 4 < c.obs_dim) o4[q] = make_float4(ob.get(4 * q), ob.get(4 * q + 1), ob.get(4 * q + 2), ob.get(4 * q + 3));
+            if (q * 4 < D) mine[q] = make_float4(ob.get(4 * q), ob.get(4 * q + 1), ob.get(4 * q + 2), ob.get(4 * q + 3));
+        __syncthreads();
+        const float4* all = reinterpret_cast<const float4*>(stage);
+        float4* o4 = reinterpret_cast<float4*>(out + env0 * D);
+        const int total4 = FWG_WAVE * D / 4;
+#pragma unroll 4
+        for (int i = lane; i < total4; i += FWG_WAVE) {
+            const int l = (4 * i) / D;
+            if (((lanes >> l) & 1ull) && env0 + l < N) o4[i] = all[i];
+        }
     } else {
+        const int Ds = obs_stage_stride(D);
 #pragma unroll
         for (int k = 0; k < FWG_MAX_OBS * FWG_MAX_ROWS; ++k)
-            if (k < c.obs_dim) out[k] = ob.get(k);
+            if (k < D) stage[lane * Ds + k] = ob.get(k);
+        __syncthreads();
+        int l = lane / D, k = lane - l * D;
+        const int l_inc = FWG_WAVE / D, k_inc = FWG_WAVE - l_inc * D;
+#pragma unroll 4
+        for (int idx = lane; idx < FWG_WAVE * D; idx += FWG_WAVE) {
+            if (((lanes >> l) & 1ull) && env0 + l < N) out[env0 * D + idx] = stage[l * Ds + k];
+            k += k_inc; l += l_inc;
+            if (k >= D) { k -= D; ++l; }
+        }
     }
 }
 
