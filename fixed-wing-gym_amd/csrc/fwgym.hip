@@ -99,14 +99,12 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     stream_lag_rows(c, A, e, lds + M.lag);
     Env E;
     load_env<TURB>(c, A.S, A.N, e, E);
-    dma_wait();
 
-    // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first
+    // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
+    // LDS copy once the streamed window has landed, i.e. after the integration)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        aring[(A.slot_act * 3 + i) * FWG_WAVE] = raw[i];
+    for (int i = 0; i < 3; ++i)
         if (valid) ROW(A.S, A.N, L.act_ring + A.slot_act * 3 + i, e) = raw[i];
-    }
 
     // ---- phase B: action scaling (fixed_wing.py:349-354,439-459) and the simulator step (fixed_wing.py:358)
     float cmd[3];
@@ -121,10 +119,8 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     constrain_commands(c, cmd, cmd_c, sp);
     if (c.use_cmd_ring) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            cring[(A.slot_act * 3 + i) * FWG_WAVE] = cmd_c[i];
+        for (int i = 0; i < 3; ++i)
             if (valid) ROW(A.S, A.N, L.cmd_ring + A.slot_act * 3 + i, e) = cmd_c[i];
-        }
     }
     if (c.metrics) {  // control_variation accumulator (fixed_wing.py:1109-1114)
         if (E.steps > 0u) E.sdcmd += fabsf(cmd_c[0] - E.pcmd[0]) + fabsf(cmd_c[1] - E.pcmd[1]) + fabsf(cmd_c[2] - E.pcmd[2]);
@@ -141,6 +137,14 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         float n[4];
         box_muller(b, n);
         dryden_advance(c, E.dry, n);
+    }
+    if (valid) store_sim<TURB>(c, A.S, A.N, e, E, false);
+    // everything streamed HBM -> LDS at kernel start is needed from here on; the integration above hid its latency
+    dma_wait();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        aring[(A.slot_act * 3 + i) * FWG_WAVE] = raw[i];
+        if (c.use_cmd_ring) cring[(A.slot_act * 3 + i) * FWG_WAVE] = cmd_c[i];
     }
 
     // ---- phase C: gym-side bookkeeping (fixed_wing.py:360-417)
@@ -282,6 +286,8 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         }
     }
 
+    if (valid) store_gym(c, A.S, A.N, e, E, false);
+
     // ---- phase D: observation (fixed_wing.py:776-846)
     load_lag_rows(c, lds + M.lag + lane, ob);
     build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid, A.slot_act);
@@ -362,8 +368,11 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
             const float s = wave_sum(red[i]);
             if (lane == 0 && s != 0.f) atomicAdd(A.reduce + i, s);
         }
-        if (c.auto_reset && done && valid)
+        if (c.auto_reset && done && valid) {
             reset_env<TURB>(c, dc, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal);
+            store_sim<TURB>(c, A.S, A.N, e, E, true);
+            store_gym(c, A.S, A.N, e, E, true);
+        }
     }
 
     // ---- phase F: outputs and the state write-back
@@ -377,7 +386,6 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
             for (int k = 0; k < FWG_MAX_TARGETS; ++k)
                 if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
         }
-        store_env<TURB>(c, A.S, A.N, e, E);
     }
 }
 
@@ -405,7 +413,8 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane, A.slot_end, A.slot_lag, A.bit_goal);
     write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
     if (sel) {
-        store_env<TURB>(c, A.S, A.N, e, E);
+        store_sim<TURB>(c, A.S, A.N, e, E, true);
+        store_gym(c, A.S, A.N, e, E, true);
         if (A.tgt_out != nullptr) {
 #pragma unroll
             for (int k = 0; k < FWG_MAX_TARGETS; ++k)

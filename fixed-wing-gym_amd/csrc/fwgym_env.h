@@ -139,20 +139,29 @@ __device__ __forceinline__ void load_env(const DevCfg& c, const float* __restric
     }
 }
 
+// The write-back is split so that each part is issued as soon as its values are final: the simulator state right after
+// the integration, the bookkeeping after the gym logic -- the store traffic then overlaps the remaining computation
+// instead of forming one burst at the end of the kernel.
 template <bool TURB>
-__device__ __forceinline__ void store_env(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E) {
+__device__ __forceinline__ void store_sim(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E, bool with_wind) {
     const fwg_layout& L = c.L;
-    unsigned* U = reinterpret_cast<unsigned*>(S);
 #pragma unroll
     for (int i = 0; i < NY; ++i) ROW(S, N, L.phys + i, e) = E.y[i];
+    if (with_wind) {  // the steady wind only changes at reset
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ROW(S, N, L.wind + i, e) = E.wind[i];
+        for (int i = 0; i < 3; ++i) ROW(S, N, L.wind + i, e) = E.wind[i];
+    }
     if (TURB) {
 #pragma unroll
         for (int i = 0; i < FWG_N_DRYDEN; ++i) ROW(S, N, L.dryden + i, e) = E.dry[i];
     }
     ROW(S, N, L.derived + 0, e) = E.d.roll; ROW(S, N, L.derived + 1, e) = E.d.pitch; ROW(S, N, L.derived + 2, e) = E.d.yaw;
     ROW(S, N, L.derived + 3, e) = E.d.Va; ROW(S, N, L.derived + 4, e) = E.d.alpha; ROW(S, N, L.derived + 5, e) = E.d.beta;
+}
+
+__device__ __forceinline__ void store_gym(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E, bool at_reset) {
+    const fwg_layout& L = c.L;
+    unsigned* U = reinterpret_cast<unsigned*>(S);
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) ROW(S, N, L.target + k, e) = E.tgt[k];
     if (c.any_dynamic_target) {
@@ -162,7 +171,8 @@ __device__ __forceinline__ void store_env(const DevCfg& c, float* __restrict__ S
             for (int j = 0; j < 4; ++j) ROW(S, N, L.target + 3 + k * 4 + j, e) = E.tprop[k][j];
     }
     ROW(U, N, L.counters + 0, e) = E.steps; ROW(U, N, L.counters + 1, e) = E.sft;
-    ROW(U, N, L.counters + 2, e) = E.flags; ROW(U, N, L.counters + 3, e) = E.episode;
+    ROW(U, N, L.counters + 2, e) = E.flags;
+    if (at_reset) ROW(U, N, L.counters + 3, e) = E.episode;  // the episode counter only changes at reset
     if (c.reward_potential) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) ROW(S, N, L.prev_shaping + i, e) = E.psh[i];
@@ -180,7 +190,8 @@ __device__ __forceinline__ void store_env(const DevCfg& c, float* __restrict__ S
     if (c.metrics) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            ROW(S, N, L.met + 0 + k, e) = E.e0[k]; ROW(S, N, L.met + 3 + k, e) = E.esum[k];
+            if (at_reset) ROW(S, N, L.met + 0 + k, e) = E.e0[k];  // the initial error is fixed for the episode
+            ROW(S, N, L.met + 3 + k, e) = E.esum[k];
             ROW(S, N, L.met + 6 + k, e) = E.eabs[k]; ROW(S, N, L.met + 9 + k, e) = E.emin[k];
             ROW(S, N, L.met + 12 + k, e) = E.emax[k]; ROW(U, N, L.met + 15 + k, e) = E.rise[k];
             ROW(S, N, L.met + 20 + k, e) = E.perr[k];
