@@ -98,7 +98,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     for (int i = 0; i < 3; ++i) raw[i] = A.actions[e * 3 + i];   // [N][3]: a wave reads 768 contiguous bytes
     stream_lag_rows(c, A, e, lds + M.lag);
     Env E;
-    load_env<TURB>(c, A.S, A.N, e, E);
+    load_env<TURB>(c, A.S, A.N, e, E, A.bit_goal);
 
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
     // LDS copy once the streamed window has landed, i.e. after the integration)
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         if (c.goal_enabled) {
             g = goal_flags(c, err);
             goal_push(c, E, g, A.bit_goal, rec);
-            if (E.sft >= (unsigned)c.streak_req && ring_popcount(E.gring[3]) >= (unsigned)c.streak_min_count) {
+            if (E.sft >= (unsigned)c.streak_req && window_count(E, 3) >= (unsigned)c.streak_min_count) {
                 achieved_now = !(E.flags & FWG_FLAG_GOAL_ACHIEVED);
                 E.flags |= FWG_FLAG_GOAL_ACHIEVED;
                 if (c.on_success == FWG_ON_SUCCESS_DONE) { done = true; term = FWG_TERM_SUCCESS; }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         }
     }
 
-    if (valid) store_gym(c, A.S, A.N, e, E, false);
+    if (valid) store_gym(c, A.S, A.N, e, E, false, A.bit_goal);
 
     // ---- phase D: observation (fixed_wing.py:776-846)
     load_lag_rows(c, lds + M.lag + lane, ob);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
                             const unsigned st = pack16_get(E.settle, r);
                             mt[FWG_M_SETTLING_TIME + r] = st == 0xFFFFu ? NAN : (float)st;
                             mt[FWG_M_SUCCESS + r] = st == 0xFFFFu ? 0.f : 1.f;
-                            mt[FWG_M_SUCCESS_TIME_FRAC + r] = (float)E.gcnt[r] / (float)n_rec;
+                            mt[FWG_M_SUCCESS_TIME_FRAC + r] = (float)pack16_get(E.gcnt, r) / (float)n_rec;
                         }
                     }
                 }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         if (c.auto_reset && done && valid) {
             reset_env<TURB>(c, dc, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal);
             store_sim<TURB>(c, A.S, A.N, e, E, true);
-            store_gym(c, A.S, A.N, e, E, true);
+            store_gym(c, A.S, A.N, e, E, true, A.bit_goal);
         }
     }
 
@@ -409,12 +409,12 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     typename KT::Tab T = KT::tab(lds, M, lane);
     typename KT::Obs ob = KT::obs(lds, M, lane);
     Env E;
-    load_env<TURB>(c, A.S, A.N, e, E);
+    load_env<TURB>(c, A.S, A.N, e, E, A.bit_goal);
     if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane, A.slot_end, A.slot_lag, A.bit_goal);
     write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
     if (sel) {
         store_sim<TURB>(c, A.S, A.N, e, E, true);
-        store_gym(c, A.S, A.N, e, E, true);
+        store_gym(c, A.S, A.N, e, E, true, A.bit_goal);
         if (A.tgt_out != nullptr) {
 #pragma unroll
             for (int k = 0; k < FWG_MAX_TARGETS; ++k)

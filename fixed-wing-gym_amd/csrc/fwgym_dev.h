@@ -81,6 +81,28 @@ __device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x)
 __device__ __forceinline__ float fclampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 __device__ __forceinline__ float fsignf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
+// atan2 for the kinematics (angle of attack, sideslip, Euler angles): odd minimax polynomial of degree 17 on [0,1]
+// (max abs error 1.1e-7 in fp32, fitted offline) + octant folding; ~20 VALU instructions instead of the library's ~45.
+__device__ __forceinline__ float fast_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mx > 0.f ? mn * frcp(mx) : 0.f;
+    const float s = a * a;
+    float p = 0.0024566026404500008f;
+    p = p * s - 0.014400825835764408f;
+    p = p * s + 0.03978026658296585f;
+    p = p * s - 0.07234764844179153f;
+    p = p * s + 0.1049889475107193f;
+    p = p * s - 0.14161212742328644f;
+    p = p * s + 0.19985903799533844f;
+    p = p * s - 0.33332598209381104f;
+    p = p * s + 0.9999998807907104f;
+    float r = p * a;
+    r = ay > ax ? 1.57079632679489661923f - r : r;
+    r = x < 0.f ? 3.14159265358979323846f - r : r;
+    return copysignf(r, y);
+}
+
 #define FWG_PI 3.14159265358979323846f
 #define FWG_TWO_PI 6.28318530717958647692f
 #define FWG_INV_TWO_PI 0.15915494309189533577f

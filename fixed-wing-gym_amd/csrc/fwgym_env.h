@@ -73,8 +73,9 @@ struct Env {
     unsigned steps, sft, flags, episode;
     float psh[3];
     float pcmd[3];
-    unsigned gring[4][4];
-    unsigned gcnt[4];
+    unsigned gword[4];   // the 32-bit word of each goal window that holds this step's bit position
+    unsigned wcnt;       // ones inside each window, 4 x 8 bit (windows hold success_streak_req <= 128 flags)
+    unsigned gcnt[2];    // cumulative ones per window since reset, 4 x 16 bit
     float e0[3], esum[3], eabs[3], emin[3], emax[3];
     unsigned rise[3];
     unsigned settle[2];
@@ -89,7 +90,7 @@ struct Env {
 #define RING(S, N, base, slot, width, e, j) ROW(S, N, (base) + (slot) * (width) + (j), e)
 
 template <bool TURB>
-__device__ __forceinline__ void load_env(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
+__device__ __forceinline__ void load_env(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E, int goal_bit) {
     const fwg_layout& L = c.L;
     const unsigned* U = reinterpret_cast<const unsigned*>(S);
 #pragma unroll
@@ -118,13 +119,11 @@ __device__ __forceinline__ void load_env(const DevCfg& c, const float* __restric
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) E.pcmd[i] = ROW(S, N, L.prev_cmd + i, e);
-    if (c.goal_enabled) {
+    if (c.goal_enabled) {  // only the word that receives this step's flag is touched; the window counts are kept apart
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) E.gring[r][w] = ROW(U, N, L.goal_ring + r * 4 + w, e);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) E.gcnt[r] = ROW(U, N, L.goal_count + r, e);
+        for (int r = 0; r < 4; ++r) E.gword[r] = ROW(U, N, L.goal_ring + r * 4 + (goal_bit >> 5), e);
+        E.wcnt = ROW(U, N, L.goal_count + 0, e);
+        E.gcnt[0] = ROW(U, N, L.goal_count + 1, e); E.gcnt[1] = ROW(U, N, L.goal_count + 2, e);
     }
     if (c.metrics) {
 #pragma unroll
@@ -159,7 +158,8 @@ __device__ __forceinline__ void store_sim(const DevCfg& c, float* __restrict__ S
     ROW(S, N, L.derived + 3, e) = E.d.Va; ROW(S, N, L.derived + 4, e) = E.d.alpha; ROW(S, N, L.derived + 5, e) = E.d.beta;
 }
 
-__device__ __forceinline__ void store_gym(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E, bool at_reset) {
+__device__ __forceinline__ void store_gym(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E, bool at_reset,
+                                          int goal_bit) {
     const fwg_layout& L = c.L;
     unsigned* U = reinterpret_cast<unsigned*>(S);
 #pragma unroll
@@ -181,11 +181,9 @@ __device__ __forceinline__ void store_gym(const DevCfg& c, float* __restrict__ S
     for (int i = 0; i < 3; ++i) ROW(S, N, L.prev_cmd + i, e) = E.pcmd[i];
     if (c.goal_enabled) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) ROW(U, N, L.goal_ring + r * 4 + w, e) = E.gring[r][w];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ROW(U, N, L.goal_count + r, e) = E.gcnt[r];
+        for (int r = 0; r < 4; ++r) ROW(U, N, L.goal_ring + r * 4 + (goal_bit >> 5), e) = E.gword[r];
+        ROW(U, N, L.goal_count + 0, e) = E.wcnt;
+        ROW(U, N, L.goal_count + 1, e) = E.gcnt[0]; ROW(U, N, L.goal_count + 2, e) = E.gcnt[1];
     }
     if (c.metrics) {
 #pragma unroll
@@ -217,19 +215,6 @@ __device__ __forceinline__ float target_error(const DevTarget& t, float target, 
     return t.wrap ? angle_dist(target, value) : target - value;
 }
 
-__device__ __forceinline__ unsigned ring_popcount(const unsigned (&w)[4]) {
-    return __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
-}
-__device__ __forceinline__ void ring_set(unsigned (&w)[4], int bit, bool flag) {
-    const int wi = bit >> 5;
-    const unsigned m = 1u << (bit & 31);
-    // all four words are rewritten (mask 0 = no-op) so that the window stays in registers (no dynamic indexing)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned mi = (i == wi) ? m : 0u;
-        w[i] = (w[i] & ~mi) | (flag ? mi : 0u);
-    }
-}
 __device__ __forceinline__ unsigned pack16_get(const unsigned (&p)[2], int i) { return (p[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu; }
 __device__ __forceinline__ void pack16_set(unsigned (&p)[2], int i, unsigned v) {
     const int sh = (i & 1) * 16;
@@ -251,19 +236,26 @@ __device__ __forceinline__ unsigned goal_flags(const DevCfg& c, const float (&er
     return g | (all ? 8u : 0u);
 }
 
-// push the goal flags of one record into the four windows + cumulative counts, and latch the metric settling index
-// (first record index at which a full window satisfies the fraction, fixed_wing.py:1116-1128)
+// Push the goal flags of one record into the four windows (target0..2, all).  A window is a ring of
+// success_streak_req bits addressed by the global step counter, so the bit being overwritten is exactly the one that
+// leaves the window: the ones-count of the window is updated incrementally (no popcount over the ring), the cumulative
+// count feeds success_time_frac, and the metric settling index latches the first record at which a full window
+// satisfies the fraction (fixed_wing.py:1116-1128).
+__device__ __forceinline__ unsigned window_count(const Env& E, int r) { return (E.wcnt >> (8 * r)) & 0xFFu; }
 __device__ __forceinline__ void goal_push(const DevCfg& c, Env& E, unsigned g, int bit, unsigned rec_index) {
     const unsigned n_rec = rec_index + 1;
+    const unsigned m = 1u << (bit & 31);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const bool present = (r == 3) || (r < c.n_targets && c.target[r].has_bound);
+        const bool present = (r == 3) || (r < c.n_targets && c.target[r < 3 ? r : 0].has_bound);
         if (present) {
-            const bool f = (g >> r) & 1u;
-            ring_set(E.gring[r], bit, f);
-            E.gcnt[r] += f ? 1u : 0u;
+            const unsigned f = (g >> r) & 1u;
+            const unsigned old = (E.gword[r] & m) ? 1u : 0u;
+            E.gword[r] = f ? (E.gword[r] | m) : (E.gword[r] & ~m);
+            E.wcnt += (f - old) << (8 * r);     // per-byte add/subtract; each byte stays within [0, 128]
+            E.gcnt[r >> 1] += f << (16 * (r & 1));
             if (c.metrics && pack16_get(E.settle, r) == 0xFFFFu && n_rec >= (unsigned)c.streak_req &&
-                ring_popcount(E.gring[r]) >= (unsigned)c.streak_min_count)
+                window_count(E, r) >= (unsigned)c.streak_min_count)
                 pack16_set(E.settle, r, rec_index);
         }
     }
@@ -599,13 +591,15 @@ __device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, con
         for (int k = 0; k < FWG_MAX_TARGETS; ++k)
             if (k < c.n_targets) ROW(A.S, A.N, c.L.end_ring + g_end * 3 + k, e) = err[k];
     }
+    E.wcnt = 0u; E.gcnt[0] = 0u; E.gcnt[1] = 0u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        E.gcnt[r] = 0u;
+    for (int r = 0; r < 4; ++r) E.gword[r] = 0u;
+    if (c.goal_enabled) {
+        unsigned* U = reinterpret_cast<unsigned*>(A.S);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) E.gring[r][w] = 0u;
+        for (int w = 0; w < 16; ++w) ROW(U, A.N, c.L.goal_ring + w, e) = 0u;  // the word holding g_bit is rewritten by store_gym
+        goal_push(c, E, goal_flags(c, err), g_bit, 0u);
     }
-    if (c.goal_enabled) goal_push(c, E, goal_flags(c, err), g_bit, 0u);
     // ---- observation: every row is the initial record (+ per-row init noise when length > 1)
     build_row0(c, A, e, E, T, ob, ring, g_lag, true, 0);
     if (c.obs_length > 1) {

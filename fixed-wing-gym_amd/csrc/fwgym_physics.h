@@ -26,11 +26,11 @@ __device__ __forceinline__ Air airspeed(const Rot& R, float u, float v, float w,
     a.va = v - (R.r01 * wind[0] + R.r11 * wind[1] + R.r21 * wind[2]);
     a.wa = w - (R.r02 * wind[0] + R.r12 * wind[1] + R.r22 * wind[2]);
     if (TURB) { a.ua -= gust[0]; a.va -= gust[1]; a.wa -= gust[2]; }
-    const float v2 = fmaxf(a.ua * a.ua + a.va * a.va + a.wa * a.wa, 1e-30f);
-    const float rv = frsq(v2);
-    a.Va = v2 * rv;
-    a.alpha = atan2f(a.wa, a.ua);
-    a.beta = asinf(fclampf(a.va * rv, -1.f, 1.f));
+    const float xz2 = a.ua * a.ua + a.wa * a.wa;
+    const float v2 = fmaxf(xz2 + a.va * a.va, 1e-30f);
+    a.Va = v2 * frsq(v2);
+    a.alpha = fast_atan2(a.wa, a.ua);
+    a.beta = fast_atan2(a.va, xz2 * frsq(fmaxf(xz2, 1e-30f)));  // = asin(va / Va)
     return a;
 }
 
@@ -164,9 +164,10 @@ template <bool TURB>
 __device__ __forceinline__ Derived derive(const float (&y)[NY], const float (&wind)[3], const float (&gust)[6]) {
     Derived d;
     const float e0 = y[0], e1 = y[1], e2 = y[2], e3 = y[3];
-    d.roll = atan2f(2.f * (e0 * e1 + e2 * e3), e0 * e0 + e3 * e3 - e1 * e1 - e2 * e2);
-    d.pitch = asinf(fclampf(2.f * (e0 * e2 - e1 * e3), -1.f, 1.f));
-    d.yaw = atan2f(2.f * (e0 * e3 + e1 * e2), e0 * e0 + e1 * e1 - e2 * e2 - e3 * e3);
+    d.roll = fast_atan2(2.f * (e0 * e1 + e2 * e3), e0 * e0 + e3 * e3 - e1 * e1 - e2 * e2);
+    const float sp = fclampf(2.f * (e0 * e2 - e1 * e3), -1.f, 1.f);
+    d.pitch = fast_atan2(sp, __builtin_amdgcn_sqrtf(fmaxf(1.f - sp * sp, 0.f)));  // = asin(sp)
+    d.yaw = fast_atan2(2.f * (e0 * e3 + e1 * e2), e0 * e0 + e1 * e1 - e2 * e2 - e3 * e3);
     const Rot R = rot_from_quat(e0, e1, e2, e3);
     const Air a = airspeed<TURB>(R, y[10], y[11], y[12], wind, gust);
     d.Va = a.Va; d.alpha = a.alpha; d.beta = a.beta;
@@ -246,34 +247,39 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const f
     return fail;
 }
 
-// Dryden: gust sample of the current step = C x ; advance x' = A x + B n with 4 standard normals
+// Dryden: gust sample of the current step = C x ; advance x' = A x + B n with 4 standard normals.  The joint filter
+// is block structured -- states u(0) | v,r(1..3) | w,q(4..6) | p(7), one noise channel per block -- so only the
+// non-zero blocks of the dense matrices are evaluated (config.py dryden_matrices / oracle physics.dryden_continuous).
 __device__ __forceinline__ void dryden_output(const DevCfg& c, const float (&x)[FWG_N_DRYDEN], float (&gust)[6]) {
-#pragma unroll
-    for (int o = 0; o < 6; ++o) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < FWG_N_DRYDEN; ++j) s += c.dryC[o * FWG_N_DRYDEN + j] * x[j];
-        gust[o] = s;
-    }
+    const float* C = c.dryC;
+    gust[0] = C[0 * 8 + 0] * x[0];
+    gust[1] = C[1 * 8 + 1] * x[1] + C[1 * 8 + 2] * x[2] + C[1 * 8 + 3] * x[3];
+    gust[2] = C[2 * 8 + 4] * x[4] + C[2 * 8 + 5] * x[5] + C[2 * 8 + 6] * x[6];
+    gust[3] = C[3 * 8 + 7] * x[7];
+    gust[4] = C[4 * 8 + 4] * x[4] + C[4 * 8 + 5] * x[5] + C[4 * 8 + 6] * x[6];
+    gust[5] = C[5 * 8 + 1] * x[1] + C[5 * 8 + 2] * x[2] + C[5 * 8 + 3] * x[3];
 }
 __device__ __forceinline__ void dryden_advance(const DevCfg& c, float (&x)[FWG_N_DRYDEN], const float (&n)[4]) {
+    const float* A = c.dryA;
+    const float* B = c.dryB;
     float xn[FWG_N_DRYDEN];
+    xn[0] = A[0] * x[0] + B[0 * 4 + 0] * n[0];
 #pragma unroll
-    for (int i = 0; i < FWG_N_DRYDEN; ++i) {
-        float s = 0.f;
+    for (int i = 1; i < 4; ++i)
+        xn[i] = A[i * 8 + 1] * x[1] + A[i * 8 + 2] * x[2] + A[i * 8 + 3] * x[3] + B[i * 4 + 1] * n[1];
 #pragma unroll
-        for (int j = 0; j < FWG_N_DRYDEN; ++j) s += c.dryA[i * FWG_N_DRYDEN + j] * x[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s += c.dryB[i * 4 + j] * n[j];
-        xn[i] = s;
-    }
+    for (int i = 4; i < 7; ++i)
+        xn[i] = A[i * 8 + 4] * x[4] + A[i * 8 + 5] * x[5] + A[i * 8 + 6] * x[6] + B[i * 4 + 2] * n[2];
+    xn[7] = A[7 * 8 + 7] * x[7] + B[7 * 4 + 3] * n[3];
 #pragma unroll
     for (int i = 0; i < FWG_N_DRYDEN; ++i) x[i] = xn[i];
 }
+// Box-Muller with the hardware transcendental units: v_log_f32, v_sqrt_f32 and v_sin/v_cos_f32 (which take their
+// argument in revolutions, so sin(2 pi u) is a single instruction)
 __device__ __forceinline__ void box_muller(const u4& b, float (&n)[4]) {
-    const float r0 = sqrtf(-2.f * logf(u01(b.x))), r1 = sqrtf(-2.f * logf(u01(b.z)));
-    float s0, c0, s1, c1;
-    sincosf(FWG_TWO_PI * u01(b.y), &s0, &c0);
-    sincosf(FWG_TWO_PI * u01(b.w), &s1, &c1);
-    n[0] = r0 * c0; n[1] = r0 * s0; n[2] = r1 * c1; n[3] = r1 * s1;
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(b.x)));  // -2 ln u = -2 ln2 log2 u
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(b.z)));
+    const float t0 = u01(b.y), t1 = u01(b.w);
+    n[0] = r0 * __builtin_amdgcn_cosf(t0); n[1] = r0 * __builtin_amdgcn_sinf(t0);
+    n[2] = r1 * __builtin_amdgcn_cosf(t1); n[3] = r1 * __builtin_amdgcn_sinf(t1);
 }

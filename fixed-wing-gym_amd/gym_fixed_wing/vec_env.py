@@ -238,7 +238,7 @@ class FixedWingVecEnv(object):
         m = self._mem
         nat.check(self._lib, self._lib.fwg_step(self._handle, m.ptr(actions), m.ptr(self._obs), m.ptr(self._rew), m.ptr(self._done),
                                                 m.ptr(self._term), m.ptr(self._term_obs), m.ptr(self._metrics),
-                                                m.ptr(self._target), m.stream()))
+                                                ctypes.c_void_p(), m.stream()))   # targets stay in the state arena
         return self._obs, self._rew, self._done
 
     # ------------------------------------------------------------------------------------------------------------------

@@ -10,7 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
-#include <condition_variable>
+#include <functional>
+#include <ucontext.h>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -27,7 +28,7 @@ struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct emu_idx { unsigned x, y, z; };
-static thread_local emu_idx threadIdx, blockIdx, blockDim;
+static emu_idx threadIdx, blockIdx, blockDim;
 
 typedef int hipError_t;
 typedef void* hipStream_t;
@@ -44,35 +45,34 @@ static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 
-// ---- block-wide lock-step primitives -------------------------------------------------------------------------------
-struct emu_barrier {
-    std::mutex m; std::condition_variable cv; unsigned n = 0, count = 0, gen = 0;
-    void wait() {
-        std::unique_lock<std::mutex> lk(m);
-        const unsigned g = gen;
-        if (++count == n) { count = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
-    }
-};
-static emu_barrier emu_bar;
+// ---- block-wide lock-step primitives: the 64 lanes of a workgroup are fibers (ucontext) of ONE thread; a lane runs
+// until it reaches a barrier (or returns), then the next lane runs; a full round-robin pass = one barrier phase ----
+struct emu_lane { ucontext_t ctx; char* stack; int state; };  // state: 0 runnable, 1 at barrier, 2 finished
+static emu_lane emu_lanes[1024];
+static ucontext_t emu_sched_ctx;
+static unsigned emu_cur = 0;
 static uint32_t emu_xchg[1024];
 alignas(16) float lds[64 * 1024 / 4];  // the block's dynamic LDS (`extern __shared__ float lds[]` in the kernels)
+static emu_idx emu_block_idx, emu_block_dim;
 
-static inline void __syncthreads() { emu_bar.wait(); }
+static inline void __syncthreads() {
+    emu_lanes[emu_cur].state = 1;
+    swapcontext(&emu_lanes[emu_cur].ctx, &emu_sched_ctx);
+}
 static inline unsigned long long __ballot(int pred) {
     emu_xchg[threadIdx.x] = pred ? 1u : 0u;
-    emu_bar.wait();
+    __syncthreads();
     unsigned long long m = 0;
     for (unsigned i = 0; i < blockDim.x && i < 64; ++i) m |= (unsigned long long)emu_xchg[i] << i;
-    emu_bar.wait();
+    __syncthreads();
     return m;
 }
 static inline float __shfl_xor(float v, int mask, int) {
     memcpy(&emu_xchg[threadIdx.x], &v, 4);
-    emu_bar.wait();
+    __syncthreads();
     float r;
     memcpy(&r, &emu_xchg[threadIdx.x ^ (unsigned)mask], 4);
-    emu_bar.wait();
+    __syncthreads();
     return r;
 }
 static std::mutex emu_atomic_mutex;
@@ -85,22 +85,48 @@ static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 #define __expf(x) expf(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
+#define __builtin_amdgcn_sqrtf(x) sqrtf(x)
+#define __builtin_amdgcn_logf(x) log2f(x)
+#define __builtin_amdgcn_sinf(x) sinf(6.28318530717958647692f * (x))
+#define __builtin_amdgcn_cosf(x) cosf(6.28318530717958647692f * (x))
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
     (((float*)(l))[threadIdx.x] = *(const float*)(g))
 using std::max;
 using std::min;
 
+static std::function<void()> emu_body;
+static void emu_trampoline() {
+    emu_body();
+    emu_lanes[emu_cur].state = 2;
+    swapcontext(&emu_lanes[emu_cur].ctx, &emu_sched_ctx);
+}
 template <typename K, typename... Args>
 static void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
+    static const size_t STACK = 2u << 20;
+    emu_body = [=]() { kernel(args...); };
     for (unsigned b = 0; b < grid.x; ++b) {
-        emu_bar.n = block.x; emu_bar.count = 0;
-        std::vector<std::thread> ts;
-        for (unsigned t = 0; t < block.x; ++t)
-            ts.emplace_back([=]() {
+        for (unsigned t = 0; t < block.x; ++t) {
+            emu_lane& L = emu_lanes[t];
+            if (!L.stack) L.stack = (char*)malloc(STACK);
+            getcontext(&L.ctx);
+            L.ctx.uc_stack.ss_sp = L.stack;
+            L.ctx.uc_stack.ss_size = STACK;
+            L.ctx.uc_link = &emu_sched_ctx;
+            L.state = 0;
+            makecontext(&L.ctx, emu_trampoline, 0);
+        }
+        for (;;) {
+            unsigned alive = 0;
+            for (unsigned t = 0; t < block.x; ++t) {
+                if (emu_lanes[t].state == 2) continue;
+                ++alive;
+                emu_cur = t;
                 threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; blockDim = {block.x, 1, 1};
-                kernel(args...);
-            });
-        for (auto& t : ts) t.join();
+                emu_lanes[t].state = 0;
+                swapcontext(&emu_sched_ctx, &emu_lanes[t].ctx);
+            }
+            if (!alive) break;
+        }
     }
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
