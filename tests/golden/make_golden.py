@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/*.json -- BUILD CONTAINER ONLY.
+
+The gym-side half of the hot path has a true importable reference: the VERBATIM reference module
+/root/reference/gym_fixed_wing/fixed_wing.py, imported here over stub `gym` / `pyfly` packages (the
+stub `pyfly` is the oracle's restated simulator, because PyFly itself is absent).  This script drives that verbatim
+module through scripted scenarios and records inputs and outputs of reset()/step()/get_metric() as small JSON
+fixtures.  Nothing of the reference travels: a fixture holds the configuration dict that was used (data), the
+scenario inputs and the recorded outputs.
+
+    python tests/golden/make_golden.py
+
+Fixtures (G1-G3 of SURVEY.md section 8c):
+  g1_<case>.json  per-step obs / reward / done / termination / target and the episodic metrics, for the shipped config
+                  variants and the feature switches (potential reward, on_success modes, resampling, failure branch)
+  g2_curriculum.json  init/target ranges after set_curriculum_level(level) for several levels
+  g3_spaces.json      observation/action space bounds and shapes from __init__
+"""
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "fixed-wing-gym_amd"), os.path.join(ROOT, "tests"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from _ref_harness import load_reference  # noqa: E402
+import configs  # noqa: E402
+
+
+class ScriptedRNG:
+    """Deterministic stand-in for env.np_random (the attribute is public, fixed_wing.py:57): makes fixtures independent
+    of MT19937 while still exercising every draw site."""
+
+    def __init__(self):
+        self.k = 0
+
+    def _u(self):
+        self.k += 1
+        return ((self.k * 0.6180339887498949) % 1.0)
+
+    def uniform(self, low=0.0, high=1.0):
+        return low + (high - low) * self._u()
+
+    def normal(self, loc=0.0, scale=1.0):
+        return loc + scale * (2.0 * self._u() - 1.0)
+
+
+def _clean(x):
+    if isinstance(x, dict):
+        return {k: _clean(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clean(v) for v in x]
+    if isinstance(x, np.ndarray):
+        return _clean(x.tolist())
+    if isinstance(x, (np.floating, float)):
+        return None if np.isnan(x) else float(x)
+    if isinstance(x, (np.bool_, bool)):
+        return bool(x)
+    if isinstance(x, (np.integer, int)):
+        return int(x)
+    return x
+
+
+def actions_for(seed, steps, scale):
+    rng = np.random.default_rng(seed)
+    cur = rng.uniform(-1, 1, 3)
+    out = []
+    for _ in range(steps):
+        if rng.uniform() < 0.3:
+            cur = np.clip(cur + rng.normal(0, 0.4, 3), -scale, scale)
+        out.append(cur.copy())
+    return out
+
+
+SCENARIO_STATE = {"roll": 0.35, "pitch": -0.12, "yaw": 0.8, "omega_p": 0.1, "omega_q": -0.05, "omega_r": 0.02,
+                  "position_n": 0.0, "position_e": 0.0, "position_d": -100.0, "velocity_u": 19.0, "velocity_v": 0.6,
+                  "velocity_w": 1.1, "elevator": 0.0, "aileron": 0.0, "throttle": 0.4,
+                  "wind_n": 0.0, "wind_e": 0.0, "wind_d": 0.0}
+SCENARIO_TARGET = {"roll": -0.2, "pitch": 0.1, "Va": 22.0}
+
+G1_CASES = [c for c in configs.CASES if c[0] not in ("spec_c3", "cnn_step2_turb", "dev_noise")]
+
+
+def run_case(ref, case, steps=140, episodes=3):
+    name, kind, ckw, skw = case
+    cfg = configs.reference_like(kind)
+    path = os.path.join("/tmp", "golden_cfg_{}.json".format(name))
+    with open(path, "w") as f:
+        json.dump(cfg, f)
+    env = ref.FixedWingAircraft(path, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
+    env.seed(7)
+    env.np_random = ScriptedRNG()
+    rec = {"case": name, "config": cfg, "config_kw": ckw, "sim_config_kw": skw, "episodes": []}
+    acts = actions_for(3, steps, 1.8 if name == "fail_prone" else 1.3)
+    t = 0
+    for ep in range(episodes):
+        st = dict(SCENARIO_STATE)
+        st["roll"] += 0.3 * ep
+        st["velocity_u"] += 1.5 * ep
+        explicit_target = None if name in ("dynamic_targets", "resample_normalize", "potential_new") else dict(SCENARIO_TARGET)
+        obs = env.reset(state=st, target=explicit_target)
+        e = {"state": st, "target": explicit_target, "reset_obs": obs, "reset_target": dict(env.target), "steps": []}
+        while t < steps:
+            a = acts[t]
+            t += 1
+            obs, rew, done, info = env.step(a.copy())
+            step = {"action": a, "obs": obs, "reward": rew, "done": done, "target": dict(info["target"]),
+                    "termination": info.get("termination")}
+            if done:
+                step["metrics"] = {m["name"]: info[m["name"]] for m in env.cfg.get("metrics", [])}
+            e["steps"].append(step)
+            if done:
+                break
+        rec["episodes"].append(e)
+        if t >= steps:
+            break
+    return rec
+
+
+def main():
+    ref = load_reference()
+    if ref is None:
+        raise SystemExit("the reference is not mounted: fixtures can only be regenerated in the build container")
+    for case in G1_CASES:
+        rec = run_case(ref, case)
+        with open(os.path.join(HERE, "g1_{}.json".format(case[0])), "w") as f:
+            json.dump(_clean(rec), f)
+        print("g1", case[0], sum(len(e["steps"]) for e in rec["episodes"]), "steps",
+              [e["steps"][-1]["termination"] for e in rec["episodes"]])
+
+    # G2: curriculum ranges (fixed_wing.py:224-285)
+    cfg = configs.reference_like("default")
+    path = "/tmp/golden_cfg_default.json"
+    with open(path, "w") as f:
+        json.dump(cfg, f)
+    env = ref.FixedWingAircraft(path)
+    g2 = {"config": cfg, "levels": {}}
+    for level in (0, 0.25, 0.5, 1):
+        env.set_curriculum_level(level)
+        sim = {n: {p: getattr(v, p) for p in ("init_min", "init_max", "constraint_min", "constraint_max", "value_min", "value_max")}
+               for n, v in env.simulator.state.items() if n in ("roll", "pitch", "velocity_u", "velocity_v", "velocity_w",
+                                                                "omega_p", "omega_q", "omega_r", "Va")}
+        g2["levels"][str(level)] = {"simulator": sim, "target": copy.deepcopy(env._target_props_init)}
+    with open(os.path.join(HERE, "g2_curriculum.json"), "w") as f:
+        json.dump(_clean(g2), f)
+
+    # G3: spaces (fixed_wing.py:62-191)
+    g3 = {}
+    for kind in ("default", "examples", "mlp", "cnn", "dev"):
+        cfg = configs.reference_like(kind)
+        path = "/tmp/golden_cfg_{}.json".format(kind)
+        with open(path, "w") as f:
+            json.dump(cfg, f)
+        for norm in (False, True):
+            env = ref.FixedWingAircraft(path, config_kw={"observation": {"normalize": norm}} if "normalize" in cfg["observation"] or norm is False else None) \
+                if ("normalize" in cfg["observation"]) else ref.FixedWingAircraft(path)
+            g3["{}_{}".format(kind, int(norm))] = {
+                "config": cfg, "normalize": norm if "normalize" in cfg["observation"] else None,
+                "obs_low": env.observation_space.low, "obs_high": env.observation_space.high,
+                "act_low": env.action_space.low, "act_high": env.action_space.high,
+                "scale_to_low": env.action_scale_to_low, "scale_to_high": env.action_scale_to_high,
+                "norm": [[o.get("mean", None), o.get("var", None)] for o in env.cfg["observation"]["states"]]}
+    with open(os.path.join(HERE, "g3_spaces.json"), "w") as f:
+        json.dump(_clean(g3), f)
+    print("g2/g3 written")
+
+
+if __name__ == "__main__":
+    main()

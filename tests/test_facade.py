@@ -1,0 +1,102 @@
+"""The reference-compatible single-env class (gym_fixed_wing.fixed_wing.FixedWingAircraft) and the VecEnv surface used
+by the reference's example scripts, exercised on the host-emulation build."""
+import os
+
+import numpy as np
+import pytest
+
+import configs
+import parity
+from emu.host_backend import HostBackend, build_emu
+from gym_fixed_wing.fixed_wing import FixedWingAircraft
+from gym_fixed_wing.vec_env import FixedWingVecEnv
+
+STATE = {"roll": 0.3, "pitch": -0.1, "yaw": 0.5, "omega_p": 0.0, "omega_q": 0.0, "omega_r": 0.0, "position_n": 0.0,
+         "position_e": 0.0, "position_d": -100.0, "velocity_u": 20.0, "velocity_v": 0.0, "velocity_w": 1.0,
+         "elevator": 0.0, "aileron": 0.0, "throttle": 0.5, "wind_n": 0.0, "wind_e": 0.0, "wind_d": 0.0}
+TARGET = {"roll": 0.0, "pitch": 0.05, "Va": 21.0}
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    return build_emu()
+
+
+def test_single_env_api_matches_oracle(emu_lib, tmp_path):
+    cfg = configs.default()
+    ckw = {"steps_max": 40}
+    env = FixedWingAircraft(cfg, config_kw=ckw, _backend=HostBackend(), _lib_path=emu_lib)
+    orc = parity.make_oracles(cfg, 1, 0, config_kw=ckw)[0]
+    assert env.observation_space.shape == (14,) and env.action_space.shape == (3,)
+    assert env.seed(0) == [0]
+    obs = env.reset(state=STATE, target=TARGET)
+    want = orc.reset(state=STATE, target=TARGET)
+    assert obs.dtype == np.float64 and obs.shape == (14,)
+    np.testing.assert_allclose(obs, want, atol=1e-5)
+    assert env.target == pytest.approx(TARGET)
+    assert env.simulator.state["roll"].value == pytest.approx(0.3, abs=1e-6)
+    rng = np.random.default_rng(0)
+    done = False
+    steps = 0
+    env.training = False
+    while not done:
+        a = rng.uniform(-1, 1, 3)
+        obs, rew, done, info = env.step(a)
+        o2, r2, d2, i2 = orc.step(a)
+        steps += 1
+        np.testing.assert_allclose(obs, o2, atol=2e-3, rtol=2e-3)
+        assert rew == pytest.approx(r2, abs=2e-3) and done == d2
+        assert set(info["target"]) == {"roll", "pitch", "Va"}
+    assert steps == 40 and info["termination"] == "steps" and env.steps_count == 40
+    assert set(info["success"]) == {"roll", "pitch", "Va", "all"}
+    assert env.get_metric("total_error")["Va"] == pytest.approx(i2["total_error"]["Va"], rel=1e-2)
+    assert len(env.history["action"]) == 40 and len(env.history["target"]["Va"]) == 41
+    assert len(env.simulator.state["roll"].history) == 41
+    with pytest.raises(AssertionError):
+        env.step(np.array([np.nan, 0, 0]))
+    png = str(tmp_path / "render" / "ep.png")
+    env.render(show=False, close=True, save_path=png)
+    assert os.path.getsize(png) > 10000
+    npy = str(tmp_path / "hist.npy")
+    env.save_history(npy, ["roll", "Va"])
+    saved = np.load(npy, allow_pickle=True).item()
+    assert len(saved["roll"]) == 41 and len(saved["Va_target"]) == 41
+    rec = env.get_initial_state()
+    assert rec["state"]["velocity_u"] == pytest.approx(20.0) and rec["target"]["Va"] == pytest.approx(21.0)
+    # while training, render is deferred to the next reset (fixed_wing.py:584-587)
+    env.training = True
+    assert env.render(show=False, save_path=str(tmp_path / "deferred.png")) is None and env.render_on_reset
+    env.reset()
+    assert os.path.exists(str(tmp_path / "deferred.png")) and not env.render_on_reset
+    env.close()
+
+
+def test_vecenv_contract(emu_lib):
+    cfg = configs.default()
+    vec = FixedWingVecEnv(cfg, num_envs=4, config_kw={"steps_max": 6}, as_numpy=True, _backend=HostBackend(), _lib_path=emu_lib)
+    assert vec.num_envs == 4 and vec.observation_space.shape == (14,)
+    obs = vec.reset()
+    assert obs.shape == (4, 14) and obs.dtype == np.float32
+    vec.step_async(np.zeros((4, 3), dtype=np.float32))
+    obs, rew, done, infos = vec.step_wait()
+    assert rew.shape == (4,) and done.shape == (4,) and len(infos) == 4 and "target" in infos[0]
+    for _ in range(5):
+        obs, rew, done, infos = vec.step(np.zeros((4, 3), dtype=np.float32))
+    assert done.all()
+    info = infos[2]
+    assert info["termination"] == "steps" and info["TimeLimit.truncated"] is True
+    assert info["terminal_observation"].shape == (14,)
+    assert not np.allclose(info["terminal_observation"], obs[2])        # obs is the first one of the next episode
+    steps = vec.get_state(["steps_count"])["steps_count"]
+    assert (steps == 0).all()
+    assert vec.get_attr("cfg")[0]["steps_max"] == 6 and vec.get_attr("simulator")[0].dt == 0.01
+    vec.env_method("set_curriculum_level", 0.25)
+    assert vec.env_config.state["roll"].init_max == pytest.approx(np.radians(110 * 0.25))
+    out = vec.env_method("reset", indices=1, state={"roll": 0.2}, target={"roll": 0.1, "pitch": 0.0, "Va": 20.0})
+    assert out[0].shape == (14,) and out[0][0] == pytest.approx(0.2, abs=1e-6) and out[0][6] == pytest.approx(0.1, abs=1e-6)
+    vec.set_attr("training", False)
+    assert vec.training is False
+    vec.check_actions = True
+    with pytest.raises(AssertionError):
+        vec.step(np.full((4, 3), np.nan, dtype=np.float32))
+    vec.close()
