@@ -90,15 +90,11 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 
     // ---- phase A: issue every load up front.  The action windows stream HBM -> LDS (global_load_lds, no VGPRs, they
     // are addressed by the run-time ring slot); everything else goes to registers.
-    for (int s = 0; s < W * 3; ++s) dma_row(&ROW(A.S, A.N, L.act_ring + s, e), lds + M.aring + s * FWG_WAVE);
-    if (c.use_cmd_ring)
-        for (int s = 0; s < W * 3; ++s) dma_row(&ROW(A.S, A.N, L.cmd_ring + s, e), lds + M.cring + s * FWG_WAVE);
     float raw[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) raw[i] = A.actions[e * 3 + i];   // [N][3]: a wave reads 768 contiguous bytes
-    stream_lag_rows(c, A, e, lds + M.lag);
     Env E;
-    load_env<TURB>(c, A.S, A.N, e, E, A.bit_goal);
+    load_sim<TURB>(c, A.S, A.N, e, E);
 
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
     // LDS copy once the streamed window has landed, i.e. after the integration)
@@ -122,13 +118,15 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         for (int i = 0; i < 3; ++i)
             if (valid) ROW(A.S, A.N, L.cmd_ring + A.slot_act * 3 + i, e) = cmd_c[i];
     }
-    if (c.metrics) {  // control_variation accumulator (fixed_wing.py:1109-1114)
-        if (E.steps > 0u) E.sdcmd += fabsf(cmd_c[0] - E.pcmd[0]) + fabsf(cmd_c[1] - E.pcmd[1]) + fabsf(cmd_c[2] - E.pcmd[2]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) E.pcmd[i] = cmd_c[i];
-    }
     float gust[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (TURB) dryden_output(c, E.dry, gust);
+    // second wave of requests: bookkeeping rows to registers, action windows and lagged observation rows HBM -> LDS;
+    // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
+    for (int s = 0; s < W * 3; ++s) dma_row(&ROW(A.S, A.N, L.act_ring + s, e), lds + M.aring + s * FWG_WAVE);
+    if (c.use_cmd_ring)
+        for (int s = 0; s < W * 3; ++s) dma_row(&ROW(A.S, A.N, L.cmd_ring + s, e), lds + M.cring + s * FWG_WAVE);
+    stream_lag_rows(c, A, e, lds + M.lag);
+    load_gym(c, A.S, A.N, e, E, A.bit_goal);
     const int fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
     const bool ok = fail == 0;
     if (!ok) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
@@ -148,6 +146,11 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     }
 
     // ---- phase C: gym-side bookkeeping (fixed_wing.py:360-417)
+    if (c.metrics) {  // control_variation accumulator (fixed_wing.py:1109-1114)
+        if (E.steps > 0u) E.sdcmd += fabsf(cmd_c[0] - E.pcmd[0]) + fabsf(cmd_c[1] - E.pcmd[1]) + fabsf(cmd_c[2] - E.pcmd[2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) E.pcmd[i] = cmd_c[i];
+    }
     E.steps += 1u;
     E.sft += 1u;
     bool done = false;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     typename KT::Tab T = KT::tab(lds, M, lane);
     typename KT::Obs ob = KT::obs(lds, M, lane);
     Env E;
-    load_env<TURB>(c, A.S, A.N, e, E, A.bit_goal);
+    load_gym(c, A.S, A.N, e, E, A.bit_goal);
     if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane, A.slot_end, A.slot_lag, A.bit_goal);
     write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
     if (sel) {

@@ -89,10 +89,11 @@ struct Env {
 // entry j of the record of env e in slot `slot` of a ring that starts at arena row `base` (SoA rows [slot][entry][env])
 #define RING(S, N, base, slot, width, e, j) ROW(S, N, (base) + (slot) * (width) + (j), e)
 
+// The load is split like the write-back: the simulator state is requested first (the integration starts as soon as it
+// arrives); the bookkeeping rows and the HBM->LDS streams are requested afterwards and land while the integration runs.
 template <bool TURB>
-__device__ __forceinline__ void load_env(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E, int goal_bit) {
+__device__ __forceinline__ void load_sim(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
     const fwg_layout& L = c.L;
-    const unsigned* U = reinterpret_cast<const unsigned*>(S);
 #pragma unroll
     for (int i = 0; i < NY; ++i) E.y[i] = ROW(S, N, L.phys + i, e);
 #pragma unroll
@@ -101,6 +102,11 @@ __device__ __forceinline__ void load_env(const DevCfg& c, const float* __restric
 #pragma unroll
         for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = ROW(S, N, L.dryden + i, e);
     }
+}
+
+__device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E, int goal_bit) {
+    const fwg_layout& L = c.L;
+    const unsigned* U = reinterpret_cast<const unsigned*>(S);
     // the derived rows (roll pitch yaw Va alpha beta) are write-only for the kernels: after a failed step they are
     // recomputed from the restored state
 #pragma unroll
