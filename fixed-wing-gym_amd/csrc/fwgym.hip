@@ -85,8 +85,8 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     const int W = L.window;
     typename KT::Tab T = KT::tab(lds, M, lane);
     typename KT::Obs ob = KT::obs(lds, M, lane);
-    float* aring = lds + M.aring + lane;   // this lane's column of the raw-action window [slot*3 + actuator][lane]
-    float* cring = lds + M.cring + lane;   // ... of the constrained-command window (only when observations need it)
+    float* aring = lds + M.aring + lane * 4;   // this lane's entries of the raw-action window [slot][lane][4]
+    float* cring = lds + M.cring + lane * 4;   // ... of the constrained-command window (only when observations need it)
 
     // ---- phase A: issue every load up front.  The action windows stream HBM -> LDS (global_load_lds, no VGPRs, they
     // are addressed by the run-time ring slot); everything else goes to registers.
@@ -98,9 +98,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
     // LDS copy once the streamed window has landed, i.e. after the integration)
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (valid) ROW(A.S, A.N, L.act_ring + A.slot_act * 3 + i, e) = raw[i];
+    if (valid) GROUP(A.S, A.N, (L.act_ring >> 2) + A.slot_act, e) = make_float4(raw[0], raw[1], raw[2], 0.f);
 
     // ---- phase B: action scaling (fixed_wing.py:349-354,439-459) and the simulator step (fixed_wing.py:358)
     float cmd[3];
@@ -113,20 +111,17 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     }
     float cmd_c[3], sp[3];
     constrain_commands(c, cmd, cmd_c, sp);
-    if (c.use_cmd_ring) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (valid) ROW(A.S, A.N, L.cmd_ring + A.slot_act * 3 + i, e) = cmd_c[i];
-    }
+    if (c.use_cmd_ring && valid)
+        GROUP(A.S, A.N, (L.cmd_ring >> 2) + A.slot_act, e) = make_float4(cmd_c[0], cmd_c[1], cmd_c[2], 0.f);
     float gust[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (TURB) dryden_output(c, E.dry, gust);
     // second wave of requests: bookkeeping rows to registers, action windows and lagged observation rows HBM -> LDS;
     // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
-    for (int s = 0; s < W * 3; ++s) dma_row(&ROW(A.S, A.N, L.act_ring + s, e), lds + M.aring + s * FWG_WAVE);
+    for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.act_ring >> 2) + s, e), lds + M.aring + s * (4 * FWG_WAVE));
     if (c.use_cmd_ring)
-        for (int s = 0; s < W * 3; ++s) dma_row(&ROW(A.S, A.N, L.cmd_ring + s, e), lds + M.cring + s * FWG_WAVE);
+        for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
     stream_lag_rows(c, A, e, lds + M.lag);
-    load_gym(c, A.S, A.N, e, E, A.bit_goal);
+    load_gym(c, A.S, A.N, e, E);
     const int fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
     const bool ok = fail == 0;
     if (!ok) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
@@ -136,13 +131,13 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         box_muller(b, n);
         dryden_advance(c, E.dry, n);
     }
-    if (valid) store_sim<TURB>(c, A.S, A.N, e, E, false);
+    if (valid) store_sim<TURB>(c, A.S, A.N, e, E);
     // everything streamed HBM -> LDS at kernel start is needed from here on; the integration above hid its latency
     dma_wait();
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        aring[(A.slot_act * 3 + i) * FWG_WAVE] = raw[i];
-        if (c.use_cmd_ring) cring[(A.slot_act * 3 + i) * FWG_WAVE] = cmd_c[i];
+        aring[A.slot_act * (4 * FWG_WAVE) + i] = raw[i];
+        if (c.use_cmd_ring) cring[A.slot_act * (4 * FWG_WAVE) + i] = cmd_c[i];
     }
 
     // ---- phase C: gym-side bookkeeping (fixed_wing.py:360-417)
@@ -195,7 +190,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
                                 int s_old = A.slot_act - k - 1; s_old += (s_old < 0) ? W : 0;
 #pragma unroll
                                 for (int i = 0; i < 3; ++i)
-                                    val += fabsf(aring[(s_new * 3 + i) * FWG_WAVE] - aring[(s_old * 3 + i) * FWG_WAVE]);
+                                    val += fabsf(aring[s_new * (4 * FWG_WAVE) + i] - aring[s_old * (4 * FWG_WAVE) + i]);
                             }
                         }
                     }
@@ -273,8 +268,8 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
                 E.esum[k] += err[k]; E.eabs[k] += fabsf(err[k]);
                 E.emin[k] = fminf(E.emin[k], err[k]); E.emax[k] = fmaxf(E.emax[k], err[k]);
                 E.perr[k] = err[k];
-                if (valid) ROW(A.S, A.N, L.end_ring + A.slot_end * 3 + k, e) = err[k];
             }
+            if (valid) GROUP(A.S, A.N, (L.end_ring >> 2) + A.slot_end, e) = make_float4(err[0], err[1], err[2], 0.f);
         }
     } else {
         done = true;
@@ -289,10 +284,10 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         }
     }
 
-    if (valid) store_gym(c, A.S, A.N, e, E, false, A.bit_goal);
+    if (valid) store_gym(c, A.S, A.N, e, E);
 
     // ---- phase D: observation (fixed_wing.py:776-846)
-    load_lag_rows(c, lds + M.lag + lane, ob);
+    load_lag_rows(c, lds + M.lag + lane * 4, ob);
     build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid, A.slot_act);
     if (c.obs_length > 1 && (!ok || (int)E.steps <= (c.obs_length - 1) * c.obs_step))
         fix_lagged_rows(c, A, e, E, T, ob, ok);
@@ -326,7 +321,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
                     float s = 0.f;
                     for (int q = 0; q < cnt; ++q) {
                         int slot = p - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
-                        s += ROW(A.S, A.N, L.end_ring + slot * 3 + k, e);
+                        s += A.S[(((unsigned)(L.end_ring >> 2) + (unsigned)slot) * (unsigned)A.N + (unsigned)e) * 4u + (unsigned)k];
                     }
                     mt[FWG_M_END_ERROR + k] = fabsf(s / (float)cnt);
                 }
@@ -345,7 +340,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
                 }
                 if (A.metrics != nullptr) {
 #pragma unroll
-                    for (int i = 0; i < FWG_N_METRICS; ++i) ROW(A.metrics, A.N, i, e) = mt[i];
+                    for (int i = 0; i < FWG_N_METRICS; ++i) A.metrics[(unsigned)i * (unsigned)A.N + (unsigned)e] = mt[i];
                 }
                 red[0] = 1.f;
 #pragma unroll
@@ -373,8 +368,8 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         }
         if (c.auto_reset && done && valid) {
             reset_env<TURB>(c, dc, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal);
-            store_sim<TURB>(c, A.S, A.N, e, E, true);
-            store_gym(c, A.S, A.N, e, E, true, A.bit_goal);
+            store_sim<TURB>(c, A.S, A.N, e, E);
+            store_gym(c, A.S, A.N, e, E);
         }
     }
 
@@ -412,12 +407,12 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     typename KT::Tab T = KT::tab(lds, M, lane);
     typename KT::Obs ob = KT::obs(lds, M, lane);
     Env E;
-    load_gym(c, A.S, A.N, e, E, A.bit_goal);
-    if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane, A.slot_end, A.slot_lag, A.bit_goal);
+    load_gym(c, A.S, A.N, e, E);
+    if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane * 4, A.slot_end, A.slot_lag, A.bit_goal);
     write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
     if (sel) {
-        store_sim<TURB>(c, A.S, A.N, e, E, true);
-        store_gym(c, A.S, A.N, e, E, true, A.bit_goal);
+        store_sim<TURB>(c, A.S, A.N, e, E);
+        store_gym(c, A.S, A.N, e, E);
         if (A.tgt_out != nullptr) {
 #pragma unroll
             for (int k = 0; k < FWG_MAX_TARGETS; ++k)
@@ -481,23 +476,19 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
         if (c.factor[f].cls == FWG_RC_ACTION && c.factor[f].type == FWG_RT_DELTA && c.factor[f].window > window)
             window = c.factor[f].window;
     if (window > FWG_MAX_WINDOW) { *why = "action window_size > 8"; return -1; }
+    // all offsets are in 32-bit words and multiples of 4: the arena is addressed in 16-byte groups [group][env]
     int o = 0;
-    L->phys = o; o += NY;
-    L->wind = o; o += 3;
-    L->dryden = o; o += c.turbulence ? FWG_N_DRYDEN : 0;
-    L->derived = o; o += 6;
-    L->target = o; o += 3 + 4 * FWG_MAX_TARGETS;
-    L->counters = o; o += 4;
-    L->prev_shaping = o; o += 3;
-    L->act_ring = o; o += window * 3;
-    L->cmd_ring = o; o += use_cmd ? window * 3 : 0;
-    L->prev_cmd = o; o += 3;
-    L->goal_ring = o; o += 16;
-    L->goal_count = o; o += 4;
-    L->met = o; o += 24;
-    L->end_ring = o; o += FWG_END_WINDOW * 3;
+    L->sim = o; o += 32;                 // y[18] | wind[3] | dryden[8] | pad
+    L->derived = o; o += 8;              // roll pitch yaw Va | alpha beta pad pad
+    L->gym = o; o += 40;                 // 10 bookkeeping groups (see load_gym)
+    L->tprop = o; o += 4 * FWG_MAX_TARGETS;
+    L->goal = o; o += 16;                // 4 windows x 4 words
+    L->act_ring = o; o += window * 4;    // raw actions, one group per slot, slot = global_step % window
+    L->cmd_ring = o; o += use_cmd ? window * 4 : 0;
+    L->end_ring = o; o += FWG_END_WINDOW * 4;
     L->lag_depth = c.obs_length > 1 ? (c.obs_length - 1) * c.obs_step + 1 : 0;
-    L->lag_ring = o; o += L->lag_depth * c.n_obs;
+    L->lag_groups = (c.n_obs + 3) / 4;
+    L->lag_ring = o; o += L->lag_depth * L->lag_groups * 4;
     L->window = window;
     L->rows = o;
     return use_cmd;
@@ -688,7 +679,7 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     h->spec = match_spec(h->h);
     h->n_envs = n_envs; h->env_base = env_id_base; h->device = device; h->seed = 0; h->gstep = 0;
     h->arena = (float*)state_arena;
-    if ((int64_t)h->h.L.rows * n_envs >= (int64_t)1 << 31) { delete h; return fail_with(FWG_ERR_INVALID, "rows*n_envs must be < 2^31"); }
+    if ((int64_t)h->h.L.rows * n_envs >= (int64_t)1 << 30) { delete h; return fail_with(FWG_ERR_INVALID, "rows*n_envs must be < 2^30"); }
     if (lds_map(h->h.obs_dim, h->h.n_obs, h->h.L.window, h->h.use_cmd_ring, true).total * sizeof(float) > 64 * 1024) {
         delete h; return fail_with(FWG_ERR_INVALID, "observation too large for the LDS scratch");
     }

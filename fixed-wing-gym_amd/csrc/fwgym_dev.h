@@ -150,9 +150,9 @@ __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5
 typedef __attribute__((address_space(1))) const void* fwg_gptr;
 typedef __attribute__((address_space(3))) void* fwg_lptr;
 
-// async HBM -> LDS copy of one SoA row segment (64 consecutive words) for this wave
-__device__ __forceinline__ void dma_row(const float* src_lane_ptr, float* lds_row) {
-    __builtin_amdgcn_global_load_lds((fwg_gptr)src_lane_ptr, (fwg_lptr)lds_row, 4, 0, 0);
+// async HBM -> LDS copy of one 16-byte group per lane (1 KiB per wave, landing as [lane][4]) -- global_load_lds_dwordx4
+__device__ __forceinline__ void dma_group(const float4* src_lane_ptr, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((fwg_gptr)src_lane_ptr, (fwg_lptr)lds_dst, 16, 0, 0);
 }
 // the compiler does not order LDS reads behind an in-flight global_load_lds: drain the vector-memory counter by hand
 #ifndef FWG_DMA_DRAIN

@@ -39,9 +39,10 @@ __host__ __device__ inline int obs_stage_stride(int obs_dim) { return obs_vec4(o
 __host__ __device__ inline LdsMap lds_map(int obs_dim, int n_obs, int window, int use_cmd_ring, bool generic) {
     LdsMap m;
     int o = 0;
-    m.aring = o; o += window * 3 * FWG_WAVE;
-    m.cring = o; o += (use_cmd_ring ? window * 3 * FWG_WAVE : 0);
-    m.lag = o; o += (obs_dim - n_obs) * FWG_WAVE;          // lagged rows streamed in as SoA rows [entry][lane]
+    const int rows = obs_dim / n_obs, ng = (n_obs + 3) / 4;
+    m.aring = o; o += window * 4 * FWG_WAVE;               // action window [slot][lane][4]
+    m.cring = o; o += (use_cmd_ring ? window * 4 * FWG_WAVE : 0);
+    m.lag = o; o += (rows - 1) * ng * 4 * FWG_WAVE;        // lagged records [row-1][group][lane][4]
     m.stage = o; o += FWG_WAVE * obs_stage_stride(obs_dim);  // [lane][obs_dim] staging of the output records
     m.tab = o; o += generic ? FWG_TAB_ROWS * FWG_WAVE : 0;
     m.obs = o; o += generic ? obs_dim * FWG_WAVE : 0;
@@ -73,8 +74,8 @@ struct Env {
     unsigned steps, sft, flags, episode;
     float psh[3];
     float pcmd[3];
-    unsigned gword[4];   // the 32-bit word of each goal window that holds this step's bit position
-    unsigned wcnt;       // ones inside each window, 4 x 8 bit (windows hold success_streak_req <= 128 flags)
+    unsigned gring[4][4]; // goal windows (target0..2, all): rings of success_streak_req <= 128 bits
+    unsigned wcnt;       // ones inside each window, 4 x 8 bit
     unsigned gcnt[2];    // cumulative ones per window since reset, 4 x 16 bit
     float e0[3], esum[3], eabs[3], emin[3], emax[3];
     unsigned rise[3];
@@ -83,125 +84,117 @@ struct Env {
     float sdcmd;
 };
 
-// element (row r, env e) of the SoA arena; 32-bit indices (fwg_create guarantees rows*N < 2^31) keep the address
-// arithmetic to one scalar multiply + one vector add per access
-#define ROW(S, N, r, e) ((S)[(unsigned)(r) * (unsigned)(N) + (unsigned)(e)])
-// entry j of the record of env e in slot `slot` of a ring that starts at arena row `base` (SoA rows [slot][entry][env])
-#define RING(S, N, base, slot, width, e, j) ROW(S, N, (base) + (slot) * (width) + (j), e)
+// Arena addressing.  The arena is an array of 16-byte GROUPS [group][env]: word w of env e lives in group w>>2,
+// component w&3.  A wave touching one group of its 64 envs moves 1 KiB with ONE vector-memory instruction -- the per-CU
+// address path costs about the same per instruction whether a lane moves 4 or 16 bytes, so the number of instructions,
+// not the bytes, is what the layout minimises.  32-bit indices (fwg_create guarantees groups*N < 2^28).
+#define GROUP(S, N, g, e) (reinterpret_cast<float4*>(S)[(unsigned)(g) * (unsigned)(N) + (unsigned)(e)])
+#define CGROUP(S, N, g, e) (reinterpret_cast<const float4*>(S)[(unsigned)(g) * (unsigned)(N) + (unsigned)(e)])
+__device__ __forceinline__ float u2f(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
 
-// The load is split like the write-back: the simulator state is requested first (the integration starts as soon as it
-// arrives); the bookkeeping rows and the HBM->LDS streams are requested afterwards and land while the integration runs.
+// simulator block: 8 groups = y[18] | wind[3] | dryden[8] | 3 pad
 template <bool TURB>
 __device__ __forceinline__ void load_sim(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
-    const fwg_layout& L = c.L;
+    const int g0 = c.L.sim >> 2;
+    float f[32];
 #pragma unroll
-    for (int i = 0; i < NY; ++i) E.y[i] = ROW(S, N, L.phys + i, e);
+    for (int g = 0; g < (TURB ? 8 : 6); ++g) {
+        const float4 q = CGROUP(S, N, g0 + g, e);
+        f[4 * g] = q.x; f[4 * g + 1] = q.y; f[4 * g + 2] = q.z; f[4 * g + 3] = q.w;
+    }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) E.wind[i] = ROW(S, N, L.wind + i, e);
+    for (int i = 0; i < NY; ++i) E.y[i] = f[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) E.wind[i] = f[NY + i];
     if (TURB) {
 #pragma unroll
-        for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = ROW(S, N, L.dryden + i, e);
+        for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = f[NY + 3 + i];
     }
 }
 
-__device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E, int goal_bit) {
-    const fwg_layout& L = c.L;
-    const unsigned* U = reinterpret_cast<const unsigned*>(S);
-    // the derived rows (roll pitch yaw Va alpha beta) are write-only for the kernels: after a failed step they are
-    // recomputed from the restored state
-#pragma unroll
-    for (int k = 0; k < FWG_MAX_TARGETS; ++k) E.tgt[k] = ROW(S, N, L.target + k, e);
-    if (c.any_dynamic_target) {
-#pragma unroll
-        for (int k = 0; k < FWG_MAX_TARGETS; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) E.tprop[k][j] = ROW(S, N, L.target + 3 + k * 4 + j, e);
-    }
-    E.steps = ROW(U, N, L.counters + 0, e); E.sft = ROW(U, N, L.counters + 1, e);
-    E.flags = ROW(U, N, L.counters + 2, e); E.episode = ROW(U, N, L.counters + 3, e);
-    if (c.reward_potential) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) E.psh[i] = ROW(S, N, L.prev_shaping + i, e);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) E.pcmd[i] = ROW(S, N, L.prev_cmd + i, e);
-    if (c.goal_enabled) {  // only the word that receives this step's flag is touched; the window counts are kept apart
-#pragma unroll
-        for (int r = 0; r < 4; ++r) E.gword[r] = ROW(U, N, L.goal_ring + r * 4 + (goal_bit >> 5), e);
-        E.wcnt = ROW(U, N, L.goal_count + 0, e);
-        E.gcnt[0] = ROW(U, N, L.goal_count + 1, e); E.gcnt[1] = ROW(U, N, L.goal_count + 2, e);
-    }
-    if (c.metrics) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            E.e0[k] = ROW(S, N, L.met + 0 + k, e); E.esum[k] = ROW(S, N, L.met + 3 + k, e);
-            E.eabs[k] = ROW(S, N, L.met + 6 + k, e); E.emin[k] = ROW(S, N, L.met + 9 + k, e);
-            E.emax[k] = ROW(S, N, L.met + 12 + k, e); E.rise[k] = ROW(U, N, L.met + 15 + k, e);
-            E.perr[k] = ROW(S, N, L.met + 20 + k, e);
-        }
-        E.settle[0] = ROW(U, N, L.met + 18, e); E.settle[1] = ROW(U, N, L.met + 19, e);
-        E.sdcmd = ROW(S, N, L.met + 23, e);
-    }
-}
-
-// The write-back is split so that each part is issued as soon as its values are final: the simulator state right after
+// The write-back is split so that each part is issued as soon as its values are final: the simulator block right after
 // the integration, the bookkeeping after the gym logic -- the store traffic then overlaps the remaining computation
 // instead of forming one burst at the end of the kernel.
 template <bool TURB>
-__device__ __forceinline__ void store_sim(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E, bool with_wind) {
-    const fwg_layout& L = c.L;
+__device__ __forceinline__ void store_sim(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E) {
+    const int g0 = c.L.sim >> 2;
+    float f[32];
 #pragma unroll
-    for (int i = 0; i < NY; ++i) ROW(S, N, L.phys + i, e) = E.y[i];
-    if (with_wind) {  // the steady wind only changes at reset
+    for (int i = 0; i < NY; ++i) f[i] = E.y[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ROW(S, N, L.wind + i, e) = E.wind[i];
-    }
-    if (TURB) {
+    for (int i = 0; i < 3; ++i) f[NY + i] = E.wind[i];
 #pragma unroll
-        for (int i = 0; i < FWG_N_DRYDEN; ++i) ROW(S, N, L.dryden + i, e) = E.dry[i];
-    }
-    ROW(S, N, L.derived + 0, e) = E.d.roll; ROW(S, N, L.derived + 1, e) = E.d.pitch; ROW(S, N, L.derived + 2, e) = E.d.yaw;
-    ROW(S, N, L.derived + 3, e) = E.d.Va; ROW(S, N, L.derived + 4, e) = E.d.alpha; ROW(S, N, L.derived + 5, e) = E.d.beta;
+    for (int i = 0; i < FWG_N_DRYDEN; ++i) f[NY + 3 + i] = TURB ? E.dry[i] : 0.f;
+    f[29] = 0.f; f[30] = 0.f; f[31] = 0.f;
+#pragma unroll
+    for (int g = 0; g < (TURB ? 8 : 6); ++g) GROUP(S, N, g0 + g, e) = make_float4(f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+    // derived values of the committed state (write-only for the kernels: host views, controllers, rendering)
+    GROUP(S, N, (c.L.derived >> 2), e) = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
+    GROUP(S, N, (c.L.derived >> 2) + 1, e) = make_float4(E.d.alpha, E.d.beta, 0.f, 0.f);
 }
 
-__device__ __forceinline__ void store_gym(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E, bool at_reset,
-                                          int goal_bit) {
-    const fwg_layout& L = c.L;
-    unsigned* U = reinterpret_cast<unsigned*>(S);
+// bookkeeping block, 10 groups:
+//  0: tgt0 tgt1 tgt2 steps | 1: sft flags episode wcnt | 2: gcnt0 gcnt1 pcmd0 pcmd1 | 3: pcmd2 sdcmd settle0 settle1
+//  4: e0[0..2] rise0 | 5: esum[0..2] rise1 | 6: eabs[0..2] rise2 | 7: emin[0..2] perr0 | 8: emax[0..2] perr1
+//  9: perr2 psh0 psh1 psh2        then 3 groups of target properties and 4 groups of goal windows
+__device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
+    const int g0 = c.L.gym >> 2;
+    float4 q[10];
 #pragma unroll
-    for (int k = 0; k < FWG_MAX_TARGETS; ++k) ROW(S, N, L.target + k, e) = E.tgt[k];
+    for (int g = 0; g < 10; ++g)
+        if (g < 4 || c.metrics || (g == 9 && c.reward_potential)) q[g] = CGROUP(S, N, g0 + g, e);
+    E.tgt[0] = q[0].x; E.tgt[1] = q[0].y; E.tgt[2] = q[0].z; E.steps = f2u(q[0].w);
+    E.sft = f2u(q[1].x); E.flags = f2u(q[1].y); E.episode = f2u(q[1].z); E.wcnt = f2u(q[1].w);
+    E.gcnt[0] = f2u(q[2].x); E.gcnt[1] = f2u(q[2].y); E.pcmd[0] = q[2].z; E.pcmd[1] = q[2].w;
+    E.pcmd[2] = q[3].x; E.sdcmd = q[3].y; E.settle[0] = f2u(q[3].z); E.settle[1] = f2u(q[3].w);
+    if (c.metrics) {
+        E.e0[0] = q[4].x; E.e0[1] = q[4].y; E.e0[2] = q[4].z; E.rise[0] = f2u(q[4].w);
+        E.esum[0] = q[5].x; E.esum[1] = q[5].y; E.esum[2] = q[5].z; E.rise[1] = f2u(q[5].w);
+        E.eabs[0] = q[6].x; E.eabs[1] = q[6].y; E.eabs[2] = q[6].z; E.rise[2] = f2u(q[6].w);
+        E.emin[0] = q[7].x; E.emin[1] = q[7].y; E.emin[2] = q[7].z; E.perr[0] = q[7].w;
+        E.emax[0] = q[8].x; E.emax[1] = q[8].y; E.emax[2] = q[8].z; E.perr[1] = q[8].w;
+    }
+    if (c.metrics || c.reward_potential) { E.perr[2] = q[9].x; E.psh[0] = q[9].y; E.psh[1] = q[9].z; E.psh[2] = q[9].w; }
+    if (c.any_dynamic_target) {
+#pragma unroll
+        for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+            const float4 t = CGROUP(S, N, (c.L.tprop >> 2) + k, e);
+            E.tprop[k][0] = t.x; E.tprop[k][1] = t.y; E.tprop[k][2] = t.z; E.tprop[k][3] = t.w;
+        }
+    }
+    if (c.goal_enabled) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 t = CGROUP(S, N, (c.L.goal >> 2) + r, e);
+            E.gring[r][0] = f2u(t.x); E.gring[r][1] = f2u(t.y); E.gring[r][2] = f2u(t.z); E.gring[r][3] = f2u(t.w);
+        }
+    }
+}
+
+__device__ __forceinline__ void store_gym(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E) {
+    const int g0 = c.L.gym >> 2;
+    GROUP(S, N, g0 + 0, e) = make_float4(E.tgt[0], E.tgt[1], E.tgt[2], u2f(E.steps));
+    GROUP(S, N, g0 + 1, e) = make_float4(u2f(E.sft), u2f(E.flags), u2f(E.episode), u2f(E.wcnt));
+    GROUP(S, N, g0 + 2, e) = make_float4(u2f(E.gcnt[0]), u2f(E.gcnt[1]), E.pcmd[0], E.pcmd[1]);
+    GROUP(S, N, g0 + 3, e) = make_float4(E.pcmd[2], E.sdcmd, u2f(E.settle[0]), u2f(E.settle[1]));
+    if (c.metrics) {
+        GROUP(S, N, g0 + 4, e) = make_float4(E.e0[0], E.e0[1], E.e0[2], u2f(E.rise[0]));
+        GROUP(S, N, g0 + 5, e) = make_float4(E.esum[0], E.esum[1], E.esum[2], u2f(E.rise[1]));
+        GROUP(S, N, g0 + 6, e) = make_float4(E.eabs[0], E.eabs[1], E.eabs[2], u2f(E.rise[2]));
+        GROUP(S, N, g0 + 7, e) = make_float4(E.emin[0], E.emin[1], E.emin[2], E.perr[0]);
+        GROUP(S, N, g0 + 8, e) = make_float4(E.emax[0], E.emax[1], E.emax[2], E.perr[1]);
+    }
+    if (c.metrics || c.reward_potential) GROUP(S, N, g0 + 9, e) = make_float4(E.perr[2], E.psh[0], E.psh[1], E.psh[2]);
     if (c.any_dynamic_target) {
 #pragma unroll
         for (int k = 0; k < FWG_MAX_TARGETS; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ROW(S, N, L.target + 3 + k * 4 + j, e) = E.tprop[k][j];
+            GROUP(S, N, (c.L.tprop >> 2) + k, e) = make_float4(E.tprop[k][0], E.tprop[k][1], E.tprop[k][2], E.tprop[k][3]);
     }
-    ROW(U, N, L.counters + 0, e) = E.steps; ROW(U, N, L.counters + 1, e) = E.sft;
-    ROW(U, N, L.counters + 2, e) = E.flags;
-    if (at_reset) ROW(U, N, L.counters + 3, e) = E.episode;  // the episode counter only changes at reset
-    if (c.reward_potential) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ROW(S, N, L.prev_shaping + i, e) = E.psh[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ROW(S, N, L.prev_cmd + i, e) = E.pcmd[i];
     if (c.goal_enabled) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ROW(U, N, L.goal_ring + r * 4 + (goal_bit >> 5), e) = E.gword[r];
-        ROW(U, N, L.goal_count + 0, e) = E.wcnt;
-        ROW(U, N, L.goal_count + 1, e) = E.gcnt[0]; ROW(U, N, L.goal_count + 2, e) = E.gcnt[1];
-    }
-    if (c.metrics) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (at_reset) ROW(S, N, L.met + 0 + k, e) = E.e0[k];  // the initial error is fixed for the episode
-            ROW(S, N, L.met + 3 + k, e) = E.esum[k];
-            ROW(S, N, L.met + 6 + k, e) = E.eabs[k]; ROW(S, N, L.met + 9 + k, e) = E.emin[k];
-            ROW(S, N, L.met + 12 + k, e) = E.emax[k]; ROW(U, N, L.met + 15 + k, e) = E.rise[k];
-            ROW(S, N, L.met + 20 + k, e) = E.perr[k];
-        }
-        ROW(U, N, L.met + 18, e) = E.settle[0]; ROW(U, N, L.met + 19, e) = E.settle[1];
-        ROW(S, N, L.met + 23, e) = E.sdcmd;
+        for (int r = 0; r < 4; ++r)
+            GROUP(S, N, (c.L.goal >> 2) + r, e) = make_float4(u2f(E.gring[r][0]), u2f(E.gring[r][1]), u2f(E.gring[r][2]), u2f(E.gring[r][3]));
     }
 }
 
@@ -250,14 +243,21 @@ __device__ __forceinline__ unsigned goal_flags(const DevCfg& c, const float (&er
 __device__ __forceinline__ unsigned window_count(const Env& E, int r) { return (E.wcnt >> (8 * r)) & 0xFFu; }
 __device__ __forceinline__ void goal_push(const DevCfg& c, Env& E, unsigned g, int bit, unsigned rec_index) {
     const unsigned n_rec = rec_index + 1;
+    const int wi = bit >> 5;
     const unsigned m = 1u << (bit & 31);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const bool present = (r == 3) || (r < c.n_targets && c.target[r < 3 ? r : 0].has_bound);
         if (present) {
             const unsigned f = (g >> r) & 1u;
-            const unsigned old = (E.gword[r] & m) ? 1u : 0u;
-            E.gword[r] = f ? (E.gword[r] | m) : (E.gword[r] & ~m);
+            unsigned old = 0u;
+            // all four words are rewritten (mask 0 = no-op) so that the window stays in registers (no dynamic indexing)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned mi = (i == wi) ? m : 0u;
+                old |= (E.gring[r][i] & mi) ? 1u : 0u;
+                E.gring[r][i] = (E.gring[r][i] & ~mi) | (f ? mi : 0u);
+            }
             E.wcnt += (f - old) << (8 * r);     // per-byte add/subtract; each byte stays within [0, 128]
             E.gcnt[r >> 1] += f << (16 * (r & 1));
             if (c.metrics && pack16_get(E.settle, r) == 0xFFFFu && n_rec >= (unsigned)c.streak_req &&
@@ -357,7 +357,7 @@ __device__ __forceinline__ void next_targets(const DevCfg& c, Env& E) {
 
 // "action" observation entry (fixed_wing.py:813-828) for the newest row: sum of |diff| over the last `w` raw actions
 // (or constrained commands) of actuator ai, or the back-scaled actuator value when no action has been taken yet.
-// `ring` = this lane's column of the LDS action window [slot*3 + actuator][lane].
+// `ring` = this lane's entry of the LDS action window [slot][lane][4] (streamed in with 16-byte global_load_lds).
 __device__ __forceinline__ float backscale_action(const DevCfg& c, int ai, float actuator) {
     if (c.scale_actions)
         return (c.scale_high - c.scale_low) * (actuator - c.act_to_low[ai]) * c.inv_act_span[ai] + c.scale_low;
@@ -374,7 +374,7 @@ __device__ __forceinline__ float action_obs(const DevCfg& c, const float* ring, 
         if (k <= W - 2 && k <= m - 2) {
             int s_new = cur_slot - k; s_new += (s_new < 0) ? W : 0;
             int s_old = cur_slot - k - 1; s_old += (s_old < 0) ? W : 0;
-            s += fabsf(ring[(s_new * 3 + ai) * FWG_WAVE] - ring[(s_old * 3 + ai) * FWG_WAVE]);
+            s += fabsf(ring[s_new * (4 * FWG_WAVE) + ai] - ring[s_old * (4 * FWG_WAVE) + ai]);
         }
     }
     return s;
@@ -395,28 +395,50 @@ __device__ __forceinline__ void build_row0(const DevCfg& c, const KArgs& A, long
             else v = action_obs(c, ring, o.src, o.window, E.steps, act_slot, T.get(FWG_V_ELEVATOR + o.src));
             if (o.norm) v = (v - o.mean) * o.inv_var;
             ob.put(j, v);
-            if (push && c.obs_length > 1) RING(A.S, A.N, c.L.lag_ring, ring_slot, c.n_obs, e, j) = v;
         }
+    }
+    if (push && c.obs_length > 1) {  // the record enters the lag ring as ceil(n_obs/4) 16-byte groups
+        const int ng = c.L.lag_groups;
+#pragma unroll
+        for (int g = 0; g < FWG_MAX_OBS / 4; ++g)
+            if (g < ng)
+                GROUP(A.S, A.N, (c.L.lag_ring >> 2) + ring_slot * ng + g, e) =
+                    make_float4(ob.get(4 * g), 4 * g + 1 < c.n_obs ? ob.get(4 * g + 1) : 0.f,
+                                4 * g + 2 < c.n_obs ? ob.get(4 * g + 2) : 0.f, 4 * g + 3 < c.n_obs ? ob.get(4 * g + 3) : 0.f);
     }
 }
 
 // lagged rows r >= 1 = the records pushed r*obs_step steps ago: streamed HBM -> LDS at kernel start
 // (stream_lag_rows, global_load_lds: no VGPRs while the physics runs), collected into the record here
 __device__ __forceinline__ void stream_lag_rows(const DevCfg& c, const KArgs& A, long e, float* lds_lag) {
+    const int ng = c.L.lag_groups;
     for (int r = 1; r < c.obs_length; ++r)
-        for (int j = 0; j < c.n_obs; ++j)
-            dma_row(&RING(A.S, A.N, c.L.lag_ring, A.lag_slots[r], c.n_obs, e, j), lds_lag + ((r - 1) * c.n_obs + j) * FWG_WAVE);
+        for (int g = 0; g < ng; ++g)
+            dma_group(&CGROUP(A.S, A.N, (c.L.lag_ring >> 2) + A.lag_slots[r] * ng + g, e), lds_lag + ((r - 1) * ng + g) * (4 * FWG_WAVE));
 }
 template <class OB>
-__device__ __forceinline__ void load_lag_rows(const DevCfg& c, const float* lag_col, OB& ob) {
+__device__ __forceinline__ void load_lag_rows(const DevCfg& c, const float* lag_lane, OB& ob) {
+    const int ng = c.L.lag_groups;
 #pragma unroll
     for (int r = 1; r < FWG_MAX_ROWS; ++r) {
         if (r < c.obs_length) {
 #pragma unroll
-            for (int j = 0; j < FWG_MAX_OBS; ++j)
-                if (j < c.n_obs) ob.put(r * c.n_obs + j, lag_col[((r - 1) * c.n_obs + j) * FWG_WAVE]);
+            for (int g = 0; g < FWG_MAX_OBS / 4; ++g) {
+                if (g < ng) {
+                    const float4 q = *reinterpret_cast<const float4*>(lag_lane + ((r - 1) * ng + g) * (4 * FWG_WAVE));
+                    ob.put(r * c.n_obs + 4 * g, q.x);
+                    if (4 * g + 1 < c.n_obs) ob.put(r * c.n_obs + 4 * g + 1, q.y);
+                    if (4 * g + 2 < c.n_obs) ob.put(r * c.n_obs + 4 * g + 2, q.z);
+                    if (4 * g + 3 < c.n_obs) ob.put(r * c.n_obs + 4 * g + 3, q.w);
+                }
+            }
         }
     }
+}
+
+// entry j of the record of env e in ring slot `slot` (rare per-lane fix-up reads)
+__device__ __forceinline__ float lag_entry(const DevCfg& c, const KArgs& A, long e, int slot, int j) {
+    return A.S[(((unsigned)(c.L.lag_ring >> 2) + (unsigned)(slot * c.L.lag_groups + (j >> 2))) * (unsigned)A.N + (unsigned)e) * 4u + (unsigned)(j & 3)];
 }
 
 // Fix-ups of the lagged rows r >= 1 that the plain ring read cannot provide (fixed_wing.py:790-832):
@@ -448,7 +470,7 @@ __device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A,
                     v = backscale_action(c, o.src, T.get(FWG_V_ELEVATOR + o.src)) + noise;
                     if (o.norm) v = (v - o.mean) * o.inv_var;
                 } else {
-                    v = RING(A.S, A.N, c.L.lag_ring, slot0, c.n_obs, e, j) + noise * (o.norm ? o.inv_var : 1.f);
+                    v = lag_entry(c, A, e, slot0, j) + noise * (o.norm ? o.inv_var : 1.f);
                 }
                 ob.put(r * c.n_obs + j, v);
             }
@@ -457,7 +479,7 @@ __device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A,
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j)
                 if (j < c.n_obs && c.obs[j].type != FWG_OBS_ACTION)
-                    ob.put(r * c.n_obs + j, RING(A.S, A.N, c.L.lag_ring, slot, c.n_obs, e, j));
+                    ob.put(r * c.n_obs + j, lag_entry(c, A, e, slot, j));
         }
     }
 }
@@ -592,20 +614,13 @@ __device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, con
     }
     E.settle[0] = 0xFFFFFFFFu; E.settle[1] = 0xFFFFFFFFu;
     E.sdcmd = 0.f;
-    if (c.metrics) {
-#pragma unroll
-        for (int k = 0; k < FWG_MAX_TARGETS; ++k)
-            if (k < c.n_targets) ROW(A.S, A.N, c.L.end_ring + g_end * 3 + k, e) = err[k];
-    }
+    if (c.metrics) GROUP(A.S, A.N, (c.L.end_ring >> 2) + g_end, e) = make_float4(err[0], err[1], err[2], 0.f);
     E.wcnt = 0u; E.gcnt[0] = 0u; E.gcnt[1] = 0u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) E.gword[r] = 0u;
-    if (c.goal_enabled) {
-        unsigned* U = reinterpret_cast<unsigned*>(A.S);
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int w = 0; w < 16; ++w) ROW(U, A.N, c.L.goal_ring + w, e) = 0u;  // the word holding g_bit is rewritten by store_gym
-        goal_push(c, E, goal_flags(c, err), g_bit, 0u);
-    }
+        for (int w = 0; w < 4; ++w) E.gring[r][w] = 0u;
+    if (c.goal_enabled) goal_push(c, E, goal_flags(c, err), g_bit, 0u);
     // ---- observation: every row is the initial record (+ per-row init noise when length > 1)
     build_row0(c, A, e, E, T, ob, ring, g_lag, true, 0);
     if (c.obs_length > 1) {

@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 5
+FWG_ABI_VERSION = 6
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -114,9 +114,8 @@ class Config(C.Structure):
 
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ["rows", "phys", "wind", "dryden", "derived", "target", "counters", "prev_shaping", "act_ring",
-                 "cmd_ring", "prev_cmd", "goal_ring", "goal_count", "met", "end_ring", "lag_ring", "window",
-                 "lag_depth"]]
+                ["rows", "sim", "derived", "gym", "tprop", "goal", "act_ring", "cmd_ring", "end_ring", "lag_ring",
+                 "window", "lag_depth", "lag_groups"]]
 
 
 class NativeError(RuntimeError):

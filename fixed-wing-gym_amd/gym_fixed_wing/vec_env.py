@@ -110,7 +110,8 @@ class FixedWingVecEnv(object):
         self.layout = nat.Layout()
         nat.check(self._lib, self._lib.fwg_get_layout(ctypes.byref(self._c), ctypes.byref(self.layout)))
         N, m = self.num_envs, self._mem
-        self.state = m.zeros((self.layout.rows, N))           # SoA state arena [field][env], zero = "never reset"
+        # state arena: 16-byte groups [rows/4][env][4] (word w of env e = state[w >> 2, e, w & 3]); zero = "never reset"
+        self.state = m.zeros((self.layout.rows // 4, N, 4))
         self._obs = m.zeros((N, self.obs_dim))
         self._rew = m.zeros((N,))
         self._done = m.zeros((N,), "u8")
@@ -300,28 +301,31 @@ class FixedWingVecEnv(object):
         return out
 
     # ------------------------------------------------------------------------------------------------------------------
+    def word(self, w):
+        """Device view [N] of word w of every env (strided view into the grouped arena, no copy)."""
+        return self.state[w >> 2, :, w & 3]
+
     def field(self, name):
         """Device view [N] of one simulator variable or bookkeeping field of the state arena (no copy)."""
-        L, S = self.layout, self.state
-        phys = {"e0": 0, "e1": 1, "e2": 2, "e3": 3, "omega_p": 4, "omega_q": 5, "omega_r": 6, "position_n": 7,
-                "position_e": 8, "position_d": 9, "velocity_u": 10, "velocity_v": 11, "velocity_w": 12,
-                "elevon_right": 13, "elevon_left": 14, "throttle": 15, "elevon_right_dot": 16, "elevon_left_dot": 17}
+        L = self.layout
+        sim = {"e0": 0, "e1": 1, "e2": 2, "e3": 3, "omega_p": 4, "omega_q": 5, "omega_r": 6, "position_n": 7,
+               "position_e": 8, "position_d": 9, "velocity_u": 10, "velocity_v": 11, "velocity_w": 12,
+               "elevon_right": 13, "elevon_left": 14, "throttle": 15, "elevon_right_dot": 16, "elevon_left_dot": 17,
+               "wind_n": 18, "wind_e": 19, "wind_d": 20}
         derived = {"roll": 0, "pitch": 1, "yaw": 2, "Va": 3, "alpha": 4, "beta": 5}
-        if name in phys:
-            return S[L.phys + phys[name]]
+        if name in sim:
+            return self.word(L.sim + sim[name])
         if name in derived:
-            return S[L.derived + derived[name]]
-        if name in ("wind_n", "wind_e", "wind_d"):
-            return S[L.wind + ("wind_n", "wind_e", "wind_d").index(name)]
+            return self.word(L.derived + derived[name])
         if name == "elevator":
-            return 0.5 * (S[L.phys + 13] + S[L.phys + 14])
+            return 0.5 * (self.word(L.sim + 13) + self.word(L.sim + 14))
         if name == "aileron":
-            return 0.5 * (S[L.phys + 14] - S[L.phys + 13])
+            return 0.5 * (self.word(L.sim + 14) - self.word(L.sim + 13))
         if name.startswith("target_"):
-            return S[L.target + self.target_names.index(name[7:])]
-        if name in ("steps_count", "steps_for_target", "flags", "episode"):
-            row = L.counters + ("steps_count", "steps_for_target", "flags", "episode").index(name)
-            return self._mem.view_i32(S[row])
+            return self.word(L.gym + self.target_names.index(name[7:]))
+        counters = {"steps_count": 3, "steps_for_target": 4, "flags": 5, "episode": 6}
+        if name in counters:
+            return self._mem.view_i32(self.state)[(L.gym + counters[name]) >> 2, :, (L.gym + counters[name]) & 3]
         raise KeyError(name)
 
     def get_state(self, names):

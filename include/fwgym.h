@@ -12,8 +12,8 @@
  *     (thread-local); nothing throws across the ABI.
  *   - per-environment SIMULATION failures are data, not API errors: done=1 and term_code=FWG_TERM_VAR0+var_id,
  *     mirroring fixed_wing.py:409-416.
- *   - the caller owns every buffer, including the persistent state arena (rows x N 32-bit words, SoA
- *     [field][env]); the library allocates only its small device-side constant block and reduction scratch in
+ *   - the caller owns every buffer, including the persistent state arena (rows x N 32-bit words in 16-byte
+ *     groups [rows/4][env][4]); the library allocates only its small device-side constant block and reduction scratch in
  *     fwg_create.  No allocation and no synchronisation happens in fwg_step/fwg_reset.
  *   - a handle is not thread-safe; use one handle per GPU/stream.
  */
@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 5
+#define FWG_ABI_VERSION 6
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -182,26 +182,22 @@ typedef struct fwg_config {
     double rise_low, rise_high;         /* metrics[rise_time].low/high (fixed_wing.py:1131) */
 } fwg_config;
 
-/* Row offsets (in units of N words) of the SoA state arena the caller must allocate: float32/uint32 [rows][N]. */
+/* The caller-owned state arena is an array of 16-byte GROUPS [rows/4][N] of 32-bit words: word w of env e lives at
+ * ((w >> 2) * N + e) * 4 + (w & 3).  All offsets below are in words and multiples of 4. */
 typedef struct fwg_layout {
-    int32_t rows;        /* total */
-    int32_t phys;        /* 18: e0 e1 e2 e3 | p q r | pn pe pd | u v w | elevon_r elevon_l throttle | elevon_r_dot elevon_l_dot */
-    int32_t wind;        /* 3: steady wind n,e,d */
-    int32_t dryden;      /* 8 (present only when turbulence) */
-    int32_t derived;     /* 6: roll pitch yaw Va alpha beta of the committed state */
-    int32_t target;      /* 3 values + 4 property words per target (slope|amplitude, period, phase, bias) */
-    int32_t counters;    /* 4 x uint32: steps_count, steps_for_target, flags, episode */
-    int32_t prev_shaping;/* 3 */
-    int32_t act_ring;    /* window*3 raw actions, slot = global_step % window */
-    int32_t cmd_ring;    /* window*3 constrained commands (only when observations need them) */
-    int32_t prev_cmd;    /* 3 */
-    int32_t goal_ring;   /* 4 rings (target0..2, all) x 4 uint32 */
-    int32_t goal_count;  /* 4 x uint32 cumulative */
-    int32_t met;         /* e0 3 | sum 3 | sum_abs 3 | min 3 | max 3 | rise 3 (u32 lo16=low idx, hi16=high idx) | settle 2 (u32 packed 4x16) | prev_err 3 | sum_dcmd 1 | n_cmd 1 */
-    int32_t end_ring;    /* 50*3, slot = global_step % 50 */
-    int32_t lag_ring;    /* ((length-1)*step+1) * n_obs un-normalised rows, slot = global_step % depth */
+    int32_t rows;        /* total words per env (multiple of 4); arena = rows * N words */
+    int32_t sim;         /* 32: e0 e1 e2 e3 | p q r pn | pe pd u v | w elevon_r elevon_l throttle | elevon_r_dot elevon_l_dot wind_n wind_e | wind_d dryden0..2 | dryden3..6 | dryden7 pad pad pad */
+    int32_t derived;     /* 8: roll pitch yaw Va | alpha beta pad pad (committed state, written every step) */
+    int32_t gym;         /* 40: tgt0 tgt1 tgt2 steps_count | steps_for_target flags episode window_counts | goal_counts(2) prev_cmd0 prev_cmd1 | prev_cmd2 sum_dcmd settle(2) | e0(3) rise0 | sum_e(3) rise1 | sum_abs_e(3) rise2 | min_e(3) prev_err0 | max_e(3) prev_err1 | prev_err2 prev_shaping(3) */
+    int32_t tprop;       /* 12: per target slope|amplitude, period, phase, bias (linear/sinusoidal targets) */
+    int32_t goal;        /* 16: goal windows target0..2, all: 4 x 128 bit */
+    int32_t act_ring;    /* window*4: raw actions (a0 a1 a2 pad) per slot, slot = global_step % window */
+    int32_t cmd_ring;    /* window*4: constrained commands (only when observations need them) */
+    int32_t end_ring;    /* 50*4: errors (e0 e1 e2 pad) per slot, slot = global_step % 50 */
+    int32_t lag_ring;    /* lag_depth*lag_groups*4: normalised observation records, slot = global_step % lag_depth */
     int32_t window;      /* action window depth */
-    int32_t lag_depth;
+    int32_t lag_depth;   /* (length-1)*step+1 */
+    int32_t lag_groups;  /* ceil(n_obs/4) */
 } fwg_layout;
 
 /* rows of the metrics block (float32 [FWG_N_METRICS][N], valid where done) -- get_metric, fixed_wing.py:1095-1162 */
@@ -226,7 +222,8 @@ int fwg_abi_version(void);
 int fwg_get_layout(const fwg_config* cfg_host, fwg_layout* out_host);
 
 /* Replaces FixedWingAircraft.__init__ (fixed_wing.py:14-212) for n_envs environments on HIP device `device`.
- * `state_arena` must hold layout.rows * n_envs 32-bit words and stay alive until fwg_destroy.
+ * `state_arena` must hold layout.rows * n_envs 32-bit words (16-byte aligned, zero-initialised) and stay alive until
+ * fwg_destroy.
  * `env_id_base` is the global index of this handle's first env (multi-GPU sharding: RNG streams depend only on the
  * global env index, so results do not depend on how envs are split over GPUs). */
 int fwg_create(const fwg_config* cfg_host, int64_t n_envs, int device, void* state_arena, int64_t env_id_base,

@@ -140,12 +140,18 @@ def oracle_spec_from_env_config(ec):
 
 def physics_state(vec):
     """(y[N,18], wind[N,3], dryden[N,8]) float64 copies of the device state."""
-    L = vec.layout
-    S = _np(vec.state)
-    y = S[L.phys:L.phys + 18].T.astype(np.float64)
-    wind = S[L.wind:L.wind + 3].T.astype(np.float64)
-    dry = S[L.dryden:L.dryden + 8].T.astype(np.float64) if vec.env_config.turbulence else np.zeros((y.shape[0], 8))
+    W = words(vec)
+    s0 = vec.layout.sim
+    y = W[s0:s0 + 18].T.astype(np.float64)
+    wind = W[s0 + 18:s0 + 21].T.astype(np.float64)
+    dry = W[s0 + 21:s0 + 29].T.astype(np.float64) if vec.env_config.turbulence else np.zeros((y.shape[0], 8))
     return y, wind, dry
+
+
+def words(vec):
+    """Host copy of the arena as [word][env] (the device layout is 16-byte groups [word >> 2][env][word & 3])."""
+    S = _np(vec.state)
+    return np.ascontiguousarray(S.transpose(0, 2, 1).reshape(S.shape[0] * 4, S.shape[1]))
 
 
 def scaled_actions(vec, raw):

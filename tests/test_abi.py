@@ -37,7 +37,7 @@ def test_layout_and_version_without_gpu():
     c = EnvConfig().compile()
     lay = nat.Layout()
     nat.check(lib, lib.fwg_get_layout(ctypes.byref(c), ctypes.byref(lay)))
-    assert lay.phys == 0 and lay.rows > 100 and lay.window == 5 and lay.lag_depth == 0
+    assert lay.sim == 0 and lay.rows > 100 and lay.rows % 4 == 0 and lay.window == 5 and lay.lag_depth == 0
     # a struct of the wrong size is refused, not misread
     c.struct_bytes -= 8
     assert lib.fwg_get_layout(ctypes.byref(c), ctypes.byref(lay)) == -2

@@ -80,7 +80,7 @@ def test_single_step_state_parity_1e5(n, turb):
         err = np.abs(y1 - want) / np.maximum(np.abs(want), parity.STATE_SCALE)
         worst = max(worst, float(err.max()))
         assert err.max() <= 1e-5, (t, np.unravel_index(np.argmax(err), err.shape), err.max())
-        S = parity._np(vec.state)
+        S = parity.words(vec)
         L = vec.layout
         for k, nm in enumerate(["roll", "pitch", "yaw", "Va", "alpha", "beta"]):
             e = np.abs(S[L.derived + k] - d[nm])
@@ -106,12 +106,12 @@ def test_full_size_properties():
         for t in range(steps):
             obs, rew, done, _ = vec.step(acts[t])
             hist.append((np.array(obs), np.array(rew), np.array(done)))
-        S = parity._np(vec.state)
+        S = parity.words(vec)
         outs.append((hist, S.copy()))
         L = vec.layout
-        q = S[L.phys:L.phys + 4]
+        q = S[L.sim:L.sim + 4]
         assert np.abs(np.sum(q * q, axis=0) - 1).max() < 1e-5
-        assert np.all(np.isfinite(S[:L.counters]))  # float rows: physics, wind, Dryden, derived, targets
+        assert np.all(np.isfinite(S[:L.gym + 3]))  # float words: simulator block, derived values, targets
         vec.close()
     for (o1, r1, d1), (o2, r2, d2) in zip(outs[0][0], outs[1][0]):
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
