@@ -24,20 +24,13 @@ for p in (ROOT, os.path.join(ROOT, "fixed-wing-gym_amd"), os.path.join(ROOT, "te
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
-ALG_BYTES = {"c3": 937, "c2": 417}   # algorithmic bytes per env-step, SURVEY.md section 8(d)
+ALG_BYTES = {"c3": 937, "c2": 417, "c5": 409}   # algorithmic bytes per env-step, SURVEY.md section 8(d)
 REDUCE_EVERY = 128
 
 
 def workload(name):
-    import configs
-    if name == "c3":
-        cfg = configs.reference_like("cnn")
-        return cfg, {"observation": {"step": 2}}, {"turbulence": True, "turbulence_intensity": "moderate"}, 65536, \
-            "C3: 65536 envs/GPU, Dryden turbulence moderate, obs 5x12 lag step 2, auto-reset, metrics on"
-    if name == "c2":
-        cfg = configs.reference_like("default")
-        return cfg, None, None, 4096, "C2: 4096 envs/GPU, turbulence off, obs 14-vector, auto-reset, metrics on"
-    raise SystemExit("unknown workload " + name)
+    from gym_fixed_wing import presets
+    return presets.workload(name)
 
 
 def _cpu_worker(args):
@@ -79,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -103,8 +96,10 @@ def main():
     cfg, ckw, skw, n_envs, desc = workload(args.workload)
     if args.envs:
         n_envs = args.envs
+    # derived_views=False: the rollout loop never reads roll/pitch/... back from the arena (they are in the
+    # observations), so the kernel does not write those host-view rows
     vec = FixedWingVecEnv(cfg, num_envs=n_envs, device=local, config_kw=ckw, sim_config_kw=skw, seed=0,
-                          env_id_base=rank * n_envs, auto_reset=True)
+                          env_id_base=rank * n_envs, auto_reset=True, derived_views=False)
     vec.reset()
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -168,7 +163,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "envs_per_gpu": n_envs, "total_envs": total_envs,
-                       "rk4_substeps": int(vec._c.n_substeps), "success_allgather_every": REDUCE_EVERY},
+                       "rk4_substeps": int(vec._c.n_substeps), "actuator_microsteps": int(vec._c.actuator_microsteps),
+                       "specialised_kernel": vec.spec_index >= 0, "derived_views": False,
+                       "success_allgather_every": REDUCE_EVERY},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_step", "kernel_ms": kern_ms, "stream_ms_per_step": region_ms,

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     if (c.use_cmd_ring)
         for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
     stream_lag_rows(c, A, e, lds + M.lag);
-    load_gym(c, A.S, A.N, e, E);
+    load_gym(c, A.S, A.N, e, E, A.bit_goal);
     const int fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
     const bool ok = fail == 0;
     if (!ok) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         }
     }
 
-    if (valid) store_gym(c, A.S, A.N, e, E);
+    if (valid) store_gym(c, A.S, A.N, e, E, A.bit_goal);
 
     // ---- phase D: observation (fixed_wing.py:776-846)
     load_lag_rows(c, lds + M.lag + lane * 4, ob);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         if (c.auto_reset && done && valid) {
             reset_env<TURB>(c, dc, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal);
             store_sim<TURB>(c, A.S, A.N, e, E);
-            store_gym(c, A.S, A.N, e, E);
+            store_gym(c, A.S, A.N, e, E, A.bit_goal);
         }
     }
 
@@ -407,12 +407,15 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     typename KT::Tab T = KT::tab(lds, M, lane);
     typename KT::Obs ob = KT::obs(lds, M, lane);
     Env E;
-    load_gym(c, A.S, A.N, e, E);
+    {   // only what survives a reset is needed: the sticky goal flag and the episode counter
+        const float4 w = CGROUP(A.S, A.N, (c.L.cold >> 2), e), f = CGROUP(A.S, A.N, (c.L.gym >> 2) + 1, e);
+        E.episode = f2u(w.w); E.flags = f2u(f.x);
+    }
     if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane * 4, A.slot_end, A.slot_lag, A.bit_goal);
     write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
     if (sel) {
         store_sim<TURB>(c, A.S, A.N, e, E);
-        store_gym(c, A.S, A.N, e, E);
+        store_gym(c, A.S, A.N, e, E, A.bit_goal);
         if (A.tgt_out != nullptr) {
 #pragma unroll
             for (int k = 0; k < FWG_MAX_TARGETS; ++k)
@@ -478,11 +481,12 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
     if (window > FWG_MAX_WINDOW) { *why = "action window_size > 8"; return -1; }
     // all offsets are in 32-bit words and multiples of 4: the arena is addressed in 16-byte groups [group][env]
     int o = 0;
-    L->sim = o; o += 32;                 // y[18] | wind[3] | dryden[8] | pad
+    L->sim = o; o += 28;                 // y[18] | dryden[8] | pad
+    L->cold = o; o += 8;                 // wind[3] episode | e0[3] pad  (per-episode constants, written at reset)
     L->derived = o; o += 8;              // roll pitch yaw Va | alpha beta pad pad
-    L->gym = o; o += 40;                 // 10 bookkeeping groups (see load_gym)
+    L->gym = o; o += 36;                 // 9 bookkeeping groups (see load_gym)
     L->tprop = o; o += 4 * FWG_MAX_TARGETS;
-    L->goal = o; o += 16;                // 4 windows x 4 words
+    L->goal = o; o += FWG_MAX_STREAK / 8; // goal-window ring: plain word rows, 8 positions x 4 flags per word
     L->act_ring = o; o += window * 4;    // raw actions, one group per slot, slot = global_step % window
     L->cmd_ring = o; o += use_cmd ? window * 4 : 0;
     L->end_ring = o; o += FWG_END_WINDOW * 4;
@@ -637,7 +641,7 @@ static int lower_config(const fwg_config& c, DevCfg* d, DynCfg* dy, std::string*
                                  F.value_is_timesteps, f32(F.sign > 0 ? 1.0 : (F.sign < 0 ? -1.0 : 0.0)), f32(1.0 / F.scaling),
                                  f32(F.max), f32(F.value)};
     }
-    d->metrics = c.metrics; d->auto_reset = c.auto_reset; d->use_cmd_ring = use_cmd;
+    d->metrics = c.metrics; d->auto_reset = c.auto_reset; d->use_cmd_ring = use_cmd; d->store_derived = c.store_derived;
     d->rise_low = f32(c.rise_low); d->rise_high = f32(c.rise_high);
     return 0;
 }

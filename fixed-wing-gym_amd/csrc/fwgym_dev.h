@@ -68,7 +68,7 @@ struct DevCfg {
     float term_weight[3];
     int n_factors;
     DevFactor factor[FWG_MAX_FACTORS];
-    int metrics, auto_reset, use_cmd_ring;
+    int metrics, auto_reset, use_cmd_ring, store_derived;
     float rise_low, rise_high;
     fwg_layout L;
 };

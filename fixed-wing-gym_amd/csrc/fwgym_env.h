@@ -74,8 +74,8 @@ struct Env {
     unsigned steps, sft, flags, episode;
     float psh[3];
     float pcmd[3];
-    unsigned gring[4][4]; // goal windows (target0..2, all): rings of success_streak_req <= 128 bits
-    unsigned wcnt;       // ones inside each window, 4 x 8 bit
+    unsigned gw;         // the word of the goal-window ring that holds this step's position (8 positions x 4 flags)
+    unsigned wcnt;       // ones inside each of the 4 windows (target0..2, all), 4 x 8 bit
     unsigned gcnt[2];    // cumulative ones per window since reset, 4 x 16 bit
     float e0[3], esum[3], eabs[3], emin[3], emax[3];
     unsigned rise[3];
@@ -93,24 +93,25 @@ struct Env {
 __device__ __forceinline__ float u2f(unsigned u) { return __uint_as_float(u); }
 __device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
 
-// simulator block: 8 groups = y[18] | wind[3] | dryden[8] | 3 pad
+// simulator block: 7 groups = y[18] | dryden[8] | 2 pad (5 groups when turbulence is off)
 template <bool TURB>
 __device__ __forceinline__ void load_sim(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
     const int g0 = c.L.sim >> 2;
-    float f[32];
+    float f[28];
 #pragma unroll
-    for (int g = 0; g < (TURB ? 8 : 6); ++g) {
+    for (int g = 0; g < (TURB ? 7 : 5); ++g) {
         const float4 q = CGROUP(S, N, g0 + g, e);
         f[4 * g] = q.x; f[4 * g + 1] = q.y; f[4 * g + 2] = q.z; f[4 * g + 3] = q.w;
     }
 #pragma unroll
     for (int i = 0; i < NY; ++i) E.y[i] = f[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) E.wind[i] = f[NY + i];
     if (TURB) {
 #pragma unroll
-        for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = f[NY + 3 + i];
+        for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = f[NY + i];
     }
+    // per-episode constants (written by reset only): steady wind + episode counter | initial errors
+    const float4 w = CGROUP(S, N, (c.L.cold >> 2), e);
+    E.wind[0] = w.x; E.wind[1] = w.y; E.wind[2] = w.z; E.episode = f2u(w.w);
 }
 
 // The write-back is split so that each part is issued as soon as its values are final: the simulator block right after
@@ -119,43 +120,48 @@ __device__ __forceinline__ void load_sim(const DevCfg& c, const float* __restric
 template <bool TURB>
 __device__ __forceinline__ void store_sim(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E) {
     const int g0 = c.L.sim >> 2;
-    float f[32];
+    float f[28];
 #pragma unroll
     for (int i = 0; i < NY; ++i) f[i] = E.y[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) f[NY + i] = E.wind[i];
+    for (int i = 0; i < FWG_N_DRYDEN; ++i) f[NY + i] = TURB ? E.dry[i] : 0.f;
+    f[18 + (TURB ? 8 : 0)] = 0.f; f[19 + (TURB ? 8 : 0)] = 0.f;
 #pragma unroll
-    for (int i = 0; i < FWG_N_DRYDEN; ++i) f[NY + 3 + i] = TURB ? E.dry[i] : 0.f;
-    f[29] = 0.f; f[30] = 0.f; f[31] = 0.f;
-#pragma unroll
-    for (int g = 0; g < (TURB ? 8 : 6); ++g) GROUP(S, N, g0 + g, e) = make_float4(f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
-    // derived values of the committed state (write-only for the kernels: host views, controllers, rendering)
-    GROUP(S, N, (c.L.derived >> 2), e) = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
-    GROUP(S, N, (c.L.derived >> 2) + 1, e) = make_float4(E.d.alpha, E.d.beta, 0.f, 0.f);
+    for (int g = 0; g < (TURB ? 7 : 5); ++g) GROUP(S, N, g0 + g, e) = make_float4(f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+    if (c.store_derived) {  // derived values of the committed state: only for host views (controllers, rendering)
+        GROUP(S, N, (c.L.derived >> 2), e) = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
+        GROUP(S, N, (c.L.derived >> 2) + 1, e) = make_float4(E.d.alpha, E.d.beta, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void store_cold(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E) {
+    GROUP(S, N, (c.L.cold >> 2), e) = make_float4(E.wind[0], E.wind[1], E.wind[2], u2f(E.episode));
+    GROUP(S, N, (c.L.cold >> 2) + 1, e) = make_float4(E.e0[0], E.e0[1], E.e0[2], 0.f);
 }
 
-// bookkeeping block, 10 groups:
-//  0: tgt0 tgt1 tgt2 steps | 1: sft flags episode wcnt | 2: gcnt0 gcnt1 pcmd0 pcmd1 | 3: pcmd2 sdcmd settle0 settle1
-//  4: e0[0..2] rise0 | 5: esum[0..2] rise1 | 6: eabs[0..2] rise2 | 7: emin[0..2] perr0 | 8: emax[0..2] perr1
-//  9: perr2 psh0 psh1 psh2        then 3 groups of target properties and 4 groups of goal windows
-__device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
+// bookkeeping block, 9 groups (what changes every step):
+//  0: tgt0 tgt1 tgt2 steps|sft<<16 | 1: flags wcnt gcnt0 gcnt1 | 2: pcmd0 pcmd1 pcmd2 sdcmd | 3: settle0 settle1 rise0 rise1
+//  4: rise2 esum[0..2] | 5: eabs[0..2] perr0 | 6: emin[0..2] perr1 | 7: emax[0..2] perr2 | 8: psh[0..2] pad
+// then 3 groups of target properties (linear/sinusoidal targets only) and the goal-window ring as 16 plain word rows.
+__device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E, int goal_bit) {
     const int g0 = c.L.gym >> 2;
-    float4 q[10];
+    float4 q[9];
 #pragma unroll
-    for (int g = 0; g < 10; ++g)
-        if (g < 4 || c.metrics || (g == 9 && c.reward_potential)) q[g] = CGROUP(S, N, g0 + g, e);
-    E.tgt[0] = q[0].x; E.tgt[1] = q[0].y; E.tgt[2] = q[0].z; E.steps = f2u(q[0].w);
-    E.sft = f2u(q[1].x); E.flags = f2u(q[1].y); E.episode = f2u(q[1].z); E.wcnt = f2u(q[1].w);
-    E.gcnt[0] = f2u(q[2].x); E.gcnt[1] = f2u(q[2].y); E.pcmd[0] = q[2].z; E.pcmd[1] = q[2].w;
-    E.pcmd[2] = q[3].x; E.sdcmd = q[3].y; E.settle[0] = f2u(q[3].z); E.settle[1] = f2u(q[3].w);
+    for (int g = 0; g < 9; ++g)
+        if (g < 3 || (g < 8 && c.metrics) || (g == 8 && c.reward_potential)) q[g] = CGROUP(S, N, g0 + g, e);
+    E.tgt[0] = q[0].x; E.tgt[1] = q[0].y; E.tgt[2] = q[0].z;
+    E.steps = f2u(q[0].w) & 0xFFFFu; E.sft = f2u(q[0].w) >> 16;
+    E.flags = f2u(q[1].x); E.wcnt = f2u(q[1].y); E.gcnt[0] = f2u(q[1].z); E.gcnt[1] = f2u(q[1].w);
+    E.pcmd[0] = q[2].x; E.pcmd[1] = q[2].y; E.pcmd[2] = q[2].z; E.sdcmd = q[2].w;
     if (c.metrics) {
-        E.e0[0] = q[4].x; E.e0[1] = q[4].y; E.e0[2] = q[4].z; E.rise[0] = f2u(q[4].w);
-        E.esum[0] = q[5].x; E.esum[1] = q[5].y; E.esum[2] = q[5].z; E.rise[1] = f2u(q[5].w);
-        E.eabs[0] = q[6].x; E.eabs[1] = q[6].y; E.eabs[2] = q[6].z; E.rise[2] = f2u(q[6].w);
-        E.emin[0] = q[7].x; E.emin[1] = q[7].y; E.emin[2] = q[7].z; E.perr[0] = q[7].w;
-        E.emax[0] = q[8].x; E.emax[1] = q[8].y; E.emax[2] = q[8].z; E.perr[1] = q[8].w;
+        E.settle[0] = f2u(q[3].x); E.settle[1] = f2u(q[3].y); E.rise[0] = f2u(q[3].z); E.rise[1] = f2u(q[3].w);
+        E.rise[2] = f2u(q[4].x); E.esum[0] = q[4].y; E.esum[1] = q[4].z; E.esum[2] = q[4].w;
+        E.eabs[0] = q[5].x; E.eabs[1] = q[5].y; E.eabs[2] = q[5].z; E.perr[0] = q[5].w;
+        E.emin[0] = q[6].x; E.emin[1] = q[6].y; E.emin[2] = q[6].z; E.perr[1] = q[6].w;
+        E.emax[0] = q[7].x; E.emax[1] = q[7].y; E.emax[2] = q[7].z; E.perr[2] = q[7].w;
+        const float4 z = CGROUP(S, N, (c.L.cold >> 2) + 1, e);
+        E.e0[0] = z.x; E.e0[1] = z.y; E.e0[2] = z.z;
     }
-    if (c.metrics || c.reward_potential) { E.perr[2] = q[9].x; E.psh[0] = q[9].y; E.psh[1] = q[9].z; E.psh[2] = q[9].w; }
+    if (c.reward_potential) { E.psh[0] = q[8].x; E.psh[1] = q[8].y; E.psh[2] = q[8].z; }
     if (c.any_dynamic_target) {
 #pragma unroll
         for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
@@ -163,39 +169,30 @@ __device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restric
             E.tprop[k][0] = t.x; E.tprop[k][1] = t.y; E.tprop[k][2] = t.z; E.tprop[k][3] = t.w;
         }
     }
-    if (c.goal_enabled) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float4 t = CGROUP(S, N, (c.L.goal >> 2) + r, e);
-            E.gring[r][0] = f2u(t.x); E.gring[r][1] = f2u(t.y); E.gring[r][2] = f2u(t.z); E.gring[r][3] = f2u(t.w);
-        }
-    }
+    if (c.goal_enabled)  // only the word holding this step's position; plain rows [word][env] so the access is 256 B per wave
+        E.gw = reinterpret_cast<const unsigned*>(S)[((unsigned)c.L.goal + (unsigned)(goal_bit >> 3)) * (unsigned)N + (unsigned)e];
 }
 
-__device__ __forceinline__ void store_gym(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E) {
+__device__ __forceinline__ void store_gym(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E, int goal_bit) {
     const int g0 = c.L.gym >> 2;
-    GROUP(S, N, g0 + 0, e) = make_float4(E.tgt[0], E.tgt[1], E.tgt[2], u2f(E.steps));
-    GROUP(S, N, g0 + 1, e) = make_float4(u2f(E.sft), u2f(E.flags), u2f(E.episode), u2f(E.wcnt));
-    GROUP(S, N, g0 + 2, e) = make_float4(u2f(E.gcnt[0]), u2f(E.gcnt[1]), E.pcmd[0], E.pcmd[1]);
-    GROUP(S, N, g0 + 3, e) = make_float4(E.pcmd[2], E.sdcmd, u2f(E.settle[0]), u2f(E.settle[1]));
+    GROUP(S, N, g0 + 0, e) = make_float4(E.tgt[0], E.tgt[1], E.tgt[2], u2f((E.steps & 0xFFFFu) | (E.sft << 16)));
+    GROUP(S, N, g0 + 1, e) = make_float4(u2f(E.flags), u2f(E.wcnt), u2f(E.gcnt[0]), u2f(E.gcnt[1]));
+    GROUP(S, N, g0 + 2, e) = make_float4(E.pcmd[0], E.pcmd[1], E.pcmd[2], E.sdcmd);
     if (c.metrics) {
-        GROUP(S, N, g0 + 4, e) = make_float4(E.e0[0], E.e0[1], E.e0[2], u2f(E.rise[0]));
-        GROUP(S, N, g0 + 5, e) = make_float4(E.esum[0], E.esum[1], E.esum[2], u2f(E.rise[1]));
-        GROUP(S, N, g0 + 6, e) = make_float4(E.eabs[0], E.eabs[1], E.eabs[2], u2f(E.rise[2]));
-        GROUP(S, N, g0 + 7, e) = make_float4(E.emin[0], E.emin[1], E.emin[2], E.perr[0]);
-        GROUP(S, N, g0 + 8, e) = make_float4(E.emax[0], E.emax[1], E.emax[2], E.perr[1]);
+        GROUP(S, N, g0 + 3, e) = make_float4(u2f(E.settle[0]), u2f(E.settle[1]), u2f(E.rise[0]), u2f(E.rise[1]));
+        GROUP(S, N, g0 + 4, e) = make_float4(u2f(E.rise[2]), E.esum[0], E.esum[1], E.esum[2]);
+        GROUP(S, N, g0 + 5, e) = make_float4(E.eabs[0], E.eabs[1], E.eabs[2], E.perr[0]);
+        GROUP(S, N, g0 + 6, e) = make_float4(E.emin[0], E.emin[1], E.emin[2], E.perr[1]);
+        GROUP(S, N, g0 + 7, e) = make_float4(E.emax[0], E.emax[1], E.emax[2], E.perr[2]);
     }
-    if (c.metrics || c.reward_potential) GROUP(S, N, g0 + 9, e) = make_float4(E.perr[2], E.psh[0], E.psh[1], E.psh[2]);
+    if (c.reward_potential) GROUP(S, N, g0 + 8, e) = make_float4(E.psh[0], E.psh[1], E.psh[2], 0.f);
     if (c.any_dynamic_target) {
 #pragma unroll
         for (int k = 0; k < FWG_MAX_TARGETS; ++k)
             GROUP(S, N, (c.L.tprop >> 2) + k, e) = make_float4(E.tprop[k][0], E.tprop[k][1], E.tprop[k][2], E.tprop[k][3]);
     }
-    if (c.goal_enabled) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            GROUP(S, N, (c.L.goal >> 2) + r, e) = make_float4(u2f(E.gring[r][0]), u2f(E.gring[r][1]), u2f(E.gring[r][2]), u2f(E.gring[r][3]));
-    }
+    if (c.goal_enabled)
+        reinterpret_cast<unsigned*>(S)[((unsigned)c.L.goal + (unsigned)(goal_bit >> 3)) * (unsigned)N + (unsigned)e] = E.gw;
 }
 
 // simulator variable table (index = fwg_var) so that config-driven indices can address it
@@ -235,30 +232,25 @@ __device__ __forceinline__ unsigned goal_flags(const DevCfg& c, const float (&er
     return g | (all ? 8u : 0u);
 }
 
-// Push the goal flags of one record into the four windows (target0..2, all).  A window is a ring of
-// success_streak_req bits addressed by the global step counter, so the bit being overwritten is exactly the one that
-// leaves the window: the ones-count of the window is updated incrementally (no popcount over the ring), the cumulative
+// Push the goal flags of one record into the four windows (target0..2, all).  The windows are ONE ring of
+// success_streak_req positions x 4 flag bits (8 positions per 32-bit word), addressed by the global step counter, so
+// the nibble being overwritten is exactly the one that leaves the windows: the ones-count of the window is updated incrementally (no popcount over the ring), the cumulative
 // count feeds success_time_frac, and the metric settling index latches the first record at which a full window
 // satisfies the fraction (fixed_wing.py:1116-1128).
 __device__ __forceinline__ unsigned window_count(const Env& E, int r) { return (E.wcnt >> (8 * r)) & 0xFFu; }
 __device__ __forceinline__ void goal_push(const DevCfg& c, Env& E, unsigned g, int bit, unsigned rec_index) {
     const unsigned n_rec = rec_index + 1;
-    const int wi = bit >> 5;
-    const unsigned m = 1u << (bit & 31);
+    const int sh = 4 * (bit & 7);
+    unsigned present = 8u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) present |= (r < c.n_targets && c.target[r].has_bound) ? (1u << r) : 0u;
+    const unsigned neu = g & present, old = (E.gw >> sh) & 0xFu;
+    E.gw = (E.gw & ~(0xFu << sh)) | (neu << sh);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const bool present = (r == 3) || (r < c.n_targets && c.target[r < 3 ? r : 0].has_bound);
-        if (present) {
-            const unsigned f = (g >> r) & 1u;
-            unsigned old = 0u;
-            // all four words are rewritten (mask 0 = no-op) so that the window stays in registers (no dynamic indexing)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned mi = (i == wi) ? m : 0u;
-                old |= (E.gring[r][i] & mi) ? 1u : 0u;
-                E.gring[r][i] = (E.gring[r][i] & ~mi) | (f ? mi : 0u);
-            }
-            E.wcnt += (f - old) << (8 * r);     // per-byte add/subtract; each byte stays within [0, 128]
+        if ((present >> r) & 1u) {
+            const unsigned f = (neu >> r) & 1u;
+            E.wcnt += (f - ((old >> r) & 1u)) << (8 * r);   // per-byte add/subtract; each byte stays within [0, 128]
             E.gcnt[r >> 1] += f << (16 * (r & 1));
             if (c.metrics && pack16_get(E.settle, r) == 0xFFFFu && n_rec >= (unsigned)c.streak_req &&
                 window_count(E, r) >= (unsigned)c.streak_min_count)
@@ -615,12 +607,14 @@ __device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, con
     E.settle[0] = 0xFFFFFFFFu; E.settle[1] = 0xFFFFFFFFu;
     E.sdcmd = 0.f;
     if (c.metrics) GROUP(A.S, A.N, (c.L.end_ring >> 2) + g_end, e) = make_float4(err[0], err[1], err[2], 0.f);
-    E.wcnt = 0u; E.gcnt[0] = 0u; E.gcnt[1] = 0u;
+    E.wcnt = 0u; E.gcnt[0] = 0u; E.gcnt[1] = 0u; E.gw = 0u;
+    if (c.goal_enabled) {
+        unsigned* U = reinterpret_cast<unsigned*>(A.S);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) E.gring[r][w] = 0u;
-    if (c.goal_enabled) goal_push(c, E, goal_flags(c, err), g_bit, 0u);
+        for (int w = 0; w < FWG_MAX_STREAK / 8; ++w) U[((unsigned)c.L.goal + (unsigned)w) * (unsigned)A.N + (unsigned)e] = 0u;
+        goal_push(c, E, goal_flags(c, err), g_bit, 0u);   // the word holding g_bit is written by store_gym
+    }
+    store_cold(c, A.S, A.N, e, E);
     // ---- observation: every row is the initial record (+ per-row init noise when length > 1)
     build_row0(c, A, e, E, T, ob, ring, g_lag, true, 0);
     if (c.obs_length > 1) {

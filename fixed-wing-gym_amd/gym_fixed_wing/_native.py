@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 6
+FWG_ABI_VERSION = 7
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -107,14 +107,14 @@ class Config(C.Structure):
         ("term_present", C.c_int32 * 3), ("n_factors", C.c_int32),
         ("term_weight", C.c_double * 3),
         ("factor", FactorDesc * MAX_FACTORS),
-        ("metrics", C.c_int32), ("auto_reset", C.c_int32),
+        ("metrics", C.c_int32), ("auto_reset", C.c_int32), ("store_derived", C.c_int32), ("pad_tail_", C.c_int32),
         ("rise_low", C.c_double), ("rise_high", C.c_double),
     ]
 
 
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ["rows", "sim", "derived", "gym", "tprop", "goal", "act_ring", "cmd_ring", "end_ring", "lag_ring",
+                ["rows", "sim", "cold", "derived", "gym", "tprop", "goal", "act_ring", "cmd_ring", "end_ring", "lag_ring",
                  "window", "lag_depth", "lag_groups"]]
 
 

@@ -82,6 +82,9 @@ SPECIALISED = [
     ("c2_default", "default", None, None),                                   # BASELINE configs[1]
     ("c3_cnn_step2_dryden", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),  # BASELINE configs[2]/[3]
     ("c5_examples", "examples", None, None),                                 # BASELINE configs[4]
+    # "_lean": the same configurations with derived_views=False (no per-step roll/pitch/yaw/Va/alpha/beta rows)
+    ("c2_default_lean", "default", None, None),
+    ("c3_cnn_step2_dryden_lean", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),
 ]
 
 

@@ -89,12 +89,15 @@ class LazyInfos(object):
 class FixedWingVecEnv(object):
     def __init__(self, config_path=None, num_envs=1, device=0, sim_config_path=None, sim_parameter_path=None,
                  config_kw=None, sim_config_kw=None, auto_reset=True, as_numpy=False, env_id_base=0, seed=0,
-                 _backend=None, _lib_path=None):
+                 derived_views=True, _backend=None, _lib_path=None):
         self.env_config = EnvConfig(config_path, sim_config_path, sim_parameter_path, config_kw, sim_config_kw)
         self.cfg = self.env_config.cfg
         self.num_envs = int(num_envs)
         self.as_numpy = as_numpy
         self.auto_reset = auto_reset
+        # derived_views=False drops the per-step write of roll/pitch/yaw/Va/alpha/beta into the arena (32 B/env-step);
+        # they are only needed by host-side views (field("roll"), the single-env class), never by step() itself
+        self.derived_views = bool(derived_views)
         self.training = True
         self._lib = nat.load_library(_lib_path)
         self._mem = _backend if _backend is not None else _TorchBackend(device)
@@ -106,7 +109,7 @@ class FixedWingVecEnv(object):
         self.target_names = list(ec.target_names)
         self.dt = ec.dt
 
-        self._c = ec.compile(auto_reset=auto_reset)
+        self._c = ec.compile(auto_reset=auto_reset, store_derived=self.derived_views)
         self.layout = nat.Layout()
         nat.check(self._lib, self._lib.fwg_get_layout(ctypes.byref(self._c), ctypes.byref(self.layout)))
         N, m = self.num_envs, self._mem
@@ -157,7 +160,7 @@ class FixedWingVecEnv(object):
         return int(self._lib.fwg_spec_index(self._handle))
 
     def _upload(self):
-        self._c = self.env_config.compile(auto_reset=self.auto_reset)
+        self._c = self.env_config.compile(auto_reset=self.auto_reset, store_derived=self.derived_views)
         nat.check(self._lib, self._lib.fwg_update_config(self._handle, ctypes.byref(self._c)))
 
     def set_simulator_attr(self, key, value):
@@ -310,22 +313,31 @@ class FixedWingVecEnv(object):
         L = self.layout
         sim = {"e0": 0, "e1": 1, "e2": 2, "e3": 3, "omega_p": 4, "omega_q": 5, "omega_r": 6, "position_n": 7,
                "position_e": 8, "position_d": 9, "velocity_u": 10, "velocity_v": 11, "velocity_w": 12,
-               "elevon_right": 13, "elevon_left": 14, "throttle": 15, "elevon_right_dot": 16, "elevon_left_dot": 17,
-               "wind_n": 18, "wind_e": 19, "wind_d": 20}
+               "elevon_right": 13, "elevon_left": 14, "throttle": 15, "elevon_right_dot": 16, "elevon_left_dot": 17}
         derived = {"roll": 0, "pitch": 1, "yaw": 2, "Va": 3, "alpha": 4, "beta": 5}
         if name in sim:
             return self.word(L.sim + sim[name])
         if name in derived:
+            if not self.derived_views:
+                raise KeyError("{} needs FixedWingVecEnv(derived_views=True)".format(name))
             return self.word(L.derived + derived[name])
+        if name in ("wind_n", "wind_e", "wind_d"):
+            return self.word(L.cold + ("wind_n", "wind_e", "wind_d").index(name))
         if name == "elevator":
             return 0.5 * (self.word(L.sim + 13) + self.word(L.sim + 14))
         if name == "aileron":
             return 0.5 * (self.word(L.sim + 14) - self.word(L.sim + 13))
         if name.startswith("target_"):
             return self.word(L.gym + self.target_names.index(name[7:]))
-        counters = {"steps_count": 3, "steps_for_target": 4, "flags": 5, "episode": 6}
-        if name in counters:
-            return self._mem.view_i32(self.state)[(L.gym + counters[name]) >> 2, :, (L.gym + counters[name]) & 3]
+        iw = self._mem.view_i32(self.state)
+        if name == "steps_count":
+            return iw[(L.gym + 3) >> 2, :, (L.gym + 3) & 3] & 0xFFFF
+        if name == "steps_for_target":
+            return (iw[(L.gym + 3) >> 2, :, (L.gym + 3) & 3] >> 16) & 0xFFFF
+        if name == "flags":
+            return iw[(L.gym + 4) >> 2, :, (L.gym + 4) & 3]
+        if name == "episode":
+            return iw[(L.cold + 3) >> 2, :, (L.cold + 3) & 3]
         raise KeyError(name)
 
     def get_state(self, names):

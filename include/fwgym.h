@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 6
+#define FWG_ABI_VERSION 7
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -179,6 +179,8 @@ typedef struct fwg_config {
 
     int32_t metrics;                    /* any entry in cfg["metrics"] (fixed_wing.py:419-421) */
     int32_t auto_reset;                 /* VecEnv semantics: a done env restarts inside the same fwg_step */
+    int32_t store_derived;              /* keep roll/pitch/yaw/Va/alpha/beta of the committed state in the arena (host views) */
+    int32_t pad_tail_;
     double rise_low, rise_high;         /* metrics[rise_time].low/high (fixed_wing.py:1131) */
 } fwg_config;
 
@@ -186,11 +188,12 @@ typedef struct fwg_config {
  * ((w >> 2) * N + e) * 4 + (w & 3).  All offsets below are in words and multiples of 4. */
 typedef struct fwg_layout {
     int32_t rows;        /* total words per env (multiple of 4); arena = rows * N words */
-    int32_t sim;         /* 32: e0 e1 e2 e3 | p q r pn | pe pd u v | w elevon_r elevon_l throttle | elevon_r_dot elevon_l_dot wind_n wind_e | wind_d dryden0..2 | dryden3..6 | dryden7 pad pad pad */
-    int32_t derived;     /* 8: roll pitch yaw Va | alpha beta pad pad (committed state, written every step) */
-    int32_t gym;         /* 40: tgt0 tgt1 tgt2 steps_count | steps_for_target flags episode window_counts | goal_counts(2) prev_cmd0 prev_cmd1 | prev_cmd2 sum_dcmd settle(2) | e0(3) rise0 | sum_e(3) rise1 | sum_abs_e(3) rise2 | min_e(3) prev_err0 | max_e(3) prev_err1 | prev_err2 prev_shaping(3) */
+    int32_t sim;         /* 28: e0 e1 e2 e3 | p q r pn | pe pd u v | w elevon_r elevon_l throttle | elevon_r_dot elevon_l_dot dryden0 dryden1 | dryden2..5 | dryden6 dryden7 pad pad */
+    int32_t cold;        /* 8: wind_n wind_e wind_d episode | e0(3) pad -- per-episode constants, written by reset only */
+    int32_t derived;     /* 8: roll pitch yaw Va | alpha beta pad pad of the committed state (written when store_derived) */
+    int32_t gym;         /* 36: tgt0 tgt1 tgt2 steps_count|steps_for_target<<16 | flags window_counts goal_counts(2) | prev_cmd(3) sum_dcmd | settle(2) rise0 rise1 | rise2 sum_e(3) | sum_abs_e(3) prev_err0 | min_e(3) prev_err1 | max_e(3) prev_err2 | prev_shaping(3) pad */
     int32_t tprop;       /* 12: per target slope|amplitude, period, phase, bias (linear/sinusoidal targets) */
-    int32_t goal;        /* 16: goal windows target0..2, all: 4 x 128 bit */
+    int32_t goal;        /* 16 plain word rows [word][N] (NOT grouped): goal-window ring, 8 positions x 4 flags per word */
     int32_t act_ring;    /* window*4: raw actions (a0 a1 a2 pad) per slot, slot = global_step % window */
     int32_t cmd_ring;    /* window*4: constrained commands (only when observations need them) */
     int32_t end_ring;    /* 50*4: errors (e0 e1 e2 pad) per slot, slot = global_step % 50 */

@@ -141,10 +141,10 @@ def oracle_spec_from_env_config(ec):
 def physics_state(vec):
     """(y[N,18], wind[N,3], dryden[N,8]) float64 copies of the device state."""
     W = words(vec)
-    s0 = vec.layout.sim
+    s0, c0 = vec.layout.sim, vec.layout.cold
     y = W[s0:s0 + 18].T.astype(np.float64)
-    wind = W[s0 + 18:s0 + 21].T.astype(np.float64)
-    dry = W[s0 + 21:s0 + 29].T.astype(np.float64) if vec.env_config.turbulence else np.zeros((y.shape[0], 8))
+    wind = W[c0:c0 + 3].T.astype(np.float64)
+    dry = W[s0 + 18:s0 + 26].T.astype(np.float64) if vec.env_config.turbulence else np.zeros((y.shape[0], 8))
     return y, wind, dry
 
 

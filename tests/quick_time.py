@@ -8,7 +8,8 @@ from gym_fixed_wing.vec_env import FixedWingVecEnv
 
 def run(kind, n, ckw, skw, steps=200):
     cfg = configs.reference_like(kind)
-    vec = FixedWingVecEnv(cfg, num_envs=n, device=0, config_kw=ckw, sim_config_kw=skw, seed=1)
+    vec = FixedWingVecEnv(cfg, num_envs=n, device=0, config_kw=ckw, sim_config_kw=skw, seed=1, derived_views=False)
+    assert vec.spec_index >= 0
     vec.reset()
     acts = [torch.rand((n, 3), device="cuda") * 2 - 1 for _ in range(16)]
     for t in range(50): vec.step_device(acts[t % 16])
