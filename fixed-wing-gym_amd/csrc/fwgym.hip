@@ -117,11 +117,12 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     if (TURB) dryden_output(c, E.dry, gust);
     // second wave of requests: bookkeeping rows to registers, action windows and lagged observation rows HBM -> LDS;
     // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
+    // order = order of need (returns are in order): bookkeeping rows, action windows, lagged observation rows
+    load_gym(c, A.S, A.N, e, E, A.bit_goal);
     for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.act_ring >> 2) + s, e), lds + M.aring + s * (4 * FWG_WAVE));
     if (c.use_cmd_ring)
         for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
     stream_lag_rows(c, A, e, lds + M.lag);
-    load_gym(c, A.S, A.N, e, E, A.bit_goal);
     const int fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
     const bool ok = fail == 0;
     if (!ok) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
