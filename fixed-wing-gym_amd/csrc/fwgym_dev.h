@@ -147,6 +147,7 @@ __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5
 // ---------------------------------------------------------------------------------------------------------------------
 // async HBM -> LDS streaming (global_load_lds)
 // ---------------------------------------------------------------------------------------------------------------------
+typedef float fwg_v4f __attribute__((ext_vector_type(4)));   // native 16-byte vector (for __builtin_nontemporal_store)
 typedef __attribute__((address_space(1))) const void* fwg_gptr;
 typedef __attribute__((address_space(3))) void* fwg_lptr;
 

@@ -498,6 +498,13 @@ __device__ __forceinline__ void add_obs_noise(const DevCfg& c, const KArgs& A, l
 // [N][obs_dim] batch: every lane parks its record in the LDS staging area ([lane][obs_dim]) and the wave then writes
 // the block in linear order, 1 KiB per store instruction (16 B per lane) when the record size allows.  `lanes` selects
 // the records to write (all, or the finished episodes for the terminal observations).  Must be called by all lanes.
+// The observation batch is never read back by the kernels: streaming (non-temporal) stores keep it from displacing the
+// state arena, which the next launch re-reads, out of the L2 / Infinity Cache.
+__device__ __forceinline__ void stream_store4(float4* p, float4 v) {
+    fwg_v4f x;
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    __builtin_nontemporal_store(x, reinterpret_cast<fwg_v4f*>(p));
+}
 template <class OB>
 __device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ out, long env0, long N, const OB& ob,
                                           float* stage, int lane, unsigned long long lanes) {
@@ -515,7 +522,7 @@ __device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ o
 #pragma unroll 4
         for (int i = lane; i < total4; i += FWG_WAVE) {
             const int l = (4 * i) / D;
-            if (((lanes >> l) & 1ull) && env0 + l < N) o4[i] = all[i];
+            if (((lanes >> l) & 1ull) && env0 + l < N) stream_store4(o4 + i, all[i]);
         }
     } else {
         const int Ds = obs_stage_stride(D);

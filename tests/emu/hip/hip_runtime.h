@@ -21,6 +21,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define ext_vector_type(n) vector_size(4 * (n))
 #define __shared__
 #define FWG_DMA_DRAIN() ((void)0)
 
@@ -93,6 +94,7 @@ static inline int __popc(unsigned x) { return __builtin_popcount(x); }
     memcpy((char*)(l) + threadIdx.x * (size), (const void*)(g), (size))
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 using std::max;
 using std::min;
 
