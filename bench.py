@@ -85,8 +85,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FWG_BENCH_FORCE_DIST", "0") == "1"   # the latter: exercise RCCL on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
@@ -105,11 +109,11 @@ def main():
     gen.manual_seed(1234 + rank)
     pool = [torch.rand((n_envs, 3), device=dev, generator=gen) * 2 - 1 for _ in range(32)]
     red_dev = torch.zeros(16, device=dev)
-    gathered = torch.zeros(16 * world, device=dev) if world > 1 else None
+    gathered = torch.zeros(16 * world, device=dev) if use_dist else None
 
     def reduce_step():
         red = vec.reduce_success()                 # local sums (syncs this rank's stream)
-        if world > 1:
+        if use_dist:
             red_dev.copy_(torch.as_tensor(red, dtype=torch.float32))
             dist.all_gather_into_tensor(gathered, red_dev)   # RCCL over xGMI: 64 B per rank
 
@@ -121,7 +125,7 @@ def main():
 
     run(args.warmup, 0)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -130,11 +134,11 @@ def main():
     run(args.steps, args.warmup)
     ev1.record()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
@@ -185,7 +189,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     vec.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,99 @@
+"""On-device rollout collection for PPO-style training on FixedWingVecEnv (BASELINE.json
+configs[4]).  Replaces the data path of the reference's training script -- `VecNormalize(SubprocVecEnv(...))` feeding
+`PPO2(MlpPolicy)` (examples/train_rl_controller.py:223-231) -- with device-resident pieces: running observation /
+return normalisation (VecNormalize), a 64-64 tanh MLP policy + value net (the architecture of the shipped
+models/mlp_controller), and a rollout buffer filled without leaving the GPU.  The optimiser step is out of scope."""
+import math
+
+import torch
+from torch import nn
+
+
+class RunningMeanStd(object):
+    """Batched parallel-variance update (what stable-baselines' VecNormalize keeps as obs_rms / ret_rms)."""
+
+    def __init__(self, shape, device=None, epsilon=1e-4):
+        self.mean = torch.zeros(shape, dtype=torch.float32, device=device)
+        self.var = torch.ones(shape, dtype=torch.float32, device=device)
+        self.count = epsilon
+
+    def update(self, x):
+        x = x.reshape(-1, *self.mean.shape)
+        b_mean, b_var, b_count = x.mean(dim=0), x.var(dim=0, unbiased=False), x.shape[0]
+        delta = b_mean - self.mean
+        tot = self.count + b_count
+        self.mean = self.mean + delta * (b_count / tot)
+        m2 = self.var * self.count + b_var * b_count + delta * delta * (self.count * b_count / tot)
+        self.var = m2 / tot
+        self.count = tot
+
+
+class VecNormalizeDevice(object):
+    def __init__(self, obs_shape, num_envs, device=None, clip_obs=10.0, clip_reward=10.0, gamma=0.99, training=True):
+        self.obs_rms = RunningMeanStd(obs_shape, device)
+        self.ret_rms = RunningMeanStd((), device)
+        self.ret = torch.zeros(num_envs, dtype=torch.float32, device=device)
+        self.clip_obs, self.clip_reward, self.gamma, self.training = clip_obs, clip_reward, gamma, training
+
+    def obs(self, obs):
+        if self.training:
+            self.obs_rms.update(obs)
+        return ((obs - self.obs_rms.mean) / torch.sqrt(self.obs_rms.var + 1e-8)).clamp(-self.clip_obs, self.clip_obs)
+
+    def reward(self, rew, done):
+        self.ret = self.ret * self.gamma + rew
+        if self.training:
+            self.ret_rms.update(self.ret)
+        out = (rew / torch.sqrt(self.ret_rms.var + 1e-8)).clamp(-self.clip_reward, self.clip_reward)
+        self.ret = torch.where(done.bool(), torch.zeros_like(self.ret), self.ret)
+        return out
+
+
+class MlpPolicy(nn.Module):
+    """Separate 64-64 tanh networks for the Gaussian policy mean and the value (stable-baselines MlpPolicy layout of
+    the shipped MLP controller: pi_fc0/pi_fc1/pi, vf_fc0/vf_fc1/vf), state-independent log-std."""
+
+    def __init__(self, obs_dim, act_dim=3, hidden=64):
+        super().__init__()
+        self.pi = nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                                nn.Linear(hidden, act_dim))
+        self.vf = nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                                nn.Linear(hidden, 1))
+        self.log_std = nn.Parameter(torch.zeros(act_dim))
+
+    @torch.no_grad()
+    def act(self, obs, deterministic=False):
+        mean = self.pi(obs)
+        value = self.vf(obs).squeeze(-1)
+        if deterministic:
+            return mean, value, torch.zeros(obs.shape[0], device=obs.device)
+        std = self.log_std.exp()
+        noise = torch.randn_like(mean)
+        action = mean + std * noise
+        logp = (-0.5 * noise * noise - self.log_std - 0.5 * math.log(2 * math.pi)).sum(dim=-1)
+        return action, value, logp
+
+
+def collect_rollout(vec, policy, norm, n_steps, obs=None):
+    """n_steps of policy inference + env step for all envs, everything on the device.  Returns the rollout buffer
+    {obs, actions, values, logp, rewards, dones} ([n_steps, N, ...]) and the last normalised observation."""
+    N = vec.num_envs
+    raw = vec._obs.reshape(N, -1) if obs is None else obs
+    raw = torch.as_tensor(raw)
+    dev = raw.device
+    buf = {"obs": torch.empty((n_steps, N, raw.shape[1]), device=dev), "actions": torch.empty((n_steps, N, 3), device=dev),
+           "values": torch.empty((n_steps, N), device=dev), "logp": torch.empty((n_steps, N), device=dev),
+           "rewards": torch.empty((n_steps, N), device=dev), "dones": torch.empty((n_steps, N), dtype=torch.uint8, device=dev)}
+    cur = norm.obs(raw)
+    for t in range(n_steps):
+        action, value, logp = policy.act(cur)
+        buf["obs"][t], buf["actions"][t], buf["values"][t], buf["logp"][t] = cur, action, value, logp
+        if hasattr(vec, "step_device") and isinstance(vec._obs, torch.Tensor):
+            o, r, d = vec.step_device(action.contiguous())
+        else:
+            o, r, d, _ = vec.step(action.cpu().numpy())
+            o, r, d = torch.as_tensor(o).reshape(N, -1), torch.as_tensor(r), torch.as_tensor(d)
+        buf["rewards"][t] = norm.reward(torch.as_tensor(r).to(dev), torch.as_tensor(d).to(dev))
+        buf["dones"][t] = torch.as_tensor(d).to(dev)
+        cur = norm.obs(torch.as_tensor(o).reshape(N, -1).to(dev))
+    return buf, cur

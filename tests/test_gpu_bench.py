@@ -1,0 +1,40 @@
+"""bench.py contract on the GPU box: one JSON line with the required keys; also through torch.distributed.run with the
+RCCL path forced on (one rank), so that init / barrier / all_gather_into_tensor / max-reduce are exercised."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "50",
+                          "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = _last_json(out.stdout)
+    assert KEYS <= set(j) and j["n_gpus"] == 1 and j["steps"] == 300 and j["scaling"] == "weak" and j["dtype"] == "f32"
+    assert j["value"] > 1e9 and 0.2 < j["roofline"]["frac"] < 1.0 and j["roofline"]["bound"] == "hbm"
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and j["config"]["specialised_kernel"]
+
+
+def test_bench_through_torchrun_with_rccl():
+    env = dict(os.environ, FWG_BENCH_FORCE_DIST="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "300", "--warmup", "50", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = _last_json(out.stdout)
+    assert j["n_gpus"] == 1 and j["value"] > 1e9
