@@ -71,10 +71,12 @@ template <int SPEC> struct KernelTypes {  // generic kernel: lane-private LDS co
 FWG_SPEC_LIST(FWG_SPEC_TYPES)
 
 template <bool TURB, int SPEC>
-__global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A) {
+__global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef KernelTypes<SPEC> KT;
     const DevCfg& c = SpecCfg<SPEC>::get(cp);
+    const KArgs A = resolve_slots(c, A0);
+    if (A0.gstep_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *A0.gstep_out = *A0.gstep_in + 1;
     const DynCfg& dc = *dp;
     const int lane = threadIdx.x;
     const long env0 = (long)blockIdx.x * FWG_WAVE;
@@ -392,10 +394,11 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 // reset kernel
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool TURB, int SPEC>
-__global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A) {
+__global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef KernelTypes<SPEC> KT;
     const DevCfg& c = SpecCfg<SPEC>::get(cp);
+    const KArgs A = resolve_slots(c, A0);
     const DynCfg& dc = *dp;
     const int lane = threadIdx.x;
     const long env0 = (long)blockIdx.x * FWG_WAVE;
@@ -456,6 +459,9 @@ struct fwg_handle {
     int device;
     uint64_t seed;
     int64_t gstep;  // number of env steps taken so far (drives the ring slots)
+    int graph_mode; // the counter lives on the device (d_gstep[2], double-buffered by the parity of the host count)
+    int64_t gstep_at_capture;
+    long long* d_gstep;
     size_t lds_bytes;
 };
 
@@ -694,6 +700,9 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     HIP_TRY(hipMemcpy(h->d_dyn, &h->hd, sizeof(DynCfg), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->d_reduce, sizeof(float) * FWG_N_REDUCE));
     HIP_TRY(hipMalloc((void**)&h->d_flag, sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->d_gstep, 2 * sizeof(long long)));
+    HIP_TRY(hipMemset(h->d_gstep, 0, 2 * sizeof(long long)));
+    h->graph_mode = 0;
     HIP_TRY(hipMemcpy(h->d_cfg, &h->h, sizeof(DevCfg), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->d_reduce, 0, sizeof(float) * FWG_N_REDUCE));
     HIP_TRY(hipMemset(h->d_flag, 0, sizeof(int)));
@@ -704,7 +713,7 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
 int fwg_destroy(fwg_handle* h) {
     if (!h) return FWG_OK;
     (void)hipSetDevice(h->device);
-    (void)hipFree(h->d_cfg); (void)hipFree(h->d_dyn); (void)hipFree(h->d_reduce); (void)hipFree(h->d_flag);
+    (void)hipFree(h->d_cfg); (void)hipFree(h->d_dyn); (void)hipFree(h->d_reduce); (void)hipFree(h->d_flag); (void)hipFree(h->d_gstep);
     delete h;
     return FWG_OK;
 }
@@ -758,6 +767,7 @@ int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const
     base_args(h, &A);
     A.mask = mask; A.init_state = init_state; A.init_target = init_target; A.obs = obs_out;
     fill_slots(h, h->gstep - 1, &A);  // initial records take the ring position of the last completed step
+    if (h->graph_mode) { A.gstep_in = h->d_gstep + (h->gstep & 1); A.reset_launch = 1; }
     launch<false>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return FWG_OK;
@@ -771,6 +781,7 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
     A.actions = actions; A.obs = obs_out; A.rew = reward_out; A.done = done_out; A.term = term_code_out;
     A.term_obs = terminal_obs_out; A.metrics = metrics_out; A.tgt_out = target_out;
     fill_slots(h, h->gstep, &A);
+    if (h->graph_mode) { A.gstep_in = h->d_gstep + (h->gstep & 1); A.gstep_out = h->d_gstep + ((h->gstep + 1) & 1); }
     launch<true>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     h->gstep += 1;
@@ -798,6 +809,41 @@ int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream) {
 }
 
 int fwg_spec_index(const fwg_handle* h) { return h ? h->spec : -1; }
+
+int fwg_set_graph_mode(fwg_handle* h, int enable, void* stream) {
+    if (!h) return fail_with(FWG_ERR_INVALID, "null handle");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (enable) {
+        const long long g[2] = {(long long)h->gstep, (long long)h->gstep};
+        HIP_TRY(hipMemcpy(h->d_gstep, g, sizeof(g), hipMemcpyHostToDevice));
+    } else if (h->graph_mode) {
+        long long g[2];
+        HIP_TRY(hipMemcpy(g, h->d_gstep, sizeof(g), hipMemcpyDeviceToHost));
+        h->gstep = g[0] > g[1] ? g[0] : g[1];
+    }
+    h->graph_mode = enable ? 1 : 0;
+    return FWG_OK;
+}
+
+int fwg_capture_begin(fwg_handle* h) {
+    if (!h || !h->graph_mode) return fail_with(FWG_ERR_INVALID, "fwg_capture_begin needs graph mode");
+    h->gstep_at_capture = h->gstep;
+    return FWG_OK;
+}
+int fwg_capture_end(fwg_handle* h) {   // the captured calls did not execute: take the host count back
+    if (!h || !h->graph_mode) return fail_with(FWG_ERR_INVALID, "fwg_capture_end needs graph mode");
+    if ((h->gstep - h->gstep_at_capture) % 2 != 0) return fail_with(FWG_ERR_INVALID, "captured an odd number of steps");
+    h->gstep = h->gstep_at_capture;
+    return FWG_OK;
+}
+
+int fwg_note_replayed_steps(fwg_handle* h, int64_t n_steps) {
+    if (!h || n_steps < 0) return fail_with(FWG_ERR_INVALID, "bad argument");
+    if (!h->graph_mode) return fail_with(FWG_ERR_INVALID, "fwg_note_replayed_steps needs graph mode");
+    if (n_steps % 2 != 0) return fail_with(FWG_ERR_INVALID, "a replayed launch sequence must hold an even number of steps");
+    h->gstep += n_steps;
+    return FWG_OK;
+}
 int fwg_num_specs(void) {
     int n = 0;
     while (kSpecTable[n] != nullptr) ++n;

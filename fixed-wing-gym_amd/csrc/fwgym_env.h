@@ -24,7 +24,28 @@ struct KArgs {
     unsigned seed_lo, seed_hi;
     int slot_act, slot_end, slot_lag, bit_goal;  // ring positions of the CURRENT global step
     int lag_slots[FWG_MAX_ROWS];                 // ring slot holding the row pushed r*obs_step steps ago
+    // graph mode (fwg_set_graph_mode): the global step counter lives on the device so that a captured launch sequence
+    // can be replayed; double-buffered -- a step launch reads gstep_in and block 0 publishes gstep_in+1 to gstep_out
+    const long long* gstep_in;
+    long long* gstep_out;
+    int reset_launch;                            // k_reset: positions refer to the LAST completed step (counter - 1)
 };
+
+__device__ __forceinline__ int dev_pmod(long long a, int m) { return m > 0 ? (int)(((a % m) + m) % m) : 0; }
+// ring positions of this launch: host-computed kernel arguments, or derived from the device-resident counter
+__device__ __forceinline__ KArgs resolve_slots(const DevCfg& c, const KArgs& A0) {
+    KArgs A = A0;
+    if (A0.gstep_in != nullptr) {
+        const long long g = *A0.gstep_in - (A0.reset_launch ? 1 : 0);
+        A.slot_act = dev_pmod(g, c.L.window);
+        A.slot_end = dev_pmod(g, FWG_END_WINDOW);
+        A.slot_lag = dev_pmod(g, c.L.lag_depth);
+        A.bit_goal = dev_pmod(g, c.streak_req);
+#pragma unroll
+        for (int r = 0; r < FWG_MAX_ROWS; ++r) A.lag_slots[r] = dev_pmod(g - (long long)r * c.obs_step, c.L.lag_depth);
+    }
+    return A;
+}
 
 // LDS carve (in floats) for one 64-lane block: the action windows (streamed in by global_load_lds) and, for the
 // generic (non-specialised) kernel only, the per-lane scratch tables that config-driven indices address

@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 7
+FWG_ABI_VERSION = 8
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -126,7 +126,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libfwgym.so")
 EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fwg_update_config", "fwg_seed",
            "fwg_reset", "fwg_step", "fwg_check_actions", "fwg_reduce_success", "fwg_global_step", "fwg_last_error",
-           "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index"]
+           "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index", "fwg_set_graph_mode", "fwg_note_replayed_steps",
+           "fwg_capture_begin", "fwg_capture_end"]
 _libs = {}
 
 
@@ -168,6 +169,14 @@ def load_library(path=None):
     lib.fwg_num_specs.restype = C.c_int
     lib.fwg_spec_index.argtypes = [vp]
     lib.fwg_spec_index.restype = C.c_int
+    lib.fwg_set_graph_mode.argtypes = [vp, C.c_int, vp]
+    lib.fwg_set_graph_mode.restype = C.c_int
+    lib.fwg_note_replayed_steps.argtypes = [vp, i64]
+    lib.fwg_note_replayed_steps.restype = C.c_int
+    lib.fwg_capture_begin.argtypes = [vp]
+    lib.fwg_capture_begin.restype = C.c_int
+    lib.fwg_capture_end.argtypes = [vp]
+    lib.fwg_capture_end.restype = C.c_int
     for name in ("fwg_get_layout", "fwg_create", "fwg_destroy", "fwg_update_config", "fwg_seed", "fwg_reset",
                  "fwg_step", "fwg_check_actions", "fwg_reduce_success"):
         getattr(lib, name).restype = C.c_int

@@ -15,17 +15,17 @@ class RunningMeanStd(object):
     def __init__(self, shape, device=None, epsilon=1e-4):
         self.mean = torch.zeros(shape, dtype=torch.float32, device=device)
         self.var = torch.ones(shape, dtype=torch.float32, device=device)
-        self.count = epsilon
+        self.count = torch.full((), epsilon, dtype=torch.float32, device=device)   # a tensor: graph-capturable
 
     def update(self, x):
         x = x.reshape(-1, *self.mean.shape)
         b_mean, b_var, b_count = x.mean(dim=0), x.var(dim=0, unbiased=False), x.shape[0]
         delta = b_mean - self.mean
         tot = self.count + b_count
-        self.mean = self.mean + delta * (b_count / tot)
         m2 = self.var * self.count + b_var * b_count + delta * delta * (self.count * b_count / tot)
-        self.var = m2 / tot
-        self.count = tot
+        self.mean.add_(delta * (b_count / tot))      # in place: the buffers keep their addresses under graph replay
+        self.var.copy_(m2 / tot)
+        self.count.copy_(tot)
 
 
 class VecNormalizeDevice(object):
@@ -41,11 +41,11 @@ class VecNormalizeDevice(object):
         return ((obs - self.obs_rms.mean) / torch.sqrt(self.obs_rms.var + 1e-8)).clamp(-self.clip_obs, self.clip_obs)
 
     def reward(self, rew, done):
-        self.ret = self.ret * self.gamma + rew
+        self.ret.mul_(self.gamma).add_(rew)
         if self.training:
             self.ret_rms.update(self.ret)
         out = (rew / torch.sqrt(self.ret_rms.var + 1e-8)).clamp(-self.clip_reward, self.clip_reward)
-        self.ret = torch.where(done.bool(), torch.zeros_like(self.ret), self.ret)
+        self.ret.mul_(1.0 - done.to(self.ret.dtype))
         return out
 
 
@@ -97,3 +97,50 @@ def collect_rollout(vec, policy, norm, n_steps, obs=None):
         buf["dones"][t] = torch.as_tensor(d).to(dev)
         cur = norm.obs(torch.as_tensor(o).reshape(N, -1).to(dev))
     return buf, cur
+
+
+class GraphedRollout(object):
+    """The whole n-step rollout (policy forward, normalisation, fused env step, buffer writes) captured ONCE into a
+    hipGraph (torch.cuda.CUDAGraph) and replayed: no per-kernel host launch cost.  Needs the env's graph mode (the
+    global step counter lives on the device, see include/fwgym.h) and an even n_steps."""
+
+    def __init__(self, vec, policy, norm, n_steps):
+        assert n_steps % 2 == 0, "graph mode double-buffers the step counter: capture an even number of steps"
+        self.vec, self.policy, self.norm, self.n_steps = vec, policy, norm, n_steps
+        N, D = vec.num_envs, vec.obs_dim
+        dev = vec._obs.device
+        self.buf = {"obs": torch.empty((n_steps, N, D), device=dev), "actions": torch.empty((n_steps, N, 3), device=dev),
+                    "values": torch.empty((n_steps, N), device=dev), "logp": torch.empty((n_steps, N), device=dev),
+                    "rewards": torch.empty((n_steps, N), device=dev),
+                    "dones": torch.empty((n_steps, N), dtype=torch.uint8, device=dev)}
+        self.action = torch.zeros((N, 3), device=dev)
+        vec.set_graph_mode(True)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):          # warm-up outside capture (allocations, lazy initialisation)
+            self._body(2)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        vec.capture_begin()
+        with torch.cuda.graph(self.graph):
+            self._body(n_steps)
+        vec.capture_end()
+
+    def _body(self, n):
+        vec, buf = self.vec, self.buf
+        N = vec.num_envs
+        cur = self.norm.obs(vec._obs.reshape(N, -1))
+        for t in range(n):
+            action, value, logp = self.policy.act(cur)
+            self.action.copy_(action)
+            buf["obs"][t].copy_(cur); buf["actions"][t].copy_(action); buf["values"][t].copy_(value); buf["logp"][t].copy_(logp)
+            o, r, d = vec.step_device(self.action)
+            buf["rewards"][t].copy_(self.norm.reward(r, d))
+            buf["dones"][t].copy_(d)
+            cur = self.norm.obs(o.reshape(N, -1))
+
+    def run(self):
+        self.graph.replay()
+        self.vec.note_replayed_steps(self.n_steps)
+        return self.buf

@@ -154,6 +154,20 @@ class FixedWingVecEnv(object):
         self.env_config.set_curriculum_level(level)
         self._upload()
 
+    def set_graph_mode(self, enable=True):
+        """Keeps the global step counter on the device so that a captured sequence of step launches (hipGraph /
+        torch.cuda.CUDAGraph) can be replayed; see fwg_set_graph_mode in include/fwgym.h for the rules."""
+        nat.check(self._lib, self._lib.fwg_set_graph_mode(self._handle, int(bool(enable)), self._mem.stream()))
+
+    def capture_begin(self):
+        nat.check(self._lib, self._lib.fwg_capture_begin(self._handle))
+
+    def capture_end(self):
+        nat.check(self._lib, self._lib.fwg_capture_end(self._handle))
+
+    def note_replayed_steps(self, n_steps):
+        nat.check(self._lib, self._lib.fwg_note_replayed_steps(self._handle, int(n_steps)))
+
     @property
     def spec_index(self):
         """Index of the build-time specialised kernel this env runs, -1 = generic kernel."""

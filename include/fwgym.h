@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 7
+#define FWG_ABI_VERSION 8
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -277,6 +277,16 @@ int fwg_dump_spec(const fwg_config* cfg_host, uint32_t* words_out_host, int64_t 
 /* Number of frozen configurations compiled into this library, and the one a handle runs (-1 = generic kernel). */
 int fwg_num_specs(void);
 int fwg_spec_index(const fwg_handle* h);
+
+/* hipGraph support.  The ring positions of a launch depend on the global step counter; in graph mode that counter
+ * lives on the device (each step launch publishes counter+1), so a captured sequence of fwg_step launches can be
+ * replayed any number of times.  Rules: enable before capturing; capture an EVEN number of fwg_step calls per graph
+ * (the counter is double-buffered by parity); after every replay tell the host how many steps ran
+ * (fwg_note_replayed_steps) before issuing further direct calls.  Both functions synchronise `stream`/are host-only. */
+int fwg_set_graph_mode(fwg_handle* h, int enable, void* stream);
+int fwg_capture_begin(fwg_handle* h);   /* bracket the fwg_step calls issued under stream capture (they do not execute) */
+int fwg_capture_end(fwg_handle* h);
+int fwg_note_replayed_steps(fwg_handle* h, int64_t n_steps);
 
 /* Global step counter driving the ring slots (diagnostics/tests). */
 int64_t fwg_global_step(const fwg_handle* h);

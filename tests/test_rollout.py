@@ -53,3 +53,17 @@ def test_rollout_throughput_on_gpu():
     rate = 128 * n / dt
     print("C5 rollout: {:.3e} env-steps/s end to end (policy forward + normalisation + env step), {:.1f} us/step".format(rate, dt / 128 * 1e6))
     assert torch.isfinite(buf["rewards"]).all() and rate > 1e7
+    # the same rollout as ONE replayed hipGraph
+    from gym_fixed_wing.rollout import GraphedRollout
+    g = GraphedRollout(vec, policy, norm, 128)
+    g.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        buf = g.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print("C5 rollout, hipGraph replay: {:.3e} env-steps/s, {:.1f} us/step".format(128 * n / dt, dt / 128 * 1e6))
+    assert torch.isfinite(buf["rewards"]).all() and torch.isfinite(buf["obs"]).all()
+    steps = vec.get_state(["steps_count"])["steps_count"]
+    assert steps.min() >= 0 and steps.max() <= vec.cfg["steps_max"]
