@@ -28,7 +28,7 @@ def evaluation_overrides(use_pid, config_kw=None):
 
 
 def evaluate_on_set(scenarios, config_path=None, policy=None, config_kw=None, turbulence_intensity="none", device=0,
-                    seed=0, metrics=METRICS, **vec_kw):
+                    seed=0, metrics=METRICS, pid_gains=None, **vec_kw):
     """policy: None => the PID baseline; otherwise a callable obs[N, ...] (device tensor) -> actions[N, 3]."""
     import torch
     use_pid = policy is None
@@ -53,6 +53,8 @@ def evaluate_on_set(scenarios, config_path=None, policy=None, config_kw=None, tu
             raise ValueError("When using PID roll, pitch, Va, omega_p, omega_q, omega_r must be part of the "
                              "observation vector.")
         pid = BatchedPID(n, dt=vec.dt, device=dev)
+        for k, v in (pid_gains or {}).items():
+            setattr(pid, k, v)
         pid.set_reference(*(torch.as_tensor(targets[k], device=dev) for k in names))
     active = torch.ones(n, dtype=torch.bool, device=dev)
     rewards = [[] for _ in range(n)]
