@@ -34,7 +34,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------------------------------------
 struct SpecWords { unsigned w[sizeof(DevCfg) / 4]; };
 static_assert(sizeof(SpecWords) == sizeof(DevCfg), "DevCfg must be made of 32-bit members only");
-#if defined(FWG_WITH_SPECS)
+#if defined(FWG_SPECS_FILE)      /* run-time specialisation (gym_fixed_wing/jit.py): one frozen configuration */
+#include FWG_SPECS_FILE
+#elif defined(FWG_WITH_SPECS)    /* build-time presets */
 #include "generated/specs.inc"
 #else
 #define FWG_SPEC_LIST(X)

@@ -9,6 +9,7 @@ info["terminal_observation"], per-episode metric entries in info at done).
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 
@@ -89,7 +90,7 @@ class LazyInfos(object):
 class FixedWingVecEnv(object):
     def __init__(self, config_path=None, num_envs=1, device=0, sim_config_path=None, sim_parameter_path=None,
                  config_kw=None, sim_config_kw=None, auto_reset=True, as_numpy=False, env_id_base=0, seed=0,
-                 derived_views=True, _backend=None, _lib_path=None):
+                 derived_views=True, specialize=None, _backend=None, _lib_path=None):
         self.env_config = EnvConfig(config_path, sim_config_path, sim_parameter_path, config_kw, sim_config_kw)
         self.cfg = self.env_config.cfg
         self.num_envs = int(num_envs)
@@ -110,6 +111,15 @@ class FixedWingVecEnv(object):
         self.dt = ec.dt
 
         self._c = ec.compile(auto_reset=auto_reset, store_derived=self.derived_views)
+        # configurations outside the build-time presets run the generic kernel unless a specialised copy of the
+        # library is compiled for them (opt-in: specialize=True or FWGYM_JIT=1; see jit.py)
+        if specialize is None:
+            specialize = os.environ.get("FWGYM_JIT", "0") == "1"
+        if specialize and _lib_path is None and not self._preset_matches():
+            from . import jit
+            path = jit.specialised_library(ec, auto_reset=auto_reset, store_derived=self.derived_views, base_lib=self._lib)
+            if path is not None:
+                self._lib = nat.load_library(path)
         self.layout = nat.Layout()
         nat.check(self._lib, self._lib.fwg_get_layout(ctypes.byref(self._c), ctypes.byref(self.layout)))
         N, m = self.num_envs, self._mem
@@ -153,6 +163,26 @@ class FixedWingVecEnv(object):
         examples/train_rl_controller.py:84)."""
         self.env_config.set_curriculum_level(level)
         self._upload()
+
+    def _preset_matches(self):
+        import ctypes as C
+        n = self._lib.fwg_num_specs()
+        if n == 0:
+            return False
+        from . import specialize as sp
+        return sp.spec_words(self._lib, self.env_config, self.auto_reset, self.derived_views) in self._preset_words()
+
+    def _preset_words(self):
+        cache = FixedWingVecEnv.__dict__.get("_preset_cache")
+        if cache is None:
+            import copy
+            from . import presets, specialize as sp
+            cache = []
+            for name, kind, ckw, skw in presets.SPECIALISED:
+                ec = EnvConfig(presets.preset(kind), config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
+                cache.append(sp.spec_words(self._lib, ec, True, not name.endswith("_lean")))
+            FixedWingVecEnv._preset_cache = cache
+        return cache
 
     def set_graph_mode(self, enable=True):
         """Keeps the global step counter on the device so that a captured sequence of step launches (hipGraph /

@@ -143,3 +143,38 @@ def test_success_reduction_matches_infos():
     np.testing.assert_array_equal(red[1:5], succ)
     assert np.all(vec.reduce_success() == 0)
     vec.close()
+
+
+def test_runtime_specialisation_matches_generic_kernel():
+    """A configuration outside the build-time presets: the generic kernel and a run-time specialised build of the same
+    source (gym_fixed_wing/jit.py) give the same trajectories (fp32 contraction order may differ: 1e-5), and the
+    specialised one is the one that runs."""
+    import time
+    import torch
+    cfg = configs.reference_like("examples")
+    ckw = {"steps_max": 1500, "target": {"on_success": "done", "success_streak_fraction": 1, "success_streak_req": 100}}
+    n, steps = 4096, 60
+    acts = np.random.default_rng(3).uniform(-1, 1, size=(steps, n, 3)).astype(np.float32)
+    outs, rates = [], []
+    for spec in (False, True):
+        vec = _vec(cfg, n, config_kw=ckw, seed=2, as_numpy=True, specialize=spec)
+        assert (vec.spec_index >= 0) == spec
+        vec.reset()
+        hist = []
+        for t in range(steps):
+            obs, rew, done, _ = vec.step(acts[t])
+            hist.append((np.array(obs), np.array(rew), np.array(done)))
+        outs.append(hist)
+        dev_acts = torch.as_tensor(acts[0]).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(200):
+            vec.step_device(dev_acts)
+        torch.cuda.synchronize()
+        rates.append((time.perf_counter() - t0) / 200 * 1e6)
+        vec.close()
+    for (o1, r1, d1), (o2, r2, d2) in zip(*outs):
+        np.testing.assert_allclose(o1, o2, rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(r1, r2, rtol=2e-4, atol=2e-4)
+        assert np.array_equal(d1, d2)
+    print("generic {:.1f} us/step, run-time specialised {:.1f} us/step at {} envs".format(rates[0], rates[1], n))
