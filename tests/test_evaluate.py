@@ -87,3 +87,35 @@ def test_pid_baseline_on_shipped_test_set_reports_distance_to_published_results(
     assert table["success_%"]["all"] >= 95.0
     assert report["first_step_reward_max_abs_err"] < 5e-3        # kinematics / error / reward plumbing agree
     assert 0.7 < report["episode_length_ratio_median"] < 1.3
+
+
+@pytest.mark.gpu
+def test_shipped_mlp_controller_flies_the_shipped_test_set():
+    """Drop-in check at system level: the MLP policy the reference ships (trained on real PyFly 0.1.2,
+    examples/models/mlp_controller) controls THIS simulator on the shipped test set through the evaluation protocol.
+    Weights and VecNormalize statistics come from tests/golden/mlp_controller.json (converted data files)."""
+    import torch
+    with open(os.path.join(HERE, "golden", "mlp_controller.json")) as f:
+        m = json.load(f)
+    W = {k: torch.tensor(v, dtype=torch.float32, device="cuda") for k, v in m["weights"].items()}
+    mean = torch.tensor(m["obs_rms"]["mean"], dtype=torch.float32, device="cuda")
+    std = torch.sqrt(torch.tensor(m["obs_rms"]["var"], dtype=torch.float32, device="cuda") + 1e-8)
+
+    def policy(obs):  # VecNormalize (clip 10) + stable-baselines MlpPolicy, deterministic action = mean
+        x = ((obs.reshape(obs.shape[0], -1) - mean) / std).clamp(-10, 10)
+        h = torch.tanh(x @ W["pi_fc0_w"] + W["pi_fc0_b"])
+        h = torch.tanh(h @ W["pi_fc1_w"] + W["pi_fc1_b"])
+        return h @ W["pi_w"] + W["pi_b"]
+
+    cfg = configs.reference_like("mlp")
+    res = ev.evaluate_on_set(_scenarios(), cfg, policy=policy, device=0)
+    table = ev.summarize(res)
+    lengths = np.array([len(r) for r in res["rewards"]])
+    report = {"ours": table, "published_README_RL_MLP_none": {"success_%": 100, "rise_time": [1.395, 0.336, 0.959],
+                                                              "settling_time": [2.085, 1.675, 2.308],
+                                                              "overshoot_%": [5, 25, 20], "control_variation": 0.410},
+              "episode_length_ratio_median": float(np.median(lengths / np.array(m["published_episode_lengths"])))}
+    print(json.dumps(report, indent=1))
+    with open(os.path.join(os.path.dirname(HERE), "gpurun_out", "mlp_eval_report.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    assert table["success_%"]["all"] >= 80.0
