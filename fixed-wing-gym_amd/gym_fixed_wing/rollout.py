@@ -16,10 +16,21 @@ class RunningMeanStd(object):
         self.mean = torch.zeros(shape, dtype=torch.float32, device=device)
         self.var = torch.ones(shape, dtype=torch.float32, device=device)
         self.count = torch.full((), epsilon, dtype=torch.float32, device=device)   # a tensor: graph-capturable
+        self._ones = None
 
     def update(self, x):
-        x = x.reshape(-1, *self.mean.shape)
-        b_mean, b_var, b_count = x.mean(dim=0), x.var(dim=0, unbiased=False), x.shape[0]
+        # Batch moments through a ones-row GEMM on the deviations from the running mean, not Tensor.mean/var: torch's
+        # multi-block dim-0 reductions return garbage from the second replay of a captured hipGraph on this stack
+        # (ROCm 7.x / torch 2.10; found with tests/test_rollout.py, negative running variances), and the centred
+        # form is also the numerically better one in fp32.
+        x = x.reshape(-1, max(1, self.mean.numel()))
+        b_count = x.shape[0]
+        if self._ones is None or self._ones.shape[1] != b_count:
+            self._ones = torch.ones((1, b_count), dtype=torch.float32, device=x.device)
+        d = x - self.mean.reshape(1, -1)
+        s1 = (self._ones @ d).reshape(self.mean.shape) / b_count
+        s2 = (self._ones @ (d * d)).reshape(self.mean.shape) / b_count
+        b_mean, b_var = self.mean + s1, (s2 - s1 * s1).clamp_min(0.0)
         delta = b_mean - self.mean
         tot = self.count + b_count
         m2 = self.var * self.count + b_var * b_count + delta * delta * (self.count * b_count / tot)

@@ -65,5 +65,39 @@ def test_rollout_throughput_on_gpu():
     dt = (time.perf_counter() - t0) / 3
     print("C5 rollout, hipGraph replay: {:.3e} env-steps/s, {:.1f} us/step".format(128 * n / dt, dt / 128 * 1e6))
     assert torch.isfinite(buf["rewards"]).all() and torch.isfinite(buf["obs"]).all()
+    assert float(norm.obs_rms.var.min()) > 0 and torch.isfinite(norm.obs_rms.mean).all()
     steps = vec.get_state(["steps_count"])["steps_count"]
     assert steps.min() >= 0 and steps.max() <= vec.cfg["steps_max"]
+
+
+@pytest.mark.gpu
+def test_running_statistics_survive_graph_replay():
+    """The running mean/variance must come out the same from a replayed hipGraph as from NumPy in float64 (torch's
+    own dim-0 reductions do not on this stack from the second replay on, which is why RunningMeanStd avoids them)."""
+    n, d, k = 65536, 12, 6
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    data = torch.randn((k, n, d), device="cuda", generator=gen) * torch.linspace(0.5, 6.0, d, device="cuda") + 20.0
+    rms = RunningMeanStd((d,), device="cuda")
+    ret = RunningMeanStd((), device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        rms.update(data[0]), ret.update(data[0, :, 0])
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(k):
+            rms.update(data[i])
+            ret.update(data[i, :, 0])
+    replays = 4
+    for _ in range(replays):
+        graph.replay()
+    torch.cuda.synchronize()
+    x = data.double().cpu().numpy()
+    allx = np.concatenate([x[0]] + [x.reshape(-1, d)] * replays)
+    np.testing.assert_allclose(rms.mean.cpu().numpy(), allx.mean(axis=0), rtol=2e-4)
+    np.testing.assert_allclose(rms.var.cpu().numpy(), allx.var(axis=0), rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(float(ret.mean), allx[:, 0].mean(), rtol=2e-4)
+    np.testing.assert_allclose(float(ret.var), allx[:, 0].var(), rtol=2e-3)
