@@ -79,6 +79,9 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     const DevCfg& c = SpecCfg<SPEC>::get(cp);
     const KArgs A = resolve_slots(c, A0);
     if (A0.gstep_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *A0.gstep_out = *A0.gstep_in + 1;
+#ifdef FWG_ABL_EMPTY  // FWG_ABL_*: measurement-only switches (tools/ablate.py), never defined in the product build
+    return;
+#endif
     const DynCfg& dc = *dp;
     const int lane = threadIdx.x;
     const long env0 = (long)blockIdx.x * FWG_WAVE;
@@ -126,8 +129,15 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.act_ring >> 2) + s, e), lds + M.aring + s * (4 * FWG_WAVE));
     if (c.use_cmd_ring)
         for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
+#ifndef FWG_ABL_NO_LAG
     stream_lag_rows(c, A, e, lds + M.lag);
+#endif
+#ifdef FWG_ABL_NO_SIM
+    const int fail = 0;
+    E.d = derive<TURB>(E.y, E.wind, gust);
+#else
     const int fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
+#endif
     const bool ok = fail == 0;
     if (!ok) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
     if (TURB && ok) {
@@ -136,7 +146,9 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         box_muller(b, n);
         dryden_advance(c, E.dry, n);
     }
+#ifndef FWG_ABL_NO_SIMSTORE
     if (valid) store_sim<TURB>(c, A.S, A.N, e, E);
+#endif
     // everything streamed HBM -> LDS at kernel start is needed from here on; the integration above hid its latency
     dma_wait();
 #pragma unroll
@@ -289,10 +301,14 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         }
     }
 
+#ifndef FWG_ABL_NO_GYMSTORE
     if (valid) store_gym(c, A.S, A.N, e, E, A.bit_goal);
+#endif
 
     // ---- phase D: observation (fixed_wing.py:776-846)
+#ifndef FWG_ABL_NO_LAG
     load_lag_rows(c, lds + M.lag + lane * 4, ob);
+#endif
     build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid, A.slot_act);
     if (c.obs_length > 1 && (!ok || (int)E.steps <= (c.obs_length - 1) * c.obs_step))
         fix_lagged_rows(c, A, e, E, T, ob, ok);
@@ -379,7 +395,11 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     }
 
     // ---- phase F: outputs and the state write-back
+#ifndef FWG_ABL_NO_OBSWRITE
     write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull);
+#else
+    if (ob.get(0) == 1.2345e30f) A.obs[e] = ob.get(1) + ob.get(c.obs_dim - 1);
+#endif
     if (valid) {
         A.rew[e] = reward;
         A.done[e] = done ? 1 : 0;
@@ -887,3 +907,182 @@ static void launch(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
     if (h->h.turbulence) launch_one<IS_STEP, true, -1>(h, A, stream);
     else launch_one<IS_STEP, false, -1>(h, A, stream);
 }
+
+// =====================================================================================================================
+// rollout head (include/fwgym.h "Rollout head"): VecNormalize statistics + MlpPolicy on the matrix cores
+// =====================================================================================================================
+#include <vector>
+#include "fwgym_actor.h"
+
+struct fwg_actor {
+    int device;
+    int64_t n_envs, env_base;
+    int D, act_dim, nk1;
+    float gamma, clip_obs, clip_rew, eps;
+    int training, precise, parity;
+    uint64_t seed;
+    ActorStats* d_stats;   // [2]
+    ActorAcc* d_acc;       // [2]
+    frag_t* d_frags;
+    float* d_log_std;
+    float* d_ret;
+    size_t lds_act[2];     // dynamic LDS of k_actor_act<1>, <3>
+};
+
+static size_t actor_lds_bytes(int nk1, int parts) {
+    return (size_t)2 * parts * actor_frags(nk1) * 64 * sizeof(frag_t) + (2 * FWG_ACT_MAX_OBS + 4) * sizeof(float);
+}
+
+static ActorArgs actor_args(const fwg_actor* a) {
+    ActorArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ret = a->d_ret; A.stats = a->d_stats; A.acc = a->d_acc; A.frags = a->d_frags; A.log_std = a->d_log_std;
+    A.N = (long)a->n_envs; A.env_base = (long)a->env_base;
+    A.D = a->D; A.nk1 = a->nk1; A.act_dim = a->act_dim; A.parity = a->parity; A.training = a->training;
+    A.gamma = a->gamma; A.clip_obs = a->clip_obs; A.clip_rew = a->clip_rew; A.eps = a->eps;
+    A.seed_lo = (unsigned)(a->seed & 0xFFFFFFFFull); A.seed_hi = (unsigned)(a->seed >> 32);
+    return A;
+}
+
+extern "C" {
+
+int fwg_actor_create(int device, int64_t n_envs, int obs_dim, int act_dim, float gamma, float clip_obs, float clip_reward,
+                     float epsilon, fwg_actor** out) {
+    if (!out) return fail_with(FWG_ERR_INVALID, "fwg_actor_create: null argument");
+    if (n_envs < 1) return fail_with(FWG_ERR_INVALID, "fwg_actor_create: n_envs < 1");
+    if (obs_dim < 1 || obs_dim > FWG_ACT_MAX_OBS) return fail_with(FWG_ERR_INVALID, "fwg_actor_create: obs_dim must be in [1, 64]");
+    if (act_dim < 1 || act_dim > FWG_ACT_MAX_ACT) return fail_with(FWG_ERR_INVALID, "fwg_actor_create: act_dim must be in [1, 4]");
+    HIP_TRY(hipSetDevice(device));
+    fwg_actor* a = new fwg_actor();
+    memset(a, 0, sizeof(*a));
+    a->device = device; a->n_envs = n_envs; a->D = obs_dim; a->act_dim = act_dim; a->nk1 = (obs_dim + 15) / 16;
+    a->gamma = gamma; a->clip_obs = clip_obs; a->clip_rew = clip_reward; a->eps = epsilon;
+    a->training = 1; a->precise = 1;
+    const size_t nfrag = (size_t)2 * 2 * actor_frags(a->nk1) * 64;
+    HIP_TRY(hipMalloc((void**)&a->d_stats, 2 * sizeof(ActorStats)));
+    HIP_TRY(hipMalloc((void**)&a->d_acc, 2 * sizeof(ActorAcc)));
+    HIP_TRY(hipMalloc((void**)&a->d_frags, nfrag * sizeof(frag_t)));
+    HIP_TRY(hipMalloc((void**)&a->d_log_std, FWG_ACT_MAX_ACT * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&a->d_ret, (size_t)n_envs * sizeof(float)));
+    HIP_TRY(hipMemset(a->d_acc, 0, 2 * sizeof(ActorAcc)));
+    HIP_TRY(hipMemset(a->d_frags, 0, nfrag * sizeof(frag_t)));
+    HIP_TRY(hipMemset(a->d_log_std, 0, FWG_ACT_MAX_ACT * sizeof(float)));
+    HIP_TRY(hipMemset(a->d_ret, 0, (size_t)n_envs * sizeof(float)));
+    ActorStats s[2];
+    memset(s, 0, sizeof(s));
+    for (int p = 0; p < 2; ++p) {   // RunningMeanStd(epsilon=1e-4): mean 0, var 1, count 1e-4
+        for (int f = 0; f < FWG_ACT_MAX_OBS; ++f) s[p].var[f] = 1.f;
+        s[p].count = 1e-4f; s[p].ret_var = 1.f; s[p].ret_count = 1e-4f;
+    }
+    HIP_TRY(hipMemcpy(a->d_stats, s, sizeof(s), hipMemcpyHostToDevice));
+    a->lds_act[0] = actor_lds_bytes(a->nk1, 1);
+    a->lds_act[1] = actor_lds_bytes(a->nk1, 2);
+    // more than 64 KiB of dynamic LDS per workgroup has to be asked for (gfx950: 160 KiB per CU)
+    HIP_TRY(hipFuncSetAttribute((const void*)k_actor_act<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds_act[0]));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_actor_act<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds_act[1]));
+    *out = a;
+    return FWG_OK;
+}
+
+void fwg_actor_destroy(fwg_actor* a) {
+    if (!a) return;
+    (void)hipFree(a->d_stats); (void)hipFree(a->d_acc); (void)hipFree(a->d_frags); (void)hipFree(a->d_log_std); (void)hipFree(a->d_ret);
+    delete a;
+}
+
+int fwg_actor_set_weights(fwg_actor* a, const fwg_actor_weights* w) {
+    if (!a || !w) return fail_with(FWG_ERR_INVALID, "fwg_actor_set_weights: null argument");
+    const float* const need[] = {w->pi_w0, w->pi_b0, w->pi_w1, w->pi_b1, w->pi_w2, w->pi_b2,
+                                 w->vf_w0, w->vf_b0, w->vf_w1, w->vf_b1, w->vf_w2, w->vf_b2, w->log_std};
+    for (const float* p : need) if (!p) return fail_with(FWG_ERR_INVALID, "fwg_actor_set_weights: null weight array");
+    HIP_TRY(hipSetDevice(a->device));
+    std::vector<unsigned> all;
+    for (int net = 0; net < 2; ++net) {
+        std::vector<unsigned> hi, lo;
+        const float* w0 = net ? w->vf_w0 : w->pi_w0; const float* b0 = net ? w->vf_b0 : w->pi_b0;
+        const float* w1 = net ? w->vf_w1 : w->pi_w1; const float* b1 = net ? w->vf_b1 : w->pi_b1;
+        const float* w2 = net ? w->vf_w2 : w->pi_w2; const float* b2 = net ? w->vf_b2 : w->pi_b2;
+        const int out = net ? 1 : a->act_dim;
+        actor_pack_layer(hi, lo, w0, b0, 64, a->D, 2, a->nk1, false);
+        actor_pack_layer(hi, lo, w1, b1, 64, 64, 2, 4, true);
+        actor_pack_layer(hi, lo, w2, b2, out, 64, 1, 4, true);
+        all.insert(all.end(), hi.begin(), hi.end());
+        all.insert(all.end(), lo.begin(), lo.end());
+    }
+    const size_t want = (size_t)2 * 2 * actor_frags(a->nk1) * 64 * 4;
+    if (all.size() != want) return fail_with(FWG_ERR_INVALID, "fwg_actor_set_weights: internal packing size mismatch");
+    HIP_TRY(hipMemcpy(a->d_frags, all.data(), all.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    float ls[FWG_ACT_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < a->act_dim; ++i) ls[i] = w->log_std[i];
+    HIP_TRY(hipMemcpy(a->d_log_std, ls, sizeof(ls), hipMemcpyHostToDevice));
+    return FWG_OK;
+}
+
+int fwg_actor_set_stats(fwg_actor* a, const fwg_actor_stats* s, void* stream) {
+    if (!a || !s) return fail_with(FWG_ERR_INVALID, "fwg_actor_set_stats: null argument");
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    ActorStats cur;
+    HIP_TRY(hipMemcpy(&cur, a->d_stats + a->parity, sizeof(cur), hipMemcpyDeviceToHost));
+    memcpy(cur.mean, s->obs_mean, sizeof(cur.mean));
+    memcpy(cur.var, s->obs_var, sizeof(cur.var));
+    cur.count = s->obs_count; cur.ret_mean = s->ret_mean; cur.ret_var = s->ret_var; cur.ret_count = s->ret_count;
+    HIP_TRY(hipMemcpy(a->d_stats + a->parity, &cur, sizeof(cur), hipMemcpyHostToDevice));
+    return FWG_OK;
+}
+
+int fwg_actor_get_stats(fwg_actor* a, fwg_actor_stats* s, void* stream) {
+    if (!a || !s) return fail_with(FWG_ERR_INVALID, "fwg_actor_get_stats: null argument");
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    ActorStats cur;
+    HIP_TRY(hipMemcpy(&cur, a->d_stats + a->parity, sizeof(cur), hipMemcpyDeviceToHost));
+    memcpy(s->obs_mean, cur.mean, sizeof(cur.mean));
+    memcpy(s->obs_var, cur.var, sizeof(cur.var));
+    s->obs_count = cur.count; s->ret_mean = cur.ret_mean; s->ret_var = cur.ret_var; s->ret_count = cur.ret_count;
+    return FWG_OK;
+}
+
+int fwg_actor_configure(fwg_actor* a, int training, int precise) {
+    if (!a) return fail_with(FWG_ERR_INVALID, "fwg_actor_configure: null handle");
+    a->training = training ? 1 : 0;
+    a->precise = precise ? 1 : 0;
+    return FWG_OK;
+}
+
+int fwg_actor_seed(fwg_actor* a, uint64_t seed, int64_t env_id_base) {
+    if (!a) return fail_with(FWG_ERR_INVALID, "fwg_actor_seed: null handle");
+    a->seed = seed; a->env_base = env_id_base;
+    return FWG_OK;
+}
+
+int fwg_actor_observe(fwg_actor* a, const float* obs, const float* reward, const uint8_t* done, void* stream) {
+    if (!a) return fail_with(FWG_ERR_INVALID, "fwg_actor_observe: null handle");
+    if (!obs && !reward) return FWG_OK;
+    HIP_TRY(hipSetDevice(a->device));
+    ActorArgs A = actor_args(a);
+    A.obs = obs; A.rew = reward; A.done = done;
+    const dim3 grid((unsigned)((a->n_envs + FWG_ACT_BLOCK - 1) / FWG_ACT_BLOCK)), block(FWG_ACT_BLOCK);
+    hipLaunchKernelGGL(k_actor_stats, grid, block, FWG_ACT_NACC * sizeof(float), (hipStream_t)stream, A);
+    HIP_TRY(hipGetLastError());
+    return FWG_OK;
+}
+
+int fwg_actor_act(fwg_actor* a, const float* obs, const float* reward, const uint8_t* done, float* norm_obs_out,
+                  float* action_out, float* value_out, float* logp_out, float* norm_reward_out, uint8_t* done_out,
+                  int deterministic, void* stream) {
+    if (!a || !obs) return fail_with(FWG_ERR_INVALID, "fwg_actor_act: null argument");
+    HIP_TRY(hipSetDevice(a->device));
+    ActorArgs A = actor_args(a);
+    A.obs = obs; A.rew = reward; A.done = done;
+    A.norm_obs = norm_obs_out; A.action = action_out; A.value = value_out; A.logp = logp_out; A.norm_rew = norm_reward_out;
+    A.done_out = done_out; A.deterministic = deterministic ? 1 : 0;
+    const dim3 grid((unsigned)((a->n_envs + FWG_ACT_BLOCK - 1) / FWG_ACT_BLOCK)), block(FWG_ACT_BLOCK);
+    if (a->precise) hipLaunchKernelGGL(k_actor_act<3>, grid, block, a->lds_act[1], (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(k_actor_act<1>, grid, block, a->lds_act[0], (hipStream_t)stream, A);
+    HIP_TRY(hipGetLastError());
+    a->parity ^= 1;
+    return FWG_OK;
+}
+
+}  // extern "C"

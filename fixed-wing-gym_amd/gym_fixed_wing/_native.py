@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 8
+FWG_ABI_VERSION = 9
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -118,6 +118,19 @@ class Layout(C.Structure):
                  "window", "lag_depth", "lag_groups"]]
 
 
+class ActorWeights(C.Structure):
+    """fwg_actor_weights: float32 host arrays in torch.nn.Linear layout."""
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in
+                ["pi_w0", "pi_b0", "pi_w1", "pi_b1", "pi_w2", "pi_b2", "vf_w0", "vf_b0", "vf_w1", "vf_b1", "vf_w2", "vf_b2",
+                 "log_std"]]
+
+
+class ActorStats(C.Structure):
+    """fwg_actor_stats: VecNormalize's obs_rms / ret_rms."""
+    _fields_ = [("obs_mean", C.c_float * 64), ("obs_var", C.c_float * 64), ("obs_count", C.c_float),
+                ("ret_mean", C.c_float), ("ret_var", C.c_float), ("ret_count", C.c_float)]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -127,7 +140,9 @@ DEFAULT_LIB = os.path.join(_HERE, "libfwgym.so")
 EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fwg_update_config", "fwg_seed",
            "fwg_reset", "fwg_step", "fwg_check_actions", "fwg_reduce_success", "fwg_global_step", "fwg_last_error",
            "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index", "fwg_set_graph_mode", "fwg_note_replayed_steps",
-           "fwg_capture_begin", "fwg_capture_end"]
+           "fwg_capture_begin", "fwg_capture_end", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
+           "fwg_actor_set_stats", "fwg_actor_get_stats", "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe",
+           "fwg_actor_act"]
 _libs = {}
 
 
@@ -177,6 +192,20 @@ def load_library(path=None):
     lib.fwg_capture_begin.restype = C.c_int
     lib.fwg_capture_end.argtypes = [vp]
     lib.fwg_capture_end.restype = C.c_int
+    f32 = C.c_float
+    lib.fwg_actor_create.argtypes = [C.c_int, i64, C.c_int, C.c_int, f32, f32, f32, f32, C.POINTER(vp)]
+    lib.fwg_actor_destroy.argtypes = [vp]
+    lib.fwg_actor_destroy.restype = None
+    lib.fwg_actor_set_weights.argtypes = [vp, C.POINTER(ActorWeights)]
+    lib.fwg_actor_set_stats.argtypes = [vp, C.POINTER(ActorStats), vp]
+    lib.fwg_actor_get_stats.argtypes = [vp, C.POINTER(ActorStats), vp]
+    lib.fwg_actor_configure.argtypes = [vp, C.c_int, C.c_int]
+    lib.fwg_actor_seed.argtypes = [vp, u64, i64]
+    lib.fwg_actor_observe.argtypes = [vp, vp, vp, vp, vp]
+    lib.fwg_actor_act.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
+    for name in ("fwg_actor_create", "fwg_actor_set_weights", "fwg_actor_set_stats", "fwg_actor_get_stats",
+                 "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe", "fwg_actor_act"):
+        getattr(lib, name).restype = C.c_int
     for name in ("fwg_get_layout", "fwg_create", "fwg_destroy", "fwg_update_config", "fwg_seed", "fwg_reset",
                  "fwg_step", "fwg_check_actions", "fwg_reduce_success"):
         getattr(lib, name).restype = C.c_int

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 8
+#define FWG_ABI_VERSION 9
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -287,6 +287,57 @@ int fwg_set_graph_mode(fwg_handle* h, int enable, void* stream);
 int fwg_capture_begin(fwg_handle* h);   /* bracket the fwg_step calls issued under stream capture (they do not execute) */
 int fwg_capture_end(fwg_handle* h);
 int fwg_note_replayed_steps(fwg_handle* h, int64_t n_steps);
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Rollout head ("actor"): what sits between two env steps in the reference's training/evaluation loops --
+ * VecNormalize (running observation / return normalisation) around the env and the stable-baselines MlpPolicy
+ * (pi and vf: obs -> 64 tanh -> 64 tanh -> act_dim / 1, state-independent log-std) acting on the normalised
+ * observation (examples/train_rl_controller.py:223-231, examples/evaluate_controller.py:93-100) -- as two HIP kernels
+ * on device-resident batches, so that one rollout step is three launches (fwg_step, fwg_actor_observe, fwg_actor_act).
+ * The MLP runs on the matrix cores (bf16 MFMA, each fp32 operand split into bf16 hi + lo: three products per tile,
+ * error ~1e-5 of the fp32 result), weights resident in LDS.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct fwg_actor fwg_actor;
+
+/* Row-major float32 host arrays in torch.nn.Linear layout (weight [out][in], bias [out]); hidden width is 64. */
+typedef struct fwg_actor_weights {
+    const float *pi_w0, *pi_b0, *pi_w1, *pi_b1, *pi_w2, *pi_b2;   /* [64][obs_dim],[64],[64][64],[64],[act_dim][64],[act_dim] */
+    const float *vf_w0, *vf_b0, *vf_w1, *vf_b1, *vf_w2, *vf_b2;   /* ... [1][64],[1] */
+    const float *log_std;                                          /* [act_dim] */
+} fwg_actor_weights;
+
+/* Running statistics as VecNormalize keeps them (obs_rms, ret_rms). */
+typedef struct fwg_actor_stats {
+    float obs_mean[64], obs_var[64];
+    float obs_count, ret_mean, ret_var, ret_count;
+} fwg_actor_stats;
+
+/* obs_dim <= 64 (a matrix observation is taken flattened), act_dim <= 4.  gamma/clip/epsilon: VecNormalize arguments
+ * (defaults of the reference's scripts: 0.99, 10, 10, 1e-8). */
+int fwg_actor_create(int device, int64_t n_envs, int obs_dim, int act_dim, float gamma, float clip_obs,
+                     float clip_reward, float epsilon, fwg_actor** out);
+void fwg_actor_destroy(fwg_actor* a);
+int fwg_actor_set_weights(fwg_actor* a, const fwg_actor_weights* w_host);
+int fwg_actor_set_stats(fwg_actor* a, const fwg_actor_stats* s_host, void* stream);
+int fwg_actor_get_stats(fwg_actor* a, fwg_actor_stats* s_host, void* stream);   /* synchronises the stream */
+/* training != 0: fwg_actor_act folds the batches seen by fwg_actor_observe into the running statistics (VecNormalize
+ * training mode); 0: statistics frozen (evaluation).  precise != 0 (default): split-bf16 products; 0: plain bf16. */
+int fwg_actor_configure(fwg_actor* a, int training, int precise);
+/* Sampling noise: Philox stream (seed, env_id_base + env, act counter). */
+int fwg_actor_seed(fwg_actor* a, uint64_t seed, int64_t env_id_base);
+/* Accumulates the batch moments of `obs` ([N][obs_dim]) and, when `reward` is not NULL, advances the discounted
+ * returns (ret = ret * gamma + reward, zeroed where `done`) and accumulates their moments (VecNormalize.step_wait). */
+int fwg_actor_observe(fwg_actor* a, const float* obs, const float* reward, const uint8_t* done, void* stream);
+/* Folds the accumulated moments into the running statistics (training mode), normalises `obs`, evaluates pi and vf,
+ * samples the action (or takes the mean when deterministic != 0).  Outputs (each may be NULL):
+ *   norm_obs_out [N][obs_dim], action_out [N][act_dim], value_out [N], logp_out [N],
+ *   norm_reward_out [N] = clip(reward / sqrt(ret_var + eps)) for the `reward` given (the transition that led here),
+ *   done_out [N] = copy of `done` (so that a rollout buffer is filled without extra copy launches).
+ * Launches under stream capture must come in EVEN numbers per graph (the statistics are double-buffered by parity). */
+int fwg_actor_act(fwg_actor* a, const float* obs, const float* reward, const uint8_t* done, float* norm_obs_out,
+                  float* action_out, float* value_out, float* logp_out, float* norm_reward_out, uint8_t* done_out,
+                  int deterministic, void* stream);
 
 /* Global step counter driving the ring slots (diagnostics/tests). */
 int64_t fwg_global_step(const fwg_handle* h);

@@ -24,6 +24,7 @@
 #define ext_vector_type(n) vector_size(4 * (n))
 #define __shared__
 #define FWG_DMA_DRAIN() ((void)0)
+#define FWG_EMU 1
 
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
@@ -45,6 +46,8 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
 
 // ---- block-wide lock-step primitives: the 64 lanes of a workgroup are fibers (ucontext) of ONE thread; a lane runs
 // until it reaches a barrier (or returns), then the next lane runs; a full round-robin pass = one barrier phase ----
@@ -53,7 +56,7 @@ static emu_lane emu_lanes[1024];
 static ucontext_t emu_sched_ctx;
 static unsigned emu_cur = 0;
 static uint32_t emu_xchg[1024];
-alignas(16) float lds[64 * 1024 / 4];  // the block's dynamic LDS (`extern __shared__ float lds[]` in the kernels)
+alignas(16) float lds[160 * 1024 / 4];  // the block's dynamic LDS (`extern __shared__ float lds[]` in the kernels)
 static emu_idx emu_block_idx, emu_block_dim;
 
 static inline void __syncthreads() {
@@ -97,6 +100,29 @@ static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4);
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 using std::max;
 using std::min;
+
+// v_mfma_f32_32x32x16_bf16 for the 64-lane wave the calling lane belongs to: lane l supplies A[l & 31][8 (l >> 5) + t]
+// and B[8 (l >> 5) + t][l & 31], t = 0..7 (bf16), and receives D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31], r = 0..15
+static unsigned short emu_mfma_a[1024][8], emu_mfma_b[1024][8];
+static inline float emu_bf16(unsigned short h) { const unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+template <class FRAG, class ACC>
+static inline ACC emu_mfma_f32_32x32x16_bf16(const FRAG& a, const FRAG& b, ACC c) {
+    static_assert(sizeof(FRAG) == 16, "operand = 8 bf16");
+    const unsigned tid = threadIdx.x;
+    memcpy(emu_mfma_a[tid], &a, 16);
+    memcpy(emu_mfma_b[tid], &b, 16);
+    __syncthreads();
+    const unsigned w0 = tid & ~63u, l = tid & 63u, j = l & 31u, half = l >> 5;
+    for (unsigned r = 0; r < 16; ++r) {
+        const unsigned i = (r & 3u) + 8u * (r >> 2) + 4u * half;
+        float s = 0.f;
+        for (unsigned k = 0; k < 16; ++k)
+            s += emu_bf16(emu_mfma_a[w0 + i + 32u * (k >> 3)][k & 7u]) * emu_bf16(emu_mfma_b[w0 + j + 32u * (k >> 3)][k & 7u]);
+        c[r] += s;
+    }
+    __syncthreads();
+    return c;
+}
 
 static std::function<void()> emu_body;
 static void emu_trampoline() {
