@@ -17,11 +17,7 @@
 #include <string>
 #include "fwgym_env.h"
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, FWG_WAVE);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum64(v); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Specialisation.  The static configuration of an environment (DevCfg: observation layout, reward factors, aircraft
@@ -410,6 +406,33 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
                 if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
         }
     }
+#ifndef FWG_ABL_NO_ACC
+    if (A.acc != nullptr) {   // attached rollout head: this wave's batch moments (wave-uniform branch)
+        const int D = c.obs_dim;
+        // VecNormalize.step_wait: ret = ret * gamma + r; ret_rms.update(ret); ret[done] = 0
+        float dr = 0.f;
+        if (valid) {
+            const float r = A.acc_ret[e] * A.acc_gamma + reward;
+            A.acc_ret[e] = done ? 0.f : r;
+            dr = r - *A.acc_ret_mean;
+        }
+#define FWG_OBS_AT(k) ob.get(k)
+#pragma unroll
+        for (int chunk = 0; chunk < (2 * FWG_MAX_OBS * FWG_MAX_ROWS + 4 + 31) / 32; ++chunk) {
+            if (32 * chunk < 2 * D + 4) {
+                float v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = FWG_ACC_COLUMN(32 * chunk + i, D, valid, FWG_OBS_AT, A.acc_mean, dr, true, true);
+#ifdef FWG_ABL_NO_TOTALS
+                acc_flush(A.acc, A.acc_cols, blockIdx.x & (FWG_ACC_SHARDS - 1), chunk, lane, v[0] + v[7] + v[13] + v[27]);
+#else
+                acc_flush(A.acc, A.acc_cols, blockIdx.x & (FWG_ACC_SHARDS - 1), chunk, lane, wave_totals32(v, lane));
+#endif
+            }
+        }
+#undef FWG_OBS_AT
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -485,6 +508,7 @@ struct fwg_handle {
     int64_t gstep_at_capture;
     long long* d_gstep;
     size_t lds_bytes;
+    struct fwg_actor* observer;   // attached rollout head (fwg_attach_observer) or null
 };
 
 static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) {
@@ -783,6 +807,8 @@ static void base_args(const fwg_handle* h, KArgs* A) {
     A->seed_lo = (unsigned)(h->seed & 0xFFFFFFFFull); A->seed_hi = (unsigned)(h->seed >> 32);
 }
 
+static void observer_args(fwg_handle* h, KArgs* A);   // defined with the rollout head below
+
 int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const float* init_target, float* obs_out, void* stream) {
     if (!h || !obs_out) return fail_with(FWG_ERR_INVALID, "null argument");
     KArgs A;
@@ -804,6 +830,7 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
     A.term_obs = terminal_obs_out; A.metrics = metrics_out; A.tgt_out = target_out;
     fill_slots(h, h->gstep, &A);
     if (h->graph_mode) { A.gstep_in = h->d_gstep + (h->gstep & 1); A.gstep_out = h->d_gstep + ((h->gstep + 1) & 1); }
+    observer_args(h, &A);
     launch<true>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     h->gstep += 1;
@@ -922,7 +949,8 @@ struct fwg_actor {
     int training, precise, parity;
     uint64_t seed;
     ActorStats* d_stats;   // [2]
-    ActorAcc* d_acc;       // [2]
+    unsigned long long* d_acc;   // [parity 2][FWG_ACC_SHARDS][acc_cols] fixed-point batch moments
+    int acc_cols;
     frag_t* d_frags;
     float* d_log_std;
     float* d_ret;
@@ -930,13 +958,15 @@ struct fwg_actor {
 };
 
 static size_t actor_lds_bytes(int nk1, int parts) {
-    return (size_t)2 * parts * actor_frags(nk1) * 64 * sizeof(frag_t) + (2 * FWG_ACT_MAX_OBS + 4) * sizeof(float);
+    return (size_t)2 * parts * actor_frags(nk1) * 64 * sizeof(frag_t) +
+           (2 * FWG_ACT_MAX_OBS + 4 + 2 * FWG_ACT_MAX_OBS + 4) * sizeof(float);
 }
 
 static ActorArgs actor_args(const fwg_actor* a) {
     ActorArgs A;
     memset(&A, 0, sizeof(A));
-    A.ret = a->d_ret; A.stats = a->d_stats; A.acc = a->d_acc; A.frags = a->d_frags; A.log_std = a->d_log_std;
+    A.ret = a->d_ret; A.stats = a->d_stats; A.frags = a->d_frags; A.log_std = a->d_log_std;
+    A.acc = a->d_acc; A.acc_cols = a->acc_cols;
     A.N = (long)a->n_envs; A.env_base = (long)a->env_base;
     A.D = a->D; A.nk1 = a->nk1; A.act_dim = a->act_dim; A.parity = a->parity; A.training = a->training;
     A.gamma = a->gamma; A.clip_obs = a->clip_obs; A.clip_rew = a->clip_rew; A.eps = a->eps;
@@ -944,7 +974,23 @@ static ActorArgs actor_args(const fwg_actor* a) {
     return A;
 }
 
+static void observer_args(fwg_handle* h, KArgs* A) {
+    fwg_actor* a = h->observer;
+    if (!a) return;
+    A->acc = a->d_acc + (size_t)a->parity * FWG_ACC_SHARDS * a->acc_cols;
+    A->acc_mean = a->d_stats[a->parity].mean; A->acc_ret_mean = &a->d_stats[a->parity].ret_mean;
+    A->acc_ret = a->d_ret; A->acc_gamma = a->gamma; A->acc_cols = a->acc_cols;
+}
+
 extern "C" {
+
+int fwg_attach_observer(fwg_handle* h, fwg_actor* a) {
+    if (!h) return fail_with(FWG_ERR_INVALID, "fwg_attach_observer: null env handle");
+    if (a && (a->n_envs != h->n_envs || a->D != h->h.obs_dim || a->device != h->device))
+        return fail_with(FWG_ERR_INVALID, "fwg_attach_observer: the head was created for another batch size / observation size / device");
+    h->observer = a;
+    return FWG_OK;
+}
 
 int fwg_actor_create(int device, int64_t n_envs, int obs_dim, int act_dim, float gamma, float clip_obs, float clip_reward,
                      float epsilon, fwg_actor** out) {
@@ -960,11 +1006,13 @@ int fwg_actor_create(int device, int64_t n_envs, int obs_dim, int act_dim, float
     a->training = 1; a->precise = 1;
     const size_t nfrag = (size_t)2 * 2 * actor_frags(a->nk1) * 64;
     HIP_TRY(hipMalloc((void**)&a->d_stats, 2 * sizeof(ActorStats)));
-    HIP_TRY(hipMalloc((void**)&a->d_acc, 2 * sizeof(ActorAcc)));
+    a->acc_cols = acc_cols_for(obs_dim);
+    const size_t acc_bytes = (size_t)2 * FWG_ACC_SHARDS * a->acc_cols * sizeof(unsigned long long);
+    HIP_TRY(hipMalloc((void**)&a->d_acc, acc_bytes));
+    HIP_TRY(hipMemset(a->d_acc, 0, acc_bytes));
     HIP_TRY(hipMalloc((void**)&a->d_frags, nfrag * sizeof(frag_t)));
     HIP_TRY(hipMalloc((void**)&a->d_log_std, FWG_ACT_MAX_ACT * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&a->d_ret, (size_t)n_envs * sizeof(float)));
-    HIP_TRY(hipMemset(a->d_acc, 0, 2 * sizeof(ActorAcc)));
     HIP_TRY(hipMemset(a->d_frags, 0, nfrag * sizeof(frag_t)));
     HIP_TRY(hipMemset(a->d_log_std, 0, FWG_ACT_MAX_ACT * sizeof(float)));
     HIP_TRY(hipMemset(a->d_ret, 0, (size_t)n_envs * sizeof(float)));
@@ -978,8 +1026,12 @@ int fwg_actor_create(int device, int64_t n_envs, int obs_dim, int act_dim, float
     a->lds_act[0] = actor_lds_bytes(a->nk1, 1);
     a->lds_act[1] = actor_lds_bytes(a->nk1, 2);
     // more than 64 KiB of dynamic LDS per workgroup has to be asked for (gfx950: 160 KiB per CU)
-    HIP_TRY(hipFuncSetAttribute((const void*)k_actor_act<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds_act[0]));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_actor_act<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds_act[1]));
+    {
+        const void* k1[4] = {(const void*)k_actor_act<1, 1>, (const void*)k_actor_act<1, 2>, (const void*)k_actor_act<1, 3>, (const void*)k_actor_act<1, 4>};
+        const void* k3[4] = {(const void*)k_actor_act<3, 1>, (const void*)k_actor_act<3, 2>, (const void*)k_actor_act<3, 3>, (const void*)k_actor_act<3, 4>};
+        HIP_TRY(hipFuncSetAttribute(k1[a->nk1 - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds_act[0]));
+        HIP_TRY(hipFuncSetAttribute(k3[a->nk1 - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds_act[1]));
+    }
     *out = a;
     return FWG_OK;
 }
@@ -1003,9 +1055,9 @@ int fwg_actor_set_weights(fwg_actor* a, const fwg_actor_weights* w) {
         const float* w1 = net ? w->vf_w1 : w->pi_w1; const float* b1 = net ? w->vf_b1 : w->pi_b1;
         const float* w2 = net ? w->vf_w2 : w->pi_w2; const float* b2 = net ? w->vf_b2 : w->pi_b2;
         const int out = net ? 1 : a->act_dim;
-        actor_pack_layer(hi, lo, w0, b0, 64, a->D, 2, a->nk1, false);
-        actor_pack_layer(hi, lo, w1, b1, 64, 64, 2, 4, true);
-        actor_pack_layer(hi, lo, w2, b2, out, 64, 1, 4, true);
+        actor_pack_layer(hi, lo, w0, b0, 64, a->D, 2, a->nk1, false, FWG_ACT_PRESCALE);
+        actor_pack_layer(hi, lo, w1, b1, 64, 64, 2, 4, true, FWG_ACT_PRESCALE);
+        actor_pack_layer(hi, lo, w2, b2, out, 64, 1, 4, true, 1.f);
         all.insert(all.end(), hi.begin(), hi.end());
         all.insert(all.end(), lo.begin(), lo.end());
     }
@@ -1063,7 +1115,7 @@ int fwg_actor_observe(fwg_actor* a, const float* obs, const float* reward, const
     ActorArgs A = actor_args(a);
     A.obs = obs; A.rew = reward; A.done = done;
     const dim3 grid((unsigned)((a->n_envs + FWG_ACT_BLOCK - 1) / FWG_ACT_BLOCK)), block(FWG_ACT_BLOCK);
-    hipLaunchKernelGGL(k_actor_stats, grid, block, FWG_ACT_NACC * sizeof(float), (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_actor_stats, grid, block, 0, (hipStream_t)stream, A);
     HIP_TRY(hipGetLastError());
     return FWG_OK;
 }
@@ -1077,9 +1129,15 @@ int fwg_actor_act(fwg_actor* a, const float* obs, const float* reward, const uin
     A.obs = obs; A.rew = reward; A.done = done;
     A.norm_obs = norm_obs_out; A.action = action_out; A.value = value_out; A.logp = logp_out; A.norm_rew = norm_reward_out;
     A.done_out = done_out; A.deterministic = deterministic ? 1 : 0;
-    const dim3 grid((unsigned)((a->n_envs + FWG_ACT_BLOCK - 1) / FWG_ACT_BLOCK)), block(FWG_ACT_BLOCK);
-    if (a->precise) hipLaunchKernelGGL(k_actor_act<3>, grid, block, a->lds_act[1], (hipStream_t)stream, A);
-    else hipLaunchKernelGGL(k_actor_act<1>, grid, block, a->lds_act[0], (hipStream_t)stream, A);
+    const dim3 grid((unsigned)((a->n_envs + FWG_ACT_ENVS - 1) / FWG_ACT_ENVS)), block(64 * FWG_ACT_WAVES);
+    hipStream_t st = (hipStream_t)stream;
+#define FWG_ACT_LAUNCH(NK)                                                                                \
+    case NK:                                                                                              \
+        if (a->precise) hipLaunchKernelGGL((k_actor_act<3, NK>), grid, block, a->lds_act[1], st, A);     \
+        else hipLaunchKernelGGL((k_actor_act<1, NK>), grid, block, a->lds_act[0], st, A);                \
+        break;
+    switch (a->nk1) { FWG_ACT_LAUNCH(1) FWG_ACT_LAUNCH(2) FWG_ACT_LAUNCH(3) FWG_ACT_LAUNCH(4) default: break; }
+#undef FWG_ACT_LAUNCH
     HIP_TRY(hipGetLastError());
     a->parity ^= 1;
     return FWG_OK;

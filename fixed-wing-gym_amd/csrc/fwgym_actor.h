@@ -14,26 +14,31 @@
 // fp32 accuracy from bf16 matrix cores: every operand is split x = hi + lo (both bf16), and
 // A B ~ A_hi B_hi + A_lo B_hi + A_hi B_lo (error ~2^-17 relative per product).
 #pragma once
-#include "fwgym_physics.h"
+#include "fwgym_env.h"
 
 #define FWG_STREAM_POLICY 6u
-#define FWG_ACT_BLOCK 256
+#define FWG_ACT_BLOCK 256          // k_actor_stats: threads = environments per block
+#define FWG_ACT_WAVES 8            // k_actor_act: waves per block, one 32-environment tile each
+#define FWG_ACT_ENVS (32 * FWG_ACT_WAVES)
+// hidden-layer weights and biases are packed pre-multiplied by 2 log2(e), so that tanh(z) = 1 - 2 / (2^acc + 1)
+#define FWG_ACT_PRESCALE 2.885390081777927f
 #define FWG_ACT_MAX_OBS 64
 #define FWG_ACT_MAX_ACT 4
 
 // running statistics + the act counter (Philox counter of the sampling noise), double-buffered by parity: every
 // k_actor_act reads copy [parity] and publishes copy [parity ^ 1], so captured launch sequences replay correctly
 struct ActorStats { float mean[FWG_ACT_MAX_OBS], var[FWG_ACT_MAX_OBS]; float count, ret_mean, ret_var, ret_count; unsigned act_counter, pad_[3]; };
-// batch moments about the running mean and the batch sizes they were taken over (0 = nothing observed)
-struct ActorAcc { float s1[FWG_ACT_MAX_OBS], s2[FWG_ACT_MAX_OBS]; float r1, r2, n_obs, n_ret; };
-#define FWG_ACT_NACC (2 * FWG_ACT_MAX_OBS + 4)
+// Batch moments reach k_actor_act through the fixed-point accumulators described in fwgym_env.h (acc_*), filled either
+// by k_actor_stats or by the env step kernel itself (fwg_attach_observer); double-buffered by parity like the statistics:
+// k_actor_act consumes copy [parity] and clears copy [parity ^ 1] for the launches that follow it.
 
 struct alignas(16) frag_t { unsigned x, y, z, w; };   // 8 bf16 = the A or B operand of one lane
 
 struct ActorArgs {
     const float* obs; const float* rew; const uint8_t* done;
     float* ret;
-    ActorStats* stats; ActorAcc* acc;   // [2] each, indexed by parity
+    ActorStats* stats;                  // [2], indexed by parity
+    unsigned long long* acc; int acc_cols;   // [2][FWG_ACC_SHARDS][acc_cols]
     const frag_t* frags;                // [net 2][part hi/lo][frag][64 lanes]
     const float* log_std;
     float* norm_obs; float* action; float* value; float* logp; float* norm_rew; uint8_t* done_out;
@@ -83,7 +88,8 @@ __device__ __forceinline__ f32x16 fwg_mfma_bf16(const frag_t& a, const frag_t& b
 #define fwg_exp2(x) __builtin_amdgcn_exp2f(x)
 #endif
 
-// eight fp32 values -> bf16 hi and lo operands
+// eight fp32 values -> bf16 hi and lo operands (round-to-nearest-even both; v_cvt_pk_bf16_f32 on the device)
+#ifdef FWG_EMU
 __device__ __forceinline__ void split8(const float (&x)[8], frag_t& hi, frag_t& lo) {
     unsigned h[8], l[8];
 #pragma unroll
@@ -94,10 +100,25 @@ __device__ __forceinline__ void split8(const float (&x)[8], frag_t& hi, frag_t& 
     hi = frag_t{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
     lo = frag_t{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
 }
+#else
+typedef __bf16 fwg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float fwg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const fwg_f32x2 v = {a, b};
+    const fwg_bf16x2 h = __builtin_convertvector(v, fwg_bf16x2);
+    const fwg_f32x2 r = v - __builtin_convertvector(h, fwg_f32x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, fwg_bf16x2));
+}
+__device__ __forceinline__ void split8(const float (&x)[8], frag_t& hi, frag_t& lo) {
+    split2(x[0], x[1], hi.x, lo.x); split2(x[2], x[3], hi.y, lo.y);
+    split2(x[4], x[5], hi.z, lo.z); split2(x[6], x[7], hi.w, lo.w);
+}
+#endif
 
-__device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (e^{2x} + 1), absolute error ~1e-7
-    const float t = fwg_exp2(2.885390081777927f * x);
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+// tanh of a pre-activation that arrives multiplied by 2 log2(e): 1 - 2 / (e^{2z} + 1), absolute error ~1e-7
+__device__ __forceinline__ float tanh_prescaled(float a) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(fwg_exp2(a) + 1.f);
 }
 
 // acc += A[idx] * B over the split parts; F = this network's fragments in LDS [part][nf][64]
@@ -125,23 +146,23 @@ __device__ __forceinline__ void hidden_to_b(const f32x16& a0, const f32x16& a1, 
     for (int kk = 0; kk < 4; ++kk) {
         float x[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] = fast_tanh(kk < 2 ? a0[8 * kk + t] : a1[8 * (kk - 2) + t]);
+        for (int t = 0; t < 8; ++t) x[t] = tanh_prescaled(kk < 2 ? a0[8 * kk + t] : a1[8 * (kk - 2) + t]);
         split8(x, hi[kk], lo[kk]);
     }
 }
 
 // one network (obs -> 64 -> 64 -> out) for the 32 environments of this half-wave tile; result rows 0..3 in out[0..3]
 // of the lanes with half == 0
-template <int SPLIT>
-__device__ __forceinline__ f32x16 mlp_forward(const frag_t* F, int nf, int nk1, int l, const frag_t (&bx_hi)[4], const frag_t (&bx_lo)[4]) {
+template <int SPLIT, int NK1>
+__device__ __forceinline__ f32x16 mlp_forward(const frag_t* F, int l, const frag_t (&bx_hi)[NK1], const frag_t (&bx_lo)[NK1]) {
+    constexpr int nk1 = NK1, nf = 2 * (NK1 + 1) + 15;
     const frag_t ones = frag_t{(l >> 5) == 0 ? 0x3F80u : 0u, 0u, 0u, 0u};   // 1.0 in k-slot (half 0, t 0)
     f32x16 a[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         f32x16 acc = {0.f};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            if (kk < nk1) acc = mma<SPLIT>(F, nf, it * (nk1 + 1) + kk, l, bx_hi[kk], bx_lo[kk], acc);
+        for (int kk = 0; kk < NK1; ++kk) acc = mma<SPLIT>(F, nf, it * (nk1 + 1) + kk, l, bx_hi[kk], bx_lo[kk], acc);
         a[it] = mma_bias<SPLIT>(F, nf, it * (nk1 + 1) + nk1, l, ones, acc);
     }
     frag_t bh_hi[4], bh_lo[4];
@@ -169,68 +190,46 @@ __device__ __forceinline__ float actor_wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// batch moments about the running mean -> acc[parity]; discounted returns
+// batch moments of an observation / reward batch that did not come out of an attached env step (the first observation
+// after reset(), evaluation loops): one thread = one environment, same accumulation as the tail of k_step
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FWG_ACT_BLOCK) void k_actor_stats(const ActorArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const long e = (long)blockIdx.x * FWG_ACT_BLOCK + tid;
     const bool valid = e < A.N;
+    const long wave = e >> 6;
+    if ((wave << 6) >= A.N) return;   // whole wave out of range (wave-uniform)
     const ActorStats& S = A.stats[A.parity];
-    for (int i = tid; i < FWG_ACT_NACC; i += FWG_ACT_BLOCK) lds[i] = 0.f;
-    __syncthreads();
-    if (A.obs != nullptr) {
-        for (int f0 = 0; f0 < A.D; f0 += 4) {
-            float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if (valid) {
-                if ((A.D & 3) == 0) {
-                    const float4 q = *reinterpret_cast<const float4*>(A.obs + e * A.D + f0);
-                    x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
-                } else {
+    const int D = A.D;
+    const bool has_obs = A.obs != nullptr, has_ret = A.rew != nullptr;
+    float dr = 0.f;
+    if (has_ret && valid) {   // VecNormalize.step_wait: ret = ret * gamma + r; ret_rms.update(ret); ret[done] = 0
+        const float r = A.ret[e] * A.gamma + A.rew[e];
+        A.ret[e] = (A.done != nullptr && A.done[e]) ? 0.f : r;
+        dr = r - S.ret_mean;
+    }
+    unsigned long long* acc = A.acc + (size_t)A.parity * FWG_ACC_SHARDS * A.acc_cols;
+    const float* row = A.obs + (valid ? e : 0) * D;
+#define FWG_OBS_AT(k) row[k]
+    for (int chunk = 0; 32 * chunk < 2 * D + 4; ++chunk) {
+        float v[32];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (f0 + i < A.D) x[i] = A.obs[e * A.D + f0 + i];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (f0 + i < A.D) {   // wave-uniform
-                    const float d = valid ? x[i] - S.mean[f0 + i] : 0.f;
-                    const float s1 = actor_wave_sum(d), s2 = actor_wave_sum(d * d);
-                    if ((tid & 63) == 0) { atomicAdd(&lds[f0 + i], s1); atomicAdd(&lds[FWG_ACT_MAX_OBS + f0 + i], s2); }
-                }
-            }
-        }
+        for (int i = 0; i < 32; ++i) v[i] = FWG_ACC_COLUMN(32 * chunk + i, D, valid, FWG_OBS_AT, S.mean, dr, has_obs, has_ret);
+        acc_flush(acc, A.acc_cols, (int)(wave & (FWG_ACC_SHARDS - 1)), chunk, lane, wave_totals32(v, lane));
     }
-    if (A.rew != nullptr) {   // VecNormalize.step_wait: ret = ret * gamma + r; ret_rms.update(ret); ret[done] = 0
-        float d = 0.f;
-        if (valid) {
-            const float r = A.ret[e] * A.gamma + A.rew[e];
-            d = r - S.ret_mean;
-            A.ret[e] = (A.done != nullptr && A.done[e]) ? 0.f : r;
-        }
-        const float s1 = actor_wave_sum(d), s2 = actor_wave_sum(d * d);
-        if ((tid & 63) == 0) { atomicAdd(&lds[2 * FWG_ACT_MAX_OBS], s1); atomicAdd(&lds[2 * FWG_ACT_MAX_OBS + 1], s2); }
-    }
-    if (tid == 0) {   // batch sizes
-        const long left = A.N - (long)blockIdx.x * FWG_ACT_BLOCK;
-        const float cnt = (float)(left < FWG_ACT_BLOCK ? left : FWG_ACT_BLOCK);
-        if (A.obs != nullptr) lds[2 * FWG_ACT_MAX_OBS + 2] = cnt;
-        if (A.rew != nullptr) lds[2 * FWG_ACT_MAX_OBS + 3] = cnt;
-    }
-    __syncthreads();
-    float* acc = reinterpret_cast<float*>(&A.acc[A.parity]);
-    for (int i = tid; i < FWG_ACT_NACC; i += FWG_ACT_BLOCK)
-        if (lds[i] != 0.f) atomicAdd(acc + i, lds[i]);
+#undef FWG_OBS_AT
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// statistics update + normalisation + pi/vf forward + sampling.  Block = 4 waves, a wave = 64 envs in two 32-env tiles
+// statistics update + normalisation + pi/vf forward + sampling.  Block = 8 waves (two per SIMD, so that one wave's
+// MFMAs overlap the other's tanh/conversion work), a wave = one 32-environment tile; the packed weights of both
+// networks sit in LDS once per block (76 KiB for obs_dim <= 16)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int SPLIT>
-__global__ __launch_bounds__(FWG_ACT_BLOCK, 1) void k_actor_act(const ActorArgs A) {
+template <int SPLIT, int NK1>
+__global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, j = l & 31, half = l >> 5;
-    const int nk1 = A.nk1, nf = actor_frags(nk1);
+    constexpr int nf = 2 * (NK1 + 1) + 15;
     constexpr int PARTS = SPLIT > 1 ? 2 : 1;
     frag_t* F = reinterpret_cast<frag_t*>(lds);                     // [net][part][nf][64]
     float* mean_s = lds + 2 * PARTS * nf * 64 * 4;                  // [64]
@@ -238,26 +237,36 @@ __global__ __launch_bounds__(FWG_ACT_BLOCK, 1) void k_actor_act(const ActorArgs 
     float* misc = rstd_s + FWG_ACT_MAX_OBS;                         // [0] = 1/sqrt(ret_var + eps)
     for (int net = 0; net < 2; ++net)
         for (int part = 0; part < PARTS; ++part)
-            for (int i = tid; i < nf * 64; i += FWG_ACT_BLOCK)
+            for (int i = tid; i < nf * 64; i += 64 * FWG_ACT_WAVES)
                 F[(net * PARTS + part) * nf * 64 + i] = A.frags[(net * 2 + part) * nf * 64 + i];
-    {   // fold the accumulated batch moments into the running statistics (parallel-variance update of VecNormalize's
-        // RunningMeanStd); every block computes the same values, block 0 publishes them for the next launch
+    {   // add the accumulator shards (integers: exact, order-free) and fold the batch into the running statistics (the
+        // parallel-variance update of VecNormalize's RunningMeanStd).  Every block computes the same values; block 0
+        // publishes them and clears the other parity's accumulators for the launches that follow
         const ActorStats& S0 = A.stats[A.parity];
         ActorStats& S1 = A.stats[A.parity ^ 1];
-        const ActorAcc& C = A.acc[A.parity];
+        const int D = A.D, cols = 2 * D + 4;
+        const unsigned long long* acc = A.acc + (size_t)A.parity * FWG_ACC_SHARDS * A.acc_cols;
+        float* tot = misc + 4;   // [cols] batch sums, column layout of fwgym_env.h
+        if (tid < cols) {
+            long long sum = 0;
+#pragma unroll
+            for (int sh = 0; sh < FWG_ACC_SHARDS; ++sh) sum += (long long)acc[(long)sh * A.acc_cols + tid];
+            tot[tid] = (tid == 2 || tid == 3) ? (float)sum : (float)sum * (1.f / FWG_ACC_SCALE);
+        }
+        __syncthreads();
+        const float n_obs = A.training ? tot[2] : 0.f, n_ret = A.training ? tot[3] : 0.f;
         if (tid < FWG_ACT_MAX_OBS) {
-            const float n = C.n_obs;
             const int f = tid;
             float m = 0.f, rs = 0.f, v = 1.f;
-            if (f < A.D) {
+            if (f < D) {
                 m = S0.mean[f]; v = S0.var[f];
-                if (A.training && n > 0.f) {
-                    const float cnt = S0.count, tot = cnt + n;
-                    const float s1 = C.s1[f] / n, s2 = C.s2[f] / n;
+                if (n_obs > 0.f) {
+                    const float cnt = S0.count, tt = cnt + n_obs;
+                    const float s1 = tot[4 + 2 * f] / n_obs, s2 = tot[5 + 2 * f] / n_obs;
                     const float bvar = fmaxf(s2 - s1 * s1, 0.f);
-                    const float m2 = v * cnt + bvar * n + s1 * s1 * (cnt * n / tot);
-                    m += s1 * (n / tot);
-                    v = m2 / tot;
+                    const float mm = v * cnt + bvar * n_obs + s1 * s1 * (cnt * n_obs / tt);
+                    m += s1 * (n_obs / tt);
+                    v = mm / tt;
                 }
                 rs = 1.f / sqrtf(v + A.eps);
             }
@@ -265,98 +274,92 @@ __global__ __launch_bounds__(FWG_ACT_BLOCK, 1) void k_actor_act(const ActorArgs 
             if (blockIdx.x == 0) { S1.mean[f] = m; S1.var[f] = v; }
         }
         if (tid == FWG_ACT_MAX_OBS) {
-            float rm = S0.ret_mean, rv = S0.ret_var, rc = S0.ret_count, oc = S0.count;
-            if (A.training) {
-                oc += C.n_obs;
-                const float n = C.n_ret;
-                if (n > 0.f) {
-                    const float tot = rc + n;
-                    const float s1 = C.r1 / n, s2 = C.r2 / n;
-                    const float bvar = fmaxf(s2 - s1 * s1, 0.f);
-                    const float m2 = rv * rc + bvar * n + s1 * s1 * (rc * n / tot);
-                    rm += s1 * (n / tot);
-                    rv = m2 / tot;
-                    rc = tot;
-                }
+            float rm = S0.ret_mean, rv = S0.ret_var, rc = S0.ret_count;
+            if (n_ret > 0.f) {
+                const float tt = rc + n_ret;
+                const float s1 = tot[0] / n_ret, s2 = tot[1] / n_ret;
+                const float bvar = fmaxf(s2 - s1 * s1, 0.f);
+                const float mm = rv * rc + bvar * n_ret + s1 * s1 * (rc * n_ret / tt);
+                rm += s1 * (n_ret / tt);
+                rv = mm / tt;
+                rc = tt;
             }
             misc[0] = 1.f / sqrtf(rv + A.eps);
             if (blockIdx.x == 0) {
-                S1.count = oc; S1.ret_mean = rm; S1.ret_var = rv; S1.ret_count = rc;
+                S1.count = S0.count + n_obs; S1.ret_mean = rm; S1.ret_var = rv; S1.ret_count = rc;
                 S1.act_counter = S0.act_counter + 1u;
             }
         }
-        if (blockIdx.x == 0) {   // nobody reads the other parity's accumulators during this launch
-            float* nxt = reinterpret_cast<float*>(&A.acc[A.parity ^ 1]);
-            for (int i = tid; i < FWG_ACT_NACC; i += FWG_ACT_BLOCK) nxt[i] = 0.f;
+        if (blockIdx.x == 0) {
+            unsigned long long* nxt = A.acc + (size_t)(A.parity ^ 1) * FWG_ACC_SHARDS * A.acc_cols;
+            for (int i = tid; i < FWG_ACC_SHARDS * A.acc_cols; i += 64 * FWG_ACT_WAVES) nxt[i] = 0ull;
         }
     }
     __syncthreads();
 
-    const float log_2pi_half = 0.9189385332046727f;
+    const long e = (long)blockIdx.x * FWG_ACT_ENVS + wv * 32 + j;
+    const bool valid = e < A.N;
+    const bool vec4 = (A.D & 3) == 0;
+    frag_t bx_hi[NK1], bx_lo[NK1];
+#pragma unroll
+    for (int kk = 0; kk < NK1; ++kk) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f0 = k_input(kk, half, 4 * q);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid && f0 < A.D) {
+                if (vec4) {
+                    const float4 g = *reinterpret_cast<const float4*>(A.obs + e * A.D + f0);
+                    v[0] = g.x; v[1] = g.y; v[2] = g.z; v[3] = g.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (f0 + i < A.D) v[i] = A.obs[e * A.D + f0 + i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // features >= D: mean 0, rstd 0 -> 0
+                v[i] = fminf(fmaxf((v[i] - mean_s[f0 + i]) * rstd_s[f0 + i], -A.clip_obs), A.clip_obs);
+                x[4 * q + i] = v[i];
+            }
+            if (A.norm_obs != nullptr && valid && f0 < A.D) {
+                if (vec4) *reinterpret_cast<float4*>(A.norm_obs + e * A.D + f0) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (f0 + i < A.D) A.norm_obs[e * A.D + f0 + i] = v[i];
+                }
+            }
+        }
+        split8(x, bx_hi[kk], bx_lo[kk]);
+    }
+    float res[2][FWG_ACT_MAX_ACT];
 #pragma unroll 1
-    for (int tile = 0; tile < 2; ++tile) {
-        const long e = (long)blockIdx.x * FWG_ACT_BLOCK + wv * 64 + tile * 32 + j;
-        const bool valid = e < A.N;
-        frag_t bx_hi[4], bx_lo[4];
+    for (int net = 0; net < 2; ++net) {   // pi, then vf: one copy of the code, registers reused
+        const f32x16 o = mlp_forward<SPLIT, NK1>(F + net * PARTS * nf * 64, l, bx_hi, bx_lo);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < nk1) {
-                float x[8];
+        for (int i = 0; i < FWG_ACT_MAX_ACT; ++i) res[net][i] = o[i];
+    }
+    if (half == 0 && valid) {
+        float n[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!A.deterministic) {
+            const u4 b = philox4x32((unsigned)(A.env_base + e), A.stats[A.parity].act_counter, 0u, FWG_STREAM_POLICY,
+                                    A.seed_lo, A.seed_hi);
+            box_muller(b, n);
+        }
+        float lp = 0.f;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int f0 = k_input(kk, half, 4 * q);
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (valid && f0 < A.D) {
-                        if ((A.D & 3) == 0) {
-                            const float4 g = *reinterpret_cast<const float4*>(A.obs + e * A.D + f0);
-                            v[0] = g.x; v[1] = g.y; v[2] = g.z; v[3] = g.w;
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) if (f0 + i < A.D) v[i] = A.obs[e * A.D + f0 + i];
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int f = f0 + i;   // < 64
-                        v[i] = fminf(fmaxf((v[i] - mean_s[f]) * rstd_s[f], -A.clip_obs), A.clip_obs);
-                        x[4 * q + i] = v[i];
-                    }
-                    if (A.norm_obs != nullptr && valid && f0 < A.D) {
-                        if ((A.D & 3) == 0) *reinterpret_cast<float4*>(A.norm_obs + e * A.D + f0) = make_float4(v[0], v[1], v[2], v[3]);
-                        else {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) if (f0 + i < A.D) A.norm_obs[e * A.D + f0 + i] = v[i];
-                        }
-                    }
-                }
-                split8(x, bx_hi[kk], bx_lo[kk]);
+        for (int i = 0; i < FWG_ACT_MAX_ACT; ++i) {
+            if (i < A.act_dim) {
+                const float ls = A.log_std[i];
+                if (A.action != nullptr) A.action[e * A.act_dim + i] = res[0][i] + expf(ls) * n[i];
+                lp += -0.5f * n[i] * n[i] - ls - 0.9189385332046727f;
             }
         }
-        const f32x16 pi = mlp_forward<SPLIT>(F, nf, nk1, l, bx_hi, bx_lo);
-        const f32x16 vf = mlp_forward<SPLIT>(F + PARTS * nf * 64, nf, nk1, l, bx_hi, bx_lo);
-        if (half == 0 && valid) {
-            const float mean[FWG_ACT_MAX_ACT] = {pi[0], pi[1], pi[2], pi[3]};
-            float n[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!A.deterministic) {
-                const u4 b = philox4x32((unsigned)(A.env_base + e), A.stats[A.parity].act_counter, 0u, FWG_STREAM_POLICY,
-                                        A.seed_lo, A.seed_hi);
-                box_muller(b, n);
-            }
-            float lp = 0.f;
-#pragma unroll
-            for (int i = 0; i < FWG_ACT_MAX_ACT; ++i) {
-                if (i < A.act_dim) {
-                    const float ls = A.log_std[i];
-                    if (A.action != nullptr) A.action[e * A.act_dim + i] = mean[i] + expf(ls) * n[i];
-                    lp += -0.5f * n[i] * n[i] - ls - log_2pi_half;
-                }
-            }
-            if (A.logp != nullptr) A.logp[e] = lp;
-            if (A.value != nullptr) A.value[e] = vf[0];
-            if (A.norm_rew != nullptr && A.rew != nullptr)
-                A.norm_rew[e] = fminf(fmaxf(A.rew[e] * misc[0], -A.clip_rew), A.clip_rew);
-            if (A.done_out != nullptr && A.done != nullptr) A.done_out[e] = A.done[e];
-        }
+        if (A.logp != nullptr) A.logp[e] = lp;
+        if (A.value != nullptr) A.value[e] = res[1][0];
+        if (A.norm_rew != nullptr && A.rew != nullptr)
+            A.norm_rew[e] = fminf(fmaxf(A.rew[e] * misc[0], -A.clip_rew), A.clip_rew);
+        if (A.done_out != nullptr && A.done != nullptr) A.done_out[e] = A.done[e];
     }
 }
 
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(FWG_ACT_BLOCK, 1) void k_actor_act(const ActorArgs 
 // ---------------------------------------------------------------------------------------------------------------------
 // one layer: W [out][in] row-major, b [out]; nit row tiles, nk k-blocks (+1 bias block) -> hi/lo words appended
 static void actor_pack_layer(std::vector<unsigned>& hi, std::vector<unsigned>& lo, const float* W, const float* b, int out,
-                             int in, int nit, int nk, bool chained) {
+                             int in, int nit, int nk, bool chained, float scale) {
     for (int it = 0; it < nit; ++it)
         for (int kk = 0; kk <= nk; ++kk)
             for (int l = 0; l < 64; ++l) {
@@ -375,9 +378,9 @@ static void actor_pack_layer(std::vector<unsigned>& hi, std::vector<unsigned>& l
                     float v = 0.f;
                     if (kk < nk) {
                         const int k = chained ? k_chained(kk, half, t) : k_input(kk, half, t);
-                        if (i < out && k < in) v = W[(size_t)i * in + k];
+                        if (i < out && k < in) v = scale * W[(size_t)i * in + k];
                     } else if (half == 0 && t == 0 && i < out) {
-                        v = b[i];
+                        v = scale * b[i];
                     }
                     const unsigned h16 = bf16_rne(v), l16 = bf16_rne(v - bf16_to_f32(h16));
                     wh[t >> 1] |= h16 << (16 * (t & 1));

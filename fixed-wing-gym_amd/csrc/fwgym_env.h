@@ -29,7 +29,80 @@ struct KArgs {
     const long long* gstep_in;
     long long* gstep_out;
     int reset_launch;                            // k_reset: positions refer to the LAST completed step (counter - 1)
+    // attached rollout head (fwg_attach_observer): every wave also adds the moments of its 64 observation records and
+    // discounted returns to the head's accumulators (acc_*), so the head needs no pass over the batch
+    unsigned long long* acc;                     // nullable [FWG_ACC_SHARDS][acc_cols] fixed-point sums
+    const float* acc_mean;                       // running observation mean [obs_dim] the deviations are taken from
+    const float* acc_ret_mean;                   // ... and the running mean of the returns
+    float* acc_ret;                              // [N] discounted returns (VecNormalize.ret)
+    float acc_gamma;
+    int acc_cols;
 };
+
+// ---- batch-moment accumulators shared by k_step, k_actor_stats and k_actor_act.  Columns: 0 / 1 sum and sum of
+// squares of the return deviations (from the running mean), 2 / 3 number of observations / returns, 4 + 2k / 5 + 2k the
+// same two sums for observation entry k.  Sums are added as 64-bit FIXED-POINT integers (2^-20 resolution): integer
+// addition is associative, so the totals -- and with them the whole rollout -- do not depend on the order the waves
+// arrive in.  FWG_ACC_SHARDS copies (wave index mod 16) keep the atomics off one cache line; the reader adds them.
+#ifndef FWG_ACC_SHARDS
+#define FWG_ACC_SHARDS 16
+#endif
+#define FWG_ACC_SCALE 1048576.f
+__host__ __device__ inline int acc_cols_for(int D) { return (2 * D + 4 + 31) & ~31; }   // whole 32-column chunks
+
+// value of lane (l ^ MASK)
+#ifdef FWG_EMU
+template <int MASK> __device__ __forceinline__ float lane_xor(float v) { return __shfl_xor(v, MASK, FWG_WAVE); }
+#else
+#define FWG_DPP_MOV(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+template <int MASK> __device__ __forceinline__ float lane_xor(float v) {
+    if (MASK == 1) return FWG_DPP_MOV(v, 0xB1);                  // quad_perm:[1,0,3,2]
+    if (MASK == 2) return FWG_DPP_MOV(v, 0x4E);                  // quad_perm:[2,3,0,1]
+    if (MASK == 8) return FWG_DPP_MOV(v, 0x128);                 // row_ror:8
+    if (MASK == 4 || MASK == 16)                                 // ds_swizzle, bit-mask mode: and 0x1F, or 0, xor MASK
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x1F | (MASK << 10)));
+    return __shfl_xor(v, MASK, FWG_WAVE);
+}
+#endif
+// 64-lane sum of one value
+__device__ __forceinline__ float wave_sum64(float v) {
+    v += lane_xor<1>(v); v += lane_xor<2>(v); v += lane_xor<4>(v); v += lane_xor<8>(v); v += lane_xor<16>(v);
+    return v + lane_xor<32>(v);
+}
+// 64-lane sums of 32 values at once: each exchange step halves the number of values a lane carries (a lane keeps the
+// half selected by one bit of its index and hands the other half to its partner), 31 exchanges instead of 32 x 6.
+// Lane l returns the total of v[l & 31].
+__device__ __forceinline__ float wave_totals32(float (&v)[32], int lane) {
+#define FWG_TOT_STAGE(H, MASK)                                                              \
+    _Pragma("unroll") for (int i = 0; i < (H); ++i) {                                        \
+        const bool up = (lane & (MASK)) != 0;                                                \
+        const float keep = up ? v[2 * i + 1] : v[2 * i], send = up ? v[2 * i] : v[2 * i + 1]; \
+        v[i] = keep + lane_xor<MASK>(send);                                                  \
+    }
+    FWG_TOT_STAGE(16, 1) FWG_TOT_STAGE(8, 2) FWG_TOT_STAGE(4, 4) FWG_TOT_STAGE(2, 8) FWG_TOT_STAGE(1, 16)
+#undef FWG_TOT_STAGE
+    return v[0] + lane_xor<32>(v[0]);
+}
+// lanes 0..31 add the chunk's totals (columns 32 chunk + lane) to shard `shard`
+__device__ __forceinline__ void acc_flush(unsigned long long* acc, int cols, int shard, int chunk, int lane, float total) {
+    const int col = 32 * chunk + lane;
+    if (lane < 32 && col < cols) {
+        const long long q = (col == 2 || col == 3) ? (long long)rintf(total) : (long long)rintf(total * FWG_ACC_SCALE);
+#ifndef FWG_ABL_NO_FLUSH
+        atomicAdd(acc + (long)shard * cols + col, (unsigned long long)q);
+#else
+        if (q == 0x7fffffffffffffffll) acc[0] = 1;
+#endif
+    }
+}
+// value of accumulator column `col` for one lane: x(k) = observation entry k (called only for k < D), dr = return deviation
+#define FWG_ACC_COLUMN(col, D, valid, X, MEAN, dr, has_obs, has_ret)                                         \
+    ((col) == 0 ? (dr) : (col) == 1 ? (dr) * (dr) : (col) == 2 ? (((valid) && (has_obs)) ? 1.f : 0.f)            \
+     : (col) == 3 ? (((valid) && (has_ret)) ? 1.f : 0.f)                                                         \
+     : ((((col) - 4) >> 1) < (D) && (valid) && (has_obs))                                                        \
+           ? ((((col) & 1) == 0) ? ((X((((col) - 4) >> 1))) - (MEAN)[(((col) - 4) >> 1)])                          \
+                                 : ((X((((col) - 4) >> 1))) - (MEAN)[(((col) - 4) >> 1)]) * ((X((((col) - 4) >> 1))) - (MEAN)[(((col) - 4) >> 1)])) \
+           : 0.f)
 
 __device__ __forceinline__ int dev_pmod(long long a, int m) { return m > 0 ? (int)(((a % m) + m) % m) : 0; }
 // ring positions of this launch: host-computed kernel arguments, or derived from the device-resident counter

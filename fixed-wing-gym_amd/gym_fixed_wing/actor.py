@@ -66,6 +66,7 @@ class DeviceActor(object):
 
     def close(self):
         if getattr(self, "_handle", None):
+            self.detach()
             self._lib.fwg_actor_destroy(self._handle)
             self._handle = None
 
@@ -110,6 +111,17 @@ class DeviceActor(object):
         nat.check(self._lib, self._lib.fwg_actor_get_stats(self._handle, ctypes.byref(s), self._mem.stream()))
         return {"obs_mean": np.array(s.obs_mean[:self.obs_dim], np.float32), "obs_var": np.array(s.obs_var[:self.obs_dim], np.float32),
                 "obs_count": s.obs_count, "ret_mean": s.ret_mean, "ret_var": s.ret_var, "ret_count": s.ret_count}
+
+    def attach(self, vec):
+        """From now on vec.step()/step_device() does the observe() bookkeeping inside the env step kernel."""
+        nat.check(self._lib, self._lib.fwg_attach_observer(vec._handle, self._handle))
+        self._attached = vec
+
+    def detach(self):
+        vec = getattr(self, "_attached", None)
+        if vec is not None and getattr(vec, "_handle", None):
+            nat.check(self._lib, self._lib.fwg_attach_observer(vec._handle, ctypes.c_void_p()))
+        self._attached = None
 
     def _p(self, t):
         return ctypes.c_void_p() if t is None else self._mem.ptr(t)

@@ -85,6 +85,7 @@ SPECIALISED = [
     # "_lean": the same configurations with derived_views=False (no per-step roll/pitch/yaw/Va/alpha/beta rows)
     ("c2_default_lean", "default", None, None),
     ("c3_cnn_step2_dryden_lean", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),
+    ("c5_examples_lean", "examples", None, None),
 ]
 
 

@@ -155,3 +155,79 @@ class GraphedRollout(object):
         self.graph.replay()
         self.vec.note_replayed_steps(self.n_steps)
         return self.buf
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The same rollout on the HIP rollout head (gym_fixed_wing.actor.DeviceActor): three launches per step
+# ----------------------------------------------------------------------------------------------------------------------
+class FusedRollout(object):
+    """n-step rollouts of FixedWingVecEnv under a DeviceActor, filling {obs, actions, values, logp, rewards, dones}
+    ([n_steps, N, ...], normalised observations/rewards as VecNormalize + PPO2 store them) plus `last_value` (the
+    bootstrap value of the observation after the last step).  Per step: fwg_step (which also leaves the batch moments for
+    the attached head) and fwg_actor_act --
+    the act that follows step t writes the rollout slice t+1 directly, so nothing is copied except the carried-over
+    slice 0.  `graph=True` captures the whole rollout into one hipGraph (n_steps must be even)."""
+
+    def __init__(self, vec, actor, n_steps, graph=False):
+        self.vec, self.actor, self.n_steps = vec, actor, int(n_steps)
+        m, N, D, A = vec._mem, vec.num_envs, vec.obs_dim, actor.act_dim
+        self.buf = {"obs": m.zeros((n_steps, N, D)), "actions": m.zeros((n_steps, N, A)), "values": m.zeros((n_steps, N)),
+                    "logp": m.zeros((n_steps, N)), "rewards": m.zeros((n_steps, N)), "dones": m.zeros((n_steps, N), "u8")}
+        # the head's outputs for the CURRENT observation, carried from one rollout to the next
+        self.cur = {"obs": m.zeros((N, D)), "actions": m.zeros((N, A)), "values": m.zeros((N,)), "logp": m.zeros((N,))}
+        self.last_value = self.cur["values"]
+        self._primed = False
+        self._graph = None
+        actor.attach(vec)      # the env step kernel leaves the batch moments itself: two launches per step
+        if graph:
+            self._capture()
+
+    def _prime(self):
+        if not self._primed:   # first observation after reset(): no transition led here
+            c = self.cur
+            self.actor.observe(self.vec._obs)
+            self.actor.act(self.vec._obs, norm_obs=c["obs"], action=c["actions"], value=c["values"], logp=c["logp"])
+            self._primed = True
+
+    def _body(self):
+        vec, actor, buf, cur, n = self.vec, self.actor, self.buf, self.cur, self.n_steps
+        for k in ("obs", "actions", "values", "logp"):
+            buf[k][0][...] = cur[k]
+        for t in range(n):
+            o, r, d = vec.step_device(buf["actions"][t])
+            nxt = cur if t == n - 1 else {k: buf[k][t + 1] for k in cur}
+            actor.act(o, reward=r, done=d, norm_obs=nxt["obs"], action=nxt["actions"], value=nxt["values"], logp=nxt["logp"],
+                      norm_reward=buf["rewards"][t], done_out=buf["dones"][t])
+
+    def _capture(self):
+        import torch
+        assert self.n_steps % 2 == 0, "graph mode double-buffers step counter and statistics: capture an even number of steps"
+        vec = self.vec
+        dev = vec._obs.device
+        vec.set_graph_mode(True)
+        self._prime()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):   # warm-up outside capture
+            o, r, d = vec.step_device(self.cur["actions"])
+            self.actor.act(o, reward=r, done=d, norm_obs=self.cur["obs"], action=self.cur["actions"], value=self.cur["values"],
+                           logp=self.cur["logp"])
+            o, r, d = vec.step_device(self.cur["actions"])
+            self.actor.act(o, reward=r, done=d, norm_obs=self.cur["obs"], action=self.cur["actions"], value=self.cur["values"],
+                           logp=self.cur["logp"])
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+        vec.capture_begin()
+        with torch.cuda.graph(self._graph):
+            self._body()
+        vec.capture_end()
+
+    def run(self):
+        self._prime()
+        if self._graph is not None:
+            self._graph.replay()
+            self.vec.note_replayed_steps(self.n_steps)
+        else:
+            self._body()
+        return self.buf

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 9
+#define FWG_ABI_VERSION 10
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -326,6 +326,11 @@ int fwg_actor_get_stats(fwg_actor* a, fwg_actor_stats* s_host, void* stream);   
 int fwg_actor_configure(fwg_actor* a, int training, int precise);
 /* Sampling noise: Philox stream (seed, env_id_base + env, act counter). */
 int fwg_actor_seed(fwg_actor* a, uint64_t seed, int64_t env_id_base);
+/* Attaches the head to an env (NULL detaches): from then on every fwg_step also leaves the batch moments of the
+ * observations it writes and advances the discounted returns with the rewards it writes -- what fwg_actor_observe
+ * would do in a launch of its own -- so that a rollout step is two launches (fwg_step, fwg_actor_act).  Same n_envs,
+ * obs_dim and device required. */
+int fwg_attach_observer(fwg_handle* h, fwg_actor* a);
 /* Accumulates the batch moments of `obs` ([N][obs_dim]) and, when `reward` is not NULL, advances the discounted
  * returns (ret = ret * gamma + reward, zeroed where `done`) and accumulates their moments (VecNormalize.step_wait). */
 int fwg_actor_observe(fwg_actor* a, const float* obs, const float* reward, const uint8_t* done, void* stream);

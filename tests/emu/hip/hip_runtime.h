@@ -81,11 +81,13 @@ static inline float __shfl_xor(float v, int mask, int) {
 }
 static std::mutex emu_atomic_mutex;
 static inline float atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); float o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); unsigned long long o = *p; *p = o + v; return o; }
 static inline int atomicOr(int* p, int v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); int o = *p; *p = o | v; return o; }
 
 // ---- intrinsics ----------------------------------------------------------------------------------------------------
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 #define __expf(x) expf(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))

@@ -101,3 +101,110 @@ def test_running_statistics_survive_graph_replay():
     np.testing.assert_allclose(rms.var.cpu().numpy(), allx.var(axis=0), rtol=2e-3, atol=1e-4)
     np.testing.assert_allclose(float(ret.mean), allx[:, 0].mean(), rtol=2e-4)
     np.testing.assert_allclose(float(ret.var), allx[:, 0].var(), rtol=2e-3)
+
+
+def _fused_vs_torch(vec, mk_actor, n_steps, graph=False):
+    """The fused rollout against the plain-torch formulation (VecNormalizeDevice + MlpPolicy) driven with the SAME
+    actions: normalised observations/rewards, values and log-probabilities of every stored transition."""
+    import math
+    from gym_fixed_wing.actor import DeviceActor
+    from gym_fixed_wing.rollout import FusedRollout
+    N, D = vec.num_envs, vec.obs_dim
+    torch.manual_seed(0)
+    policy = MlpPolicy(D)
+    with torch.no_grad():
+        policy.log_std.copy_(torch.tensor([-1.0, -0.7, -1.2]))
+    actor = mk_actor(vec)
+    actor.load_policy(policy)
+    raw = []   # raw (obs, rew, done) per step, recorded through the env's step_device
+    orig = vec.step_device
+
+    def spy(a):
+        o, r, d = orig(a)
+        if not graph:
+            raw.append((np.array(_to_np(o)), np.array(_to_np(r)), np.array(_to_np(d))))
+        return o, r, d
+    vec.step_device = spy
+    obs0 = np.array(_to_np(vec._obs))
+    ro = FusedRollout(vec, actor, n_steps, graph=graph)
+    buf = {k: np.array(_to_np(v)) for k, v in ro.run().items()}
+    last_value = np.array(_to_np(ro.last_value))
+    vec.step_device = orig
+    assert np.isfinite(buf["obs"]).all() and np.isfinite(buf["rewards"]).all() and np.isfinite(buf["logp"]).all()
+    assert np.abs(buf["obs"]).max() <= 10.0 and np.abs(buf["rewards"]).max() <= 10.0
+    if graph:
+        return buf
+    norm = VecNormalizeDevice((D,), N)
+    cur = norm.obs(torch.from_numpy(obs0).reshape(N, -1))
+    ls = policy.log_std.detach().numpy()
+    worst = 0.0
+    for t in range(n_steps):
+        np.testing.assert_allclose(buf["obs"][t], cur.numpy(), atol=2e-4)
+        with torch.no_grad():
+            mine = torch.from_numpy(buf["obs"][t])
+            mean, value = policy.pi(mine).numpy(), policy.vf(mine).squeeze(-1).numpy()
+        np.testing.assert_allclose(buf["values"][t], value, atol=1e-4)
+        z = (buf["actions"][t] - mean) / np.exp(ls)
+        np.testing.assert_allclose(buf["logp"][t], (-0.5 * z * z - ls - 0.5 * math.log(2 * math.pi)).sum(axis=1), atol=2e-3)
+        o, r, d = raw[t]
+        np.testing.assert_array_equal(buf["dones"][t], d)
+        want_r = norm.reward(torch.from_numpy(r), torch.from_numpy(d)).numpy()
+        np.testing.assert_allclose(buf["rewards"][t], want_r, atol=2e-4)
+        cur = norm.obs(torch.from_numpy(o).reshape(N, -1))
+        worst = max(worst, float(np.abs(z).max()))
+    with torch.no_grad():
+        np.testing.assert_allclose(last_value, policy.vf(cur).squeeze(-1).numpy(), atol=2e-3)
+    assert 2.0 < worst < 7.0   # the stored actions really carry unit-variance noise around the policy mean
+    return buf
+
+
+def _to_np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def test_fused_rollout_on_emulated_env():
+    from emu.host_backend import HostBackend, build_emu
+    from gym_fixed_wing.actor import DeviceActor
+    cfg = configs.reference_like("examples")
+    vec = FixedWingVecEnv(cfg, num_envs=70, config_kw={"steps_max": 9}, as_numpy=True, _backend=HostBackend(),
+                          _lib_path=build_emu())
+    vec.reset()
+    buf = _fused_vs_torch(vec, lambda v: DeviceActor.for_env(v, seed=5), 12)
+    assert buf["dones"].sum() == 70      # every env hits steps_max=9 once in 12 steps
+
+
+@pytest.mark.gpu
+def test_fused_rollout_matches_torch_on_gpu():
+    from gym_fixed_wing.actor import DeviceActor
+    cfg = configs.reference_like("examples")
+    vec = FixedWingVecEnv(cfg, num_envs=4096, device=0, config_kw={"steps_max": 20}, derived_views=False)
+    vec.reset()
+    _fused_vs_torch(vec, lambda v: DeviceActor.for_env(v, seed=5), 32)
+
+
+@pytest.mark.gpu
+def test_fused_rollout_throughput_on_gpu():
+    import time
+    from gym_fixed_wing.actor import DeviceActor
+    from gym_fixed_wing.rollout import FusedRollout
+    cfg = configs.reference_like("examples")
+    n = 65536
+    for graph in (False, True):
+        vec = FixedWingVecEnv(cfg, num_envs=n, device=0, derived_views=False)
+        vec.reset()
+        actor = DeviceActor.for_env(vec, seed=1)
+        actor.load_policy(MlpPolicy(12))
+        ro = FusedRollout(vec, actor, 128, graph=graph)
+        ro.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            buf = ro.run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        print("C5 fused rollout{}: {:.3e} env-steps/s end to end, {:.1f} us/step".format(" (hipGraph)" if graph else "", 128 * n / dt, dt / 128 * 1e6))
+        assert torch.isfinite(buf["rewards"]).all() and torch.isfinite(buf["obs"]).all() and torch.isfinite(buf["logp"]).all()
+        st = actor.get_stats()
+        assert st["obs_var"].min() > 0 and abs(st["obs_count"] - (1e-4 + n * (1 + 4 * 128 + (2 if graph else 0)))) < 64
+        assert 128 * n / dt > (5e8 if graph else 5e7)   # the eager loop is bounded by host launch overhead
+        vec.close()

@@ -5,12 +5,13 @@ import os, subprocess, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "fixed-wing-gym_amd")
 OUT = os.path.join(PKG, "gym_fixed_wing", "_abl")
-VARIANTS = {"base": [], "empty": ["-DFWG_ABL_EMPTY"], "no_sim": ["-DFWG_ABL_NO_SIM"], "no_lag": ["-DFWG_ABL_NO_LAG"],
-            "no_obswrite": ["-DFWG_ABL_NO_OBSWRITE"], "no_gymstore": ["-DFWG_ABL_NO_GYMSTORE"],
-            "no_simstore": ["-DFWG_ABL_NO_SIMSTORE"],
-            "no_stores": ["-DFWG_ABL_NO_OBSWRITE", "-DFWG_ABL_NO_GYMSTORE", "-DFWG_ABL_NO_SIMSTORE"],
-            "loads_only": ["-DFWG_ABL_NO_OBSWRITE", "-DFWG_ABL_NO_GYMSTORE", "-DFWG_ABL_NO_SIMSTORE", "-DFWG_ABL_NO_SIM"],
-            "nothing": ["-DFWG_ABL_NO_OBSWRITE", "-DFWG_ABL_NO_GYMSTORE", "-DFWG_ABL_NO_SIMSTORE", "-DFWG_ABL_NO_SIM", "-DFWG_ABL_NO_LAG"]}
+PRESETS = {"base": [], "empty": ["-DFWG_ABL_EMPTY"], "no_sim": ["-DFWG_ABL_NO_SIM"], "no_lag": ["-DFWG_ABL_NO_LAG"],
+           "no_obswrite": ["-DFWG_ABL_NO_OBSWRITE"], "no_simstore": ["-DFWG_ABL_NO_SIMSTORE"],
+           "no_stores": ["-DFWG_ABL_NO_OBSWRITE", "-DFWG_ABL_NO_GYMSTORE", "-DFWG_ABL_NO_SIMSTORE"],
+           "loads_only": ["-DFWG_ABL_NO_OBSWRITE", "-DFWG_ABL_NO_GYMSTORE", "-DFWG_ABL_NO_SIMSTORE", "-DFWG_ABL_NO_SIM"],
+           "nothing": ["-DFWG_ABL_NO_OBSWRITE", "-DFWG_ABL_NO_GYMSTORE", "-DFWG_ABL_NO_SIMSTORE", "-DFWG_ABL_NO_SIM", "-DFWG_ABL_NO_LAG"]}
+# default: the preset list; NAME="-DFLAG ..." arguments replace it
+VARIANTS = dict(PRESETS) if not any("=" in a for a in sys.argv[1:]) else {}
 VARIANTS.update({k: v.split() for k, v in (a.split("=", 1) for a in sys.argv[1:] if "=" in a)})
 
 def build():
