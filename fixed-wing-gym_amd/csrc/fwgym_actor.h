@@ -235,10 +235,13 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     float* mean_s = lds + 2 * PARTS * nf * 64 * 4;                  // [64]
     float* rstd_s = mean_s + FWG_ACT_MAX_OBS;                       // [64]
     float* misc = rstd_s + FWG_ACT_MAX_OBS;                         // [0] = 1/sqrt(ret_var + eps)
+    // packed weights HBM/L2 -> LDS without a register round trip (global_load_lds, 1 KiB per wave instruction): in
+    // flight while the statistics are folded and the observations normalised, waited for before the first MFMA
     for (int net = 0; net < 2; ++net)
         for (int part = 0; part < PARTS; ++part)
-            for (int i = tid; i < nf * 64; i += 64 * FWG_ACT_WAVES)
-                F[(net * PARTS + part) * nf * 64 + i] = A.frags[(net * 2 + part) * nf * 64 + i];
+            for (int fr = wv; fr < nf; fr += FWG_ACT_WAVES)
+                dma_group(reinterpret_cast<const float4*>(A.frags + ((net * 2 + part) * nf + fr) * 64 + l),
+                          reinterpret_cast<float*>(F + ((net * PARTS + part) * nf + fr) * 64));
     {   // add the accumulator shards (integers: exact, order-free) and fold the batch into the running statistics (the
         // parallel-variance update of VecNormalize's RunningMeanStd).  Every block computes the same values; block 0
         // publishes them and clears the other parity's accumulators for the launches that follow
@@ -332,13 +335,12 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
         }
         split8(x, bx_hi[kk], bx_lo[kk]);
     }
-    float res[2][FWG_ACT_MAX_ACT];
-#pragma unroll 1
-    for (int net = 0; net < 2; ++net) {   // pi, then vf: one copy of the code, registers reused
-        const f32x16 o = mlp_forward<SPLIT, NK1>(F + net * PARTS * nf * 64, l, bx_hi, bx_lo);
-#pragma unroll
-        for (int i = 0; i < FWG_ACT_MAX_ACT; ++i) res[net][i] = o[i];
-    }
+    dma_wait();
+    __syncthreads();
+    // both networks in one instruction stream: their MFMA chains and tanh phases are independent and interleave
+    const f32x16 o_pi = mlp_forward<SPLIT, NK1>(F, l, bx_hi, bx_lo);
+    const f32x16 o_vf = mlp_forward<SPLIT, NK1>(F + PARTS * nf * 64, l, bx_hi, bx_lo);
+    const float res[2][FWG_ACT_MAX_ACT] = {{o_pi[0], o_pi[1], o_pi[2], o_pi[3]}, {o_vf[0], o_vf[1], o_vf[2], o_vf[3]}};
     if (half == 0 && valid) {
         float n[4] = {0.f, 0.f, 0.f, 0.f};
         if (!A.deterministic) {

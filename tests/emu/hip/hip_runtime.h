@@ -96,7 +96,7 @@ static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x
 #define __builtin_amdgcn_sinf(x) sinf(6.28318530717958647692f * (x))
 #define __builtin_amdgcn_cosf(x) cosf(6.28318530717958647692f * (x))
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
-    memcpy((char*)(l) + threadIdx.x * (size), (const void*)(g), (size))
+    memcpy((char*)(l) + (threadIdx.x & 63u) * (size), (const void*)(g), (size))
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
