@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollout", default="auto", choices=["auto", "none", "fused"],
+                    help="c5 only: 'fused' (default for c5) = env step + HIP rollout head (VecNormalize + MlpPolicy + "
+                         "sampling), replayed from one hipGraph per chunk of steps; 'none' = env step on stored actions")
     args = ap.parse_args()
 
     import torch
@@ -117,7 +120,28 @@ def main():
             red_dev.copy_(torch.as_tensor(red, dtype=torch.float32))
             dist.all_gather_into_tensor(gathered, red_dev)   # RCCL over xGMI: 64 B per rank
 
+    fused = args.workload == "c5" and args.rollout != "none"
+    rollout = None
+    if fused:   # BASELINE configs[4]: PPO rollout loop with a random-init 64-64 MlpPolicy, end to end
+        from gym_fixed_wing.actor import DeviceActor
+        from gym_fixed_wing.rollout import FusedRollout, MlpPolicy
+        chunk = next((c for c in (128, 64, 32, 16, 8, 4, 2) if args.steps % c == 0 and args.warmup % c == 0), 0)
+        if chunk == 0:
+            raise SystemExit("--workload c5: --steps and --warmup must be even (hipGraph chunks)")
+        torch.manual_seed(0)
+        actor = DeviceActor.for_env(vec, seed=7, env_id_base=rank * n_envs)
+        actor.load_policy(MlpPolicy(vec.obs_dim))
+        rollout = FusedRollout(vec, actor, chunk, graph=True)
+
     def run(k, t_offset):
+        if fused:
+            done_steps = 0
+            for _ in range(k // rollout.n_steps):
+                rollout.run()
+                done_steps += rollout.n_steps
+                if done_steps % REDUCE_EVERY == 0:
+                    reduce_step()
+            return
         for t in range(k):
             vec.step_device(pool[(t_offset + t) % len(pool)])
             if (t + 1) % REDUCE_EVERY == 0:
@@ -149,7 +173,7 @@ def main():
     for t in range(64):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        vec.step_device(pool[t % len(pool)])
+        vec.step_device(rollout.cur["actions"] if fused else pool[t % len(pool)])
         b.record()
         durs.append((a, b))
     torch.cuda.synchronize(dev)
@@ -177,12 +201,14 @@ def main():
             "config": {"workload": desc, "envs_per_gpu": n_envs, "total_envs": total_envs,
                        "rk4_substeps": int(vec._c.n_substeps), "actuator_microsteps": int(vec._c.actuator_microsteps),
                        "specialised_kernel": vec.spec_index >= 0, "derived_views": False,
+                       "rollout_head": ("HIP VecNormalize + 64-64 MlpPolicy (bf16 MFMA, split operands) + sampling, "
+                                        "hipGraph chunks of {} steps".format(rollout.n_steps)) if fused else None,
                        "success_allgather_every": REDUCE_EVERY},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["bytes_per_launch"] if traffic else None,
                          "traffic_source": traffic["source"] if traffic else None,
-                         "kernel": "k_step", "kernel_ms": region_ms, "kernel_ms_isolated": kern_ms,
+                         "kernel": "k_step + k_actor_act" if fused else "k_step", "kernel_ms": region_ms, "kernel_ms_isolated": kern_ms,
                          "algorithmic_bytes_per_env_step": ALG_BYTES[args.workload]},
         }
         if not args.no_cpu_baseline:

@@ -237,11 +237,13 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     float* misc = rstd_s + FWG_ACT_MAX_OBS;                         // [0] = 1/sqrt(ret_var + eps)
     // packed weights HBM/L2 -> LDS without a register round trip (global_load_lds, 1 KiB per wave instruction): in
     // flight while the statistics are folded and the observations normalised, waited for before the first MFMA
+#ifndef FWG_ABL_ACT_NO_STAGE
     for (int net = 0; net < 2; ++net)
         for (int part = 0; part < PARTS; ++part)
             for (int fr = wv; fr < nf; fr += FWG_ACT_WAVES)
                 dma_group(reinterpret_cast<const float4*>(A.frags + ((net * 2 + part) * nf + fr) * 64 + l),
                           reinterpret_cast<float*>(F + ((net * PARTS + part) * nf + fr) * 64));
+#endif
     {   // add the accumulator shards (integers: exact, order-free) and fold the batch into the running statistics (the
         // parallel-variance update of VecNormalize's RunningMeanStd).  Every block computes the same values; block 0
         // publishes them and clears the other parity's accumulators for the launches that follow
@@ -338,8 +340,13 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     dma_wait();
     __syncthreads();
     // both networks in one instruction stream: their MFMA chains and tanh phases are independent and interleave
+#ifdef FWG_ABL_ACT_NO_MLP   // measurement only (tools/ablate.py)
+    f32x16 o_pi = {0.f}, o_vf = {0.f};
+    o_pi[0] = __uint_as_float(bx_hi[0].x ^ F[l].x); o_vf[0] = __uint_as_float(bx_lo[0].y);
+#else
     const f32x16 o_pi = mlp_forward<SPLIT, NK1>(F, l, bx_hi, bx_lo);
     const f32x16 o_vf = mlp_forward<SPLIT, NK1>(F + PARTS * nf * 64, l, bx_hi, bx_lo);
+#endif
     const float res[2][FWG_ACT_MAX_ACT] = {{o_pi[0], o_pi[1], o_pi[2], o_pi[3]}, {o_vf[0], o_vf[1], o_vf[2], o_vf[3]}};
     if (half == 0 && valid) {
         float n[4] = {0.f, 0.f, 0.f, 0.f};

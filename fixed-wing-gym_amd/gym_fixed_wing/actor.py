@@ -34,6 +34,11 @@ def weights_from_stable_baselines(params):
     shipped examples/models/mlp_controller, tests/golden/mlp_controller.json) -> torch layout [out][in]."""
     g = lambda k: np.asarray(params[k], dtype=np.float32)
     out = {}
+    if "vf_fc0_w" not in params:   # policy-only export (evaluation): a zero value network
+        params = dict(params)
+        d = np.asarray(params["pi_fc0_w"]).shape[0]
+        params.update({"vf_fc0_w": np.zeros((d, 64)), "vf_fc0_b": np.zeros(64), "vf_fc1_w": np.zeros((64, 64)),
+                       "vf_fc1_b": np.zeros(64), "vf_w": np.zeros((64, 1)), "vf_b": np.zeros(1)})
     for net, last in (("pi", "pi"), ("vf", "vf")):
         out[net + "_w0"] = g(net + "_fc0_w").T.copy(); out[net + "_b0"] = g(net + "_fc0_b")
         out[net + "_w1"] = g(net + "_fc1_w").T.copy(); out[net + "_b1"] = g(net + "_fc1_b")

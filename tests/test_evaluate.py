@@ -119,3 +119,16 @@ def test_shipped_mlp_controller_flies_the_shipped_test_set():
     with open(os.path.join(os.path.dirname(HERE), "gpurun_out", "mlp_eval_report.json"), "w") as f:
         json.dump(report, f, indent=1)
     assert table["success_%"]["all"] >= 80.0
+    # the same controller through the HIP rollout head (fwg_actor_act, statistics frozen, deterministic): the matrix-core
+    # MLP must fly the same episodes as the torch fp32 formulation above
+    from gym_fixed_wing.actor import DeviceActor, weights_from_stable_baselines
+    actor = DeviceActor(len(_scenarios()), 12, training=False, device=0)
+    actor.load_policy(weights_from_stable_baselines(m["weights"]))
+    actor.set_stats(m["obs_rms"]["mean"], m["obs_rms"]["var"], 1e6)
+    res2 = ev.evaluate_on_set(_scenarios(), cfg, policy=lambda obs: actor.act(obs.reshape(obs.shape[0], -1).contiguous(), deterministic=True)[1], device=0)
+    table2 = ev.summarize(res2)
+    lengths2 = np.array([len(r) for r in res2["rewards"]])
+    print("HIP head: success", table2["success_%"], "episodes with another length:", int((lengths2 != lengths).sum()))
+    assert table2["success_%"]["all"] == table["success_%"]["all"]
+    assert np.mean(np.abs(lengths2 - lengths)) < 2.0
+    np.testing.assert_allclose(table2["settling_time"]["all"], table["settling_time"]["all"], rtol=0.02)
