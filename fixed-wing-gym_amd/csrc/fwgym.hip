@@ -282,7 +282,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
                 E.emin[k] = fminf(E.emin[k], err[k]); E.emax[k] = fmaxf(E.emax[k], err[k]);
                 E.perr[k] = err[k];
             }
-            if (valid) GROUP(A.S, A.N, (L.end_ring >> 2) + A.slot_end, e) = make_float4(err[0], err[1], err[2], 0.f);
+            if (valid) store_group_once(A.S, A.N, (L.end_ring >> 2) + A.slot_end, e, make_float4(err[0], err[1], err[2], 0.f));
         }
     } else {
         done = true;

@@ -152,8 +152,18 @@ typedef __attribute__((address_space(1))) const void* fwg_gptr;
 typedef __attribute__((address_space(3))) void* fwg_lptr;
 
 // async HBM -> LDS copy of one 16-byte group per lane (1 KiB per wave, landing as [lane][4]) -- global_load_lds_dwordx4
+#ifndef FWG_RING_AUX
+#define FWG_RING_AUX 0
+#endif
 __device__ __forceinline__ void dma_group(const float4* src_lane_ptr, float* lds_dst) {
-    __builtin_amdgcn_global_load_lds((fwg_gptr)src_lane_ptr, (fwg_lptr)lds_dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((fwg_gptr)src_lane_ptr, (fwg_lptr)lds_dst, 16, 0, FWG_RING_AUX);
+}
+#ifndef FWG_LAG_AUX
+#define FWG_LAG_AUX 2   /* nt: measured -1.0 us per C3 step (65 536 envs) against 0, no gain for the rings or state rows */
+#endif
+// same, for data read once per launch (lagged observation rows): cache-policy bits as a build-time experiment knob
+__device__ __forceinline__ void dma_group_once(const float4* src_lane_ptr, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((fwg_gptr)src_lane_ptr, (fwg_lptr)lds_dst, 16, 0, FWG_LAG_AUX);
 }
 // the compiler does not order LDS reads behind an in-flight global_load_lds: drain the vector-memory counter by hand
 #ifndef FWG_DMA_DRAIN
