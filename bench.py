@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--obs-layout", default="dense", choices=["dense", "log"],
+                    help="c3: 'dense' = fwg_step writes the [N][5][12] batch (default); 'log' = observation history kept "
+                         "once as a row log, the observation is a zero-copy strided window of it (same values)")
     ap.add_argument("--rollout", default="auto", choices=["auto", "none", "fused"],
                     help="c5 only: 'fused' (default for c5) = env step + HIP rollout head (VecNormalize + MlpPolicy + "
                          "sampling), replayed from one hipGraph per chunk of steps; 'none' = env step on stored actions")
@@ -105,8 +108,10 @@ def main():
         n_envs = args.envs
     # derived_views=False: the rollout loop never reads roll/pitch/... back from the arena (they are in the
     # observations), so the kernel does not write those host-view rows
+    from gym_fixed_wing import presets as _presets
+    log_rows = _presets.OBS_LOG_ROWS if (args.obs_layout == "log" and args.workload == "c3") else 0
     vec = FixedWingVecEnv(cfg, num_envs=n_envs, device=local, config_kw=ckw, sim_config_kw=skw, seed=0,
-                          env_id_base=rank * n_envs, auto_reset=True, derived_views=False)
+                          env_id_base=rank * n_envs, auto_reset=True, derived_views=False, obs_log_rows=log_rows)
     vec.reset()
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -201,6 +206,7 @@ def main():
             "config": {"workload": desc, "envs_per_gpu": n_envs, "total_envs": total_envs,
                        "rk4_substeps": int(vec._c.n_substeps), "actuator_microsteps": int(vec._c.actuator_microsteps),
                        "specialised_kernel": vec.spec_index >= 0, "derived_views": False,
+                       "obs_layout": "row log [obs_step][{}][N][12] + zero-copy window".format(log_rows) if log_rows else "dense batch",
                        "rollout_head": ("HIP VecNormalize + 64-64 MlpPolicy (bf16 MFMA, split operands) + sampling, "
                                         "hipGraph chunks of {} steps".format(rollout.n_steps)) if fused else None,
                        "success_allgather_every": REDUCE_EVERY},

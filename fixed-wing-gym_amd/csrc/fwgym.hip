@@ -126,7 +126,8 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     if (c.use_cmd_ring)
         for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
 #ifndef FWG_ABL_NO_LAG
-    stream_lag_rows(c, A, e, lds + M.lag);
+    if (c.obs_log == 0) stream_lag_rows(c, A, e, lds + M.lag);
+    else log_wrap(c, A.obs, A.N, e, A.gnow, valid);
 #endif
 #ifdef FWG_ABL_NO_SIM
     const int fail = 0;
@@ -303,11 +304,18 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 
     // ---- phase D: observation (fixed_wing.py:776-846)
 #ifndef FWG_ABL_NO_LAG
-    load_lag_rows(c, lds + M.lag + lane * 4, ob);
+    if (c.obs_log == 0) load_lag_rows(c, lds + M.lag + lane * 4, ob);
 #endif
-    build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid, A.slot_act);
-    if (c.obs_length > 1 && (!ok || (int)E.steps <= (c.obs_length - 1) * c.obs_step))
-        fix_lagged_rows(c, A, e, E, T, ob, ok);
+    build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid && c.obs_log == 0, A.slot_act);
+    // row-log mode: the lagged rows stay where they are; only lanes that need the COMPLETE record in registers (episode
+    // end: terminal observation) read them back, and only early-episode / failed lanes compute rows of their own
+    const bool early = c.obs_length > 1 && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
+    const unsigned log_pad_t = E.steps;   // rows with lag >= this are padding (valid for lanes that do not finish)
+    const long long log_win = c.obs_log > 0 ? log_plane(c.obs_step, c.obs_log, c.obs_length, A.gnow, A.gnow) : 0;   // wave-uniform
+    if (c.obs_log > 0 && __ballot((done || !ok) && valid) != 0ull) {
+        if ((done || !ok) && valid) log_load_rows(c, A.obs, A.N, e, log_win, ob);
+    }
+    if (c.obs_length > 1 && (!ok || early)) fix_lagged_rows(c, A, e, E, T, ob, ok);
     if (c.obs_noise) add_obs_noise(c, A, e, E, ob);
 
     // ---- phase E: episode end -- metrics block, success reduction, terminal observation, auto-reset
@@ -392,7 +400,17 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 
     // ---- phase F: outputs and the state write-back
 #ifndef FWG_ABL_NO_OBSWRITE
-    write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull);
+    if (c.obs_log == 0) {
+        write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull);
+    } else {
+        if (valid) log_store_row(c, A.obs, A.N, e, log_win, 0, ob);   // the new record: 64 consecutive rows per wave
+        if (__ballot((done || early) && valid) != 0ull) {
+#pragma unroll
+            for (int r = 1; r < FWG_MAX_ROWS; ++r)
+                if (r < c.obs_length && valid && (done || (early && r * c.obs_step >= (int)log_pad_t)))
+                    log_store_row(c, A.obs, A.N, e, log_win, r, ob);
+        }
+    }
 #else
     if (ob.get(0) == 1.2345e30f) A.obs[e] = ob.get(1) + ob.get(c.obs_dim - 1);
 #endif
@@ -461,7 +479,14 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
         E.episode = f2u(w.w); E.flags = f2u(f.x);
     }
     if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane * 4, A.slot_end, A.slot_lag, A.bit_goal);
-    write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
+    if (c.obs_log == 0) {
+        write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
+    } else if (sel) {
+        const long long win = log_plane(c.obs_step, c.obs_log, c.obs_length, A.gnow, A.gnow);
+#pragma unroll
+        for (int r = 0; r < FWG_MAX_ROWS; ++r)
+            if (r < c.obs_length) log_store_row(c, A.obs, A.N, e, win, r, ob);
+    }
     if (sel) {
         store_sim<TURB>(c, A.S, A.N, e, E);
         store_gym(c, A.S, A.N, e, E, A.bit_goal);
@@ -543,7 +568,13 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
     L->act_ring = o; o += window * 4;    // raw actions, one group per slot, slot = global_step % window
     L->cmd_ring = o; o += use_cmd ? window * 4 : 0;
     L->end_ring = o; o += FWG_END_WINDOW * 4;
-    L->lag_depth = c.obs_length > 1 ? (c.obs_length - 1) * c.obs_step + 1 : 0;
+    if (c.obs_log_rows != 0) {
+        if (c.obs_length < 2) { *why = "obs_log_rows needs a lagged (matrix) observation"; return -1; }
+        if (c.obs_noise) { *why = "obs_log_rows: observation noise re-draws every row each step, use the dense batch"; return -1; }
+        if (c.obs_log_rows < 2 * (c.obs_length - 1) || c.obs_log_rows > 4096) { *why = "obs_log_rows must be in [2 (obs_length - 1), 4096]"; return -1; }
+    }
+    // dense batch: ring of the last (length - 1) * step + 1 records; row log: one slot holding the episode's record 0
+    L->lag_depth = c.obs_length > 1 ? (c.obs_log_rows != 0 ? 1 : (c.obs_length - 1) * c.obs_step + 1) : 0;
     L->lag_groups = (c.n_obs + 3) / 4;
     L->lag_ring = o; o += L->lag_depth * L->lag_groups * 4;
     L->window = window;
@@ -695,6 +726,7 @@ static int lower_config(const fwg_config& c, DevCfg* d, DynCfg* dy, std::string*
                                  f32(F.max), f32(F.value)};
     }
     d->metrics = c.metrics; d->auto_reset = c.auto_reset; d->use_cmd_ring = use_cmd; d->store_derived = c.store_derived;
+    d->obs_log = c.obs_log_rows;
     d->rise_low = f32(c.rise_low); d->rise_high = f32(c.rise_high);
     return 0;
 }
@@ -794,6 +826,7 @@ static inline int pmod(int64_t a, int m) { return m > 0 ? (int)(((a % m) + m) % 
 
 static void fill_slots(const fwg_handle* h, int64_t g, KArgs* A) {
     const DevCfg& d = h->h;
+    A->gnow = g;
     A->slot_act = pmod(g, d.L.window);
     A->slot_end = pmod(g, FWG_END_WINDOW);
     A->slot_lag = pmod(g, d.L.lag_depth);
@@ -834,6 +867,19 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
     launch<true>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     h->gstep += 1;
+    return FWG_OK;
+}
+
+int64_t fwg_obs_log_floats(const fwg_config* cfg, int64_t n_envs) {
+    if (!cfg || cfg->obs_log_rows <= 0) return 0;
+    return (int64_t)cfg->obs_step * cfg->obs_log_rows * n_envs * cfg->n_obs;
+}
+
+int fwg_obs_window(const fwg_handle* h, int64_t* plane) {
+    if (!h || !plane) return fail_with(FWG_ERR_INVALID, "fwg_obs_window: null argument");
+    if (h->h.obs_log <= 0) return fail_with(FWG_ERR_INVALID, "fwg_obs_window: the env writes the dense observation batch");
+    const long long g = h->gstep - 1;   // last completed step
+    *plane = log_plane(h->h.obs_step, h->h.obs_log, h->h.obs_length, g, g);
     return FWG_OK;
 }
 
@@ -986,6 +1032,8 @@ extern "C" {
 
 int fwg_attach_observer(fwg_handle* h, fwg_actor* a) {
     if (!h) return fail_with(FWG_ERR_INVALID, "fwg_attach_observer: null env handle");
+    if (a && h->h.obs_log > 0)
+        return fail_with(FWG_ERR_INVALID, "fwg_attach_observer: row-log observations keep the lagged rows out of the step kernel; use fwg_actor_observe");
     if (a && (a->n_envs != h->n_envs || a->D != h->h.obs_dim || a->device != h->device))
         return fail_with(FWG_ERR_INVALID, "fwg_attach_observer: the head was created for another batch size / observation size / device");
     h->observer = a;

@@ -69,6 +69,7 @@ struct DevCfg {
     int n_factors;
     DevFactor factor[FWG_MAX_FACTORS];
     int metrics, auto_reset, use_cmd_ring, store_derived;
+    int obs_log;   // rows per parity of the observation row log (0 = dense observation batch)
     float rise_low, rise_high;
     fwg_layout L;
 };

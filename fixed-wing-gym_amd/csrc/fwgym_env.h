@@ -29,6 +29,7 @@ struct KArgs {
     const long long* gstep_in;
     long long* gstep_out;
     int reset_launch;                            // k_reset: positions refer to the LAST completed step (counter - 1)
+    long long gnow;                              // global index of the step this launch refers to (row-log positions)
     // attached rollout head (fwg_attach_observer): every wave also adds the moments of its 64 observation records and
     // discounted returns to the head's accumulators (acc_*), so the head needs no pass over the batch
     unsigned long long* acc;                     // nullable [FWG_ACC_SHARDS][acc_cols] fixed-point sums
@@ -110,6 +111,7 @@ __device__ __forceinline__ KArgs resolve_slots(const DevCfg& c, const KArgs& A0)
     KArgs A = A0;
     if (A0.gstep_in != nullptr) {
         const long long g = *A0.gstep_in - (A0.reset_launch ? 1 : 0);
+        A.gnow = g;
         A.slot_act = dev_pmod(g, c.L.window);
         A.slot_end = dev_pmod(g, FWG_END_WINDOW);
         A.slot_lag = dev_pmod(g, c.L.lag_depth);
@@ -118,6 +120,66 @@ __device__ __forceinline__ KArgs resolve_slots(const DevCfg& c, const KArgs& A0)
         for (int r = 0; r < FWG_MAX_ROWS; ++r) A.lag_slots[r] = dev_pmod(g - (long long)r * c.obs_step, c.L.lag_depth);
     }
     return A;
+}
+
+// ---- observation row log (DevCfg::obs_log = L > 0, include/fwgym.h "Row-log observations"): float [obs_step][L][N][n_obs].
+// A parity (global step mod obs_step) appends its records in DESCENDING row order from row P - 1 down to 0,
+// P = L - (length - 1); the step that would run off the top first copies the length - 1 newest rows (0 .. length-2) to
+// rows P .. L-1, so the window [newest, newest + length) is always contiguous.
+__host__ __device__ inline long long log_fdiv(long long a, int b) { const long long q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; }
+__host__ __device__ inline int log_pmod(long long a, int m) { return (int)(((a % m) + m) % m); }
+// plane (row index over all parities) holding the record of global step gp, as seen at global step g >= gp
+__host__ __device__ inline long long log_plane(int S, int L, int len, long long g, long long gp) {
+    const int P = L - (len - 1);
+    const int p = log_pmod(gp, S);
+    const long long qp = log_fdiv(gp, S);
+    const long long qc = log_fdiv(g - log_pmod(g - p, S), S);   // newest step of that parity not after g
+    return (long long)p * L + (P - 1 - log_pmod(qp, P)) + (long long)P * (log_fdiv(qc, P) - log_fdiv(qp, P));
+}
+__device__ __forceinline__ float* log_row(const DevCfg& c, float* log, long N, long e, long long plane) {
+    return log + ((plane * N + e) * c.n_obs);
+}
+// record r (0 = newest) of the observation record `ob` -> row r of the window starting at plane `win`
+template <class OB>
+__device__ __forceinline__ void log_store_row(const DevCfg& c, float* log, long N, long e, long long win, int r, const OB& ob) {
+    float* row = log_row(c, log, N, e, win + r);
+    if ((c.n_obs & 3) == 0) {
+#pragma unroll
+        for (int q = 0; q < FWG_MAX_OBS / 4; ++q)
+            if (4 * q < c.n_obs)
+                reinterpret_cast<float4*>(row)[q] = make_float4(ob.get(r * c.n_obs + 4 * q), ob.get(r * c.n_obs + 4 * q + 1),
+                                                                ob.get(r * c.n_obs + 4 * q + 2), ob.get(r * c.n_obs + 4 * q + 3));
+    } else {
+#pragma unroll
+        for (int j = 0; j < FWG_MAX_OBS; ++j)
+            if (j < c.n_obs) row[j] = ob.get(r * c.n_obs + j);
+    }
+}
+// rows r >= 1 of the window starting at plane `win` (the records of steps g - r obs_step) -> ob (rare per-lane reads)
+template <class OB>
+__device__ __forceinline__ void log_load_rows(const DevCfg& c, const float* log, long N, long e, long long win, OB& ob) {
+#pragma unroll
+    for (int r = 1; r < FWG_MAX_ROWS; ++r) {
+        if (r < c.obs_length) {
+            const float* row = log + (((win + r) * N + e) * c.n_obs);
+#pragma unroll
+            for (int j = 0; j < FWG_MAX_OBS; ++j)
+                if (j < c.n_obs) ob.put(r * c.n_obs + j, row[j]);
+        }
+    }
+}
+// the parity's wrap step: carry the length - 1 newest rows to the top of the log (all lanes, coalesced per row)
+__device__ __forceinline__ void log_wrap(const DevCfg& c, float* log, long N, long e, long long g, bool valid) {
+    const int S = c.obs_step, L = c.obs_log, P = L - (c.obs_length - 1);
+    if (log_pmod(log_fdiv(g, S), P) != 0) return;   // wave-uniform
+    const long long base = (long long)log_pmod(g, S) * L;
+    if (valid) {
+        for (int r = 0; r < c.obs_length - 1; ++r) {
+            const float* src = log + (((base + r) * N + e) * c.n_obs);
+            float* dst = log + (((base + P + r) * N + e) * c.n_obs);
+            for (int j = 0; j < c.n_obs; ++j) dst[j] = src[j];
+        }
+    }
 }
 
 // LDS carve (in floats) for one 64-lane block: the action windows (streamed in by global_load_lds) and, for the
@@ -566,6 +628,7 @@ __device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A,
             const unsigned bits = (r & 3) == 0 ? b.x : ((r & 3) == 1 ? b.y : ((r & 3) == 2 ? b.z : b.w));
             const float noise = (2.f * u01(bits) - 1.f) * c.dt;
             int slot0 = A.slot_lag - t; slot0 += (slot0 < 0) ? depth : 0;  // ring slot of the episode's record 0
+            if (c.obs_log > 0) slot0 = 0;   // row-log mode: the ring has one slot and holds exactly that record
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j) {
                 if (j >= c.n_obs) continue;
@@ -581,10 +644,13 @@ __device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A,
             }
         } else if (!ok) {
             int slot = A.slot_lag - 1 - lag; slot += (slot < 0) ? depth : 0;
+            const float* older = c.obs_log > 0 ? A.obs + ((log_plane(c.obs_step, c.obs_log, c.obs_length, A.gnow, A.gnow - 1 - lag) * A.N + e) * c.n_obs)
+                                               : nullptr;
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j)
                 if (j < c.n_obs && c.obs[j].type != FWG_OBS_ACTION)
-                    ob.put(r * c.n_obs + j, lag_entry(c, A, e, slot, j));
+                    // (the episode's record 0 sits in the log with its reset-time noise; the clean copy is in the ring slot)
+                    ob.put(r * c.n_obs + j, c.obs_log > 0 ? (lag == t - 1 ? lag_entry(c, A, e, 0, j) : older[j]) : lag_entry(c, A, e, slot, j));
         }
     }
 }

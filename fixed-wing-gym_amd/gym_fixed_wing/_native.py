@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 10
+FWG_ABI_VERSION = 11
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -107,7 +107,7 @@ class Config(C.Structure):
         ("term_present", C.c_int32 * 3), ("n_factors", C.c_int32),
         ("term_weight", C.c_double * 3),
         ("factor", FactorDesc * MAX_FACTORS),
-        ("metrics", C.c_int32), ("auto_reset", C.c_int32), ("store_derived", C.c_int32), ("pad_tail_", C.c_int32),
+        ("metrics", C.c_int32), ("auto_reset", C.c_int32), ("store_derived", C.c_int32), ("obs_log_rows", C.c_int32),
         ("rise_low", C.c_double), ("rise_high", C.c_double),
     ]
 
@@ -142,7 +142,7 @@ EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fw
            "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index", "fwg_set_graph_mode", "fwg_note_replayed_steps",
            "fwg_capture_begin", "fwg_capture_end", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
            "fwg_actor_set_stats", "fwg_actor_get_stats", "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe",
-           "fwg_actor_act", "fwg_attach_observer"]
+           "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window"]
 _libs = {}
 
 
@@ -202,6 +202,10 @@ def load_library(path=None):
     lib.fwg_actor_configure.argtypes = [vp, C.c_int, C.c_int]
     lib.fwg_actor_seed.argtypes = [vp, u64, i64]
     lib.fwg_actor_observe.argtypes = [vp, vp, vp, vp, vp]
+    lib.fwg_obs_log_floats.argtypes = [C.POINTER(Config), i64]
+    lib.fwg_obs_log_floats.restype = i64
+    lib.fwg_obs_window.argtypes = [vp, C.POINTER(i64)]
+    lib.fwg_obs_window.restype = C.c_int
     lib.fwg_attach_observer.argtypes = [vp, vp]
     lib.fwg_attach_observer.restype = C.c_int
     lib.fwg_actor_act.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]

@@ -308,7 +308,7 @@ class EnvConfig(object):
         self.target_props_init = init
 
     # ------------------------------------------------------------------------------------------------------------------
-    def compile(self, auto_reset=True, store_derived=True):
+    def compile(self, auto_reset=True, store_derived=True, obs_log_rows=0):
         """-> _native.Config"""
         cfg, c = self.cfg, nat.Config()
         c.abi_version, c.struct_bytes = nat.FWG_ABI_VERSION, nat.C.sizeof(nat.Config)
@@ -480,4 +480,5 @@ class EnvConfig(object):
                 c.rise_low, c.rise_high = float(m.get("low", 0.1)), float(m.get("high", 0.9))
         c.auto_reset = int(bool(auto_reset))
         c.store_derived = int(bool(store_derived))
+        c.obs_log_rows = int(obs_log_rows)
         return c

@@ -86,7 +86,10 @@ SPECIALISED = [
     ("c2_default_lean", "default", None, None),
     ("c3_cnn_step2_dryden_lean", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),
     ("c5_examples_lean", "examples", None, None),
+    # "_log": observation history as a row log + zero-copy window (FixedWingVecEnv(obs_log_rows=OBS_LOG_ROWS))
+    ("c3_cnn_step2_dryden_lean_log", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),
 ]
+OBS_LOG_ROWS = 32
 
 
 def workload(name):

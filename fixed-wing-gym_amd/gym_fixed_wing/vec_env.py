@@ -90,7 +90,7 @@ class LazyInfos(object):
 class FixedWingVecEnv(object):
     def __init__(self, config_path=None, num_envs=1, device=0, sim_config_path=None, sim_parameter_path=None,
                  config_kw=None, sim_config_kw=None, auto_reset=True, as_numpy=False, env_id_base=0, seed=0,
-                 derived_views=True, specialize=None, _backend=None, _lib_path=None):
+                 derived_views=True, specialize=None, obs_log_rows=0, _backend=None, _lib_path=None):
         self.env_config = EnvConfig(config_path, sim_config_path, sim_parameter_path, config_kw, sim_config_kw)
         self.cfg = self.env_config.cfg
         self.num_envs = int(num_envs)
@@ -110,14 +110,19 @@ class FixedWingVecEnv(object):
         self.target_names = list(ec.target_names)
         self.dt = ec.dt
 
-        self._c = ec.compile(auto_reset=auto_reset, store_derived=self.derived_views)
+        # obs_log_rows = L > 0 (matrix observations, no observation noise): the observation history is kept once, as a
+        # row log, and the observation handed out is a zero-copy strided view of it (include/fwgym.h "Row-log
+        # observations"): same values, 432 B/env-step less traffic at C3.  .contiguous() gives the dense batch.
+        self.obs_log_rows = int(obs_log_rows)
+        self._c = ec.compile(auto_reset=auto_reset, store_derived=self.derived_views, obs_log_rows=self.obs_log_rows)
         # configurations outside the build-time presets run the generic kernel unless a specialised copy of the
         # library is compiled for them (opt-in: specialize=True or FWGYM_JIT=1; see jit.py)
         if specialize is None:
             specialize = os.environ.get("FWGYM_JIT", "0") == "1"
         if specialize and _lib_path is None and not self._preset_matches():
             from . import jit
-            path = jit.specialised_library(ec, auto_reset=auto_reset, store_derived=self.derived_views, base_lib=self._lib)
+            path = jit.specialised_library(ec, auto_reset=auto_reset, store_derived=self.derived_views, base_lib=self._lib,
+                                           obs_log_rows=self.obs_log_rows)
             if path is not None:
                 self._lib = nat.load_library(path)
         self.layout = nat.Layout()
@@ -126,6 +131,10 @@ class FixedWingVecEnv(object):
         # state arena: 16-byte groups [rows/4][env][4] (word w of env e = state[w >> 2, e, w & 3]); zero = "never reset"
         self.state = m.zeros((self.layout.rows // 4, N, 4))
         self._obs = m.zeros((N, self.obs_dim))
+        self._obs_buf = self._obs          # what fwg_reset / fwg_step write: the dense batch, or the row log
+        if self.obs_log_rows:
+            n_log = int(self._lib.fwg_obs_log_floats(ctypes.byref(self._c), N))
+            self._obs_buf = m.zeros((n_log // (N * self._c.n_obs), N, self._c.n_obs))   # [obs_step * L][N][n_obs]
         self._rew = m.zeros((N,))
         self._done = m.zeros((N,), "u8")
         self._term = m.zeros((N,), "u8")
@@ -170,7 +179,7 @@ class FixedWingVecEnv(object):
         if n == 0:
             return False
         from . import specialize as sp
-        return sp.spec_words(self._lib, self.env_config, self.auto_reset, self.derived_views) in self._preset_words()
+        return sp.spec_words(self._lib, self.env_config, self.auto_reset, self.derived_views, self.obs_log_rows) in self._preset_words()
 
     def _preset_words(self):
         cache = FixedWingVecEnv.__dict__.get("_preset_cache")
@@ -180,7 +189,8 @@ class FixedWingVecEnv(object):
             cache = []
             for name, kind, ckw, skw in presets.SPECIALISED:
                 ec = EnvConfig(presets.preset(kind), config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
-                cache.append(sp.spec_words(self._lib, ec, True, not name.endswith("_lean")))
+                cache.append(sp.spec_words(self._lib, ec, True, "_lean" not in name,
+                                           presets.OBS_LOG_ROWS if name.endswith("_log") else 0))
             FixedWingVecEnv._preset_cache = cache
         return cache
 
@@ -256,20 +266,32 @@ class FixedWingVecEnv(object):
         null = ctypes.c_void_p()
         nat.check(self._lib, self._lib.fwg_reset(self._handle, m.ptr(mask_t) if mask_t is not None else null,
                                                  m.ptr(st) if st is not None else null,
-                                                 m.ptr(tg) if tg is not None else null, m.ptr(self._obs), m.stream()))
+                                                 m.ptr(tg) if tg is not None else null, m.ptr(self._obs_buf), m.stream()))
+        self._refresh_obs_view()
         if st is not None or tg is not None or mask_t is not None:
             m.sync()  # the temporaries above must outlive the launch
         del n_sel
         return self._out(self._obs, (N,) + self.obs_shape)
+
+    def _refresh_obs_view(self):
+        """Row-log mode: the current observation is the window [plane, plane + length) of the log, env-major view
+        [N, length, n_obs] (zero-copy; valid until the next step/reset)."""
+        if not self.obs_log_rows:
+            return
+        plane = ctypes.c_int64()
+        nat.check(self._lib, self._lib.fwg_obs_window(self._handle, ctypes.byref(plane)))
+        win = self._obs_buf[plane.value:plane.value + self._c.obs_length]
+        self._obs = win.permute(1, 0, 2) if hasattr(win, "permute") else win.transpose(1, 0, 2)
 
     def step_async(self, actions):
         m = self._mem
         act = m.as_device(actions).reshape(self.num_envs, 3)
         if self.check_actions:
             nat.check(self._lib, self._lib.fwg_check_actions(self._handle, m.ptr(act), m.stream()))
-        nat.check(self._lib, self._lib.fwg_step(self._handle, m.ptr(act), m.ptr(self._obs), m.ptr(self._rew), m.ptr(self._done),
+        nat.check(self._lib, self._lib.fwg_step(self._handle, m.ptr(act), m.ptr(self._obs_buf), m.ptr(self._rew), m.ptr(self._done),
                                                 m.ptr(self._term), m.ptr(self._term_obs), m.ptr(self._metrics),
                                                 m.ptr(self._target), m.stream()))
+        self._refresh_obs_view()
         self._pending = act  # keeps the action buffer alive until the kernel has consumed it
 
     def step_wait(self):
@@ -284,9 +306,10 @@ class FixedWingVecEnv(object):
     def step_device(self, actions):
         """Fast path for on-device rollouts: no info objects; returns the (obs, reward, done) device tensors."""
         m = self._mem
-        nat.check(self._lib, self._lib.fwg_step(self._handle, m.ptr(actions), m.ptr(self._obs), m.ptr(self._rew), m.ptr(self._done),
+        nat.check(self._lib, self._lib.fwg_step(self._handle, m.ptr(actions), m.ptr(self._obs_buf), m.ptr(self._rew), m.ptr(self._done),
                                                 m.ptr(self._term), m.ptr(self._term_obs), m.ptr(self._metrics),
                                                 ctypes.c_void_p(), m.stream()))   # targets stay in the state arena
+        self._refresh_obs_view()
         return self._obs, self._rew, self._done
 
     # ------------------------------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 10
+#define FWG_ABI_VERSION 11
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -180,7 +180,8 @@ typedef struct fwg_config {
     int32_t metrics;                    /* any entry in cfg["metrics"] (fixed_wing.py:419-421) */
     int32_t auto_reset;                 /* VecEnv semantics: a done env restarts inside the same fwg_step */
     int32_t store_derived;              /* keep roll/pitch/yaw/Va/alpha/beta of the committed state in the arena (host views) */
-    int32_t pad_tail_;
+    int32_t obs_log_rows;   /* 0: fwg_step writes the dense [N][obs_dim] batch.  L > 0 (matrix observations without
+                             * observation noise): observation history kept once, as a row log -- see fwg_obs_window */
     double rise_low, rise_high;         /* metrics[rise_time].low/high (fixed_wing.py:1131) */
 } fwg_config;
 
@@ -259,6 +260,17 @@ int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const
  *   target_out       : NULL or float32 [N][n_targets] = info["target"] (fixed_wing.py:435) after the step */
 int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_out, uint8_t* done_out,
              uint8_t* term_code_out, float* terminal_obs_out, float* metrics_out, float* target_out, void* stream);
+
+/* Row-log observations (fwg_config.obs_log_rows = L > 0).  A lagged observation matrix is the newest record on top of
+ * records the env already produced obs_step, 2 obs_step, ... steps ago; instead of copying those rows into a dense
+ * batch every step (80 % of the observation traffic), fwg_step appends the new record to a log laid out as
+ * float32 [obs_step][L][N][n_obs] -- the buffer passed as obs_out to fwg_reset / fwg_step, fwg_obs_log_floats() long --
+ * in DESCENDING row order, so that the current observation of env e is the strided window
+ *     obs[e][i][k] = log[((*plane + i) * N + e) * n_obs + k],  i < obs_length
+ * (a zero-copy view: torch `log.view(-1, N, n_obs)[plane : plane + length].permute(1, 0, 2)`), valid until the next
+ * fwg_step / fwg_reset.  Values are identical to the dense batch.  `plane` refers to the last completed step. */
+int64_t fwg_obs_log_floats(const fwg_config* cfg_host, int64_t n_envs);
+int fwg_obs_window(const fwg_handle* h, int64_t* plane);
 
 /* Debug-mode check for NaN actions (fixed_wing.py:347); synchronises the stream. */
 int fwg_check_actions(fwg_handle* h, const float* actions, void* stream);

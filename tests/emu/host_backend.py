@@ -15,10 +15,10 @@ SRC = os.path.join(ROOT, "fixed-wing-gym_amd", "csrc")
 def build_emu(force=False):
     srcs = [os.path.join(SRC, f) for f in os.listdir(SRC) if os.path.isfile(os.path.join(SRC, f))] + [os.path.join(HERE, "hip", "hip_runtime.h"),
                                                                os.path.join(ROOT, "include", "fwgym.h")]
-    if not force and os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(s) for s in srcs):
-        return EMU_LIB
     inc = os.path.join(SRC, "generated", "specs.inc")
     srcs = srcs + ([inc] if os.path.exists(inc) else [])
+    if not force and os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(s) for s in srcs):
+        return EMU_LIB
     cmd = ["g++", "-x", "c++", "-std=c++17", "-O1", "-shared", "-fPIC", "-pthread", "-w", "-I" + HERE] + \
           (["-DFWG_WITH_SPECS"] if os.path.exists(inc) else []) + [
            "-I" + os.path.join(ROOT, "include"), "-I" + SRC, "-o", EMU_LIB, os.path.join(SRC, "fwgym.hip")]

@@ -1,0 +1,128 @@
+"""Row-log observations (FixedWingVecEnv(obs_log_rows=L), include/fwgym.h "Row-log observations"): the zero-copy window
+must hold exactly the values of the dense observation batch -- through episode ends, auto-reset, failed simulator
+steps, early-episode padding and the wrap of the log -- and the oracle parity must hold in that mode too."""
+import copy
+
+import numpy as np
+import pytest
+
+import configs
+import parity
+from gym_fixed_wing.vec_env import FixedWingVecEnv
+
+TURB = {"turbulence": True, "turbulence_intensity": "moderate"}
+
+
+def _pair(mk, cfg, n, rows, **kw):
+    return mk(cfg, n, 0, **kw), mk(cfg, n, rows, **kw)
+
+
+def _emu_env(cfg, n, rows, **kw):
+    from emu.host_backend import HostBackend, build_emu
+    return FixedWingVecEnv(copy.deepcopy(cfg), num_envs=n, as_numpy=True, _backend=HostBackend(), _lib_path=build_emu(),
+                           obs_log_rows=rows, seed=3, **kw)
+
+
+def _gpu_env(cfg, n, rows, **kw):
+    return FixedWingVecEnv(copy.deepcopy(cfg), num_envs=n, device=0, as_numpy=True, obs_log_rows=rows, seed=3, **kw)
+
+
+def run_log_vs_dense(mk, n, rows, steps, config_kw, sim_kw=None, auto_reset=True, scale=1.0, burst=2.5):
+    cfg = configs.reference_like("cnn")
+    dense, log = _pair(mk, cfg, n, rows, config_kw=config_kw, sim_config_kw=sim_kw, auto_reset=auto_reset)
+    oa, ob = dense.reset(), log.reset()
+    np.testing.assert_array_equal(oa, ob)
+    rng = np.random.default_rng(1)
+    terms = {}
+    alive = np.ones(n, dtype=bool)
+    for t in range(steps):
+        act = rng.uniform(-1, 1, (n, 3)).astype(np.float32) * (burst if t % 13 == 0 else scale)
+        oa, ra, da, ia = dense.step(act)
+        ob, rb, db, ib = log.step(act)
+        np.testing.assert_array_equal(da, db)
+        np.testing.assert_array_equal(ra[alive], rb[alive])
+        np.testing.assert_array_equal(oa[alive], ob[alive], err_msg="step {}".format(t))
+        for i in np.nonzero(da & alive)[0]:
+            terms[ia[int(i)]["termination"]] = terms.get(ia[int(i)]["termination"], 0) + 1
+            if auto_reset:
+                np.testing.assert_array_equal(ia[int(i)]["terminal_observation"], ib[int(i)]["terminal_observation"])
+        if not auto_reset:
+            alive &= ~da.astype(bool)   # a finished env that is not reset is outside the contract
+            if not alive.any():
+                break
+    dense.close(), log.close()
+    return terms
+
+
+@pytest.mark.parametrize("rows", [8, 11, 32])
+def test_log_window_equals_dense_batch_emulated(rows):
+    terms = run_log_vs_dense(_emu_env, 7, rows, 150, {"observation": {"step": 2}, "steps_max": 37}, TURB)
+    assert terms.get("steps", 0) >= 14
+
+
+def test_log_window_through_failed_steps_emulated():
+    # tight rate constraints (list index 6 = omega_p, as in configs.CASES "fail_prone"): episodes end in failed simulator
+    # steps, the branch whose observation takes its state rows from one record further back
+    tight = {"observation": {"step": 2}, "steps_max": 60,
+             "simulator": {"states": {6: {"constraint_min": -40, "constraint_max": 40}}}}
+    terms = run_log_vs_dense(_emu_env, 9, 12, 200, tight, None)
+    assert any(k not in ("steps", "success") for k in terms), terms
+
+
+def test_log_window_without_auto_reset_emulated():
+    run_log_vs_dense(_emu_env, 5, 9, 80, {"observation": {"step": 3}, "steps_max": 25}, None, auto_reset=False)
+
+
+def test_log_mode_oracle_parity_emulated():
+    from emu.host_backend import HostBackend, build_emu
+    cfg = configs.reference_like("cnn")
+    ckw = {"observation": {"step": 2}, "steps_max": 40}
+    vec = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=4, as_numpy=True, _backend=HostBackend(), _lib_path=build_emu(),
+                          obs_log_rows=12, seed=11, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(TURB))
+    oracles = parity.make_oracles(cfg, 4, 11, config_kw=ckw, sim_config_kw=TURB)
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, (100, 4, 3)).astype(np.float32)
+    res = parity.run_gym_parity(vec, oracles, 100, lambda t: acts[t], rtol=4e-3, atol=4e-3)
+    assert res["episodes"] >= 8
+
+
+def test_log_mode_rejects_what_it_cannot_represent():
+    from emu.host_backend import HostBackend, build_emu
+    from gym_fixed_wing import _native as nat
+    with pytest.raises(nat.NativeError):   # vector observation: nothing to stack
+        FixedWingVecEnv(configs.reference_like("examples"), num_envs=2, _backend=HostBackend(), _lib_path=build_emu(), obs_log_rows=8)
+    with pytest.raises(nat.NativeError):   # too short for the window
+        FixedWingVecEnv(configs.reference_like("cnn"), num_envs=2, _backend=HostBackend(), _lib_path=build_emu(), obs_log_rows=4)
+
+
+@pytest.mark.gpu
+def test_log_window_equals_dense_batch_on_gpu():
+    tight = {"observation": {"step": 2}, "steps_max": 90,
+             "simulator": {"states": {6: {"constraint_min": -60, "constraint_max": 60}}}}
+    terms = run_log_vs_dense(_gpu_env, 1000, 32, 260, tight, TURB)
+    assert terms.get("steps", 0) >= 100
+    assert any(k not in ("steps", "success") for k in terms), terms   # failed steps occurred too
+
+
+@pytest.mark.gpu
+def test_log_window_specialised_kernel_on_gpu():
+    from gym_fixed_wing import presets
+    cfg, ckw, skw, _, _ = presets.workload("c3")
+    dense = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=4096, device=0, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw),
+                            derived_views=False, seed=2)
+    log = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=4096, device=0, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw),
+                          derived_views=False, seed=2, obs_log_rows=presets.OBS_LOG_ROWS)
+    assert dense.spec_index >= 0 and log.spec_index >= 0 and dense.spec_index != log.spec_index
+    import torch
+    oa, ob = dense.reset(), log.reset()
+    assert torch.equal(oa, ob.contiguous())
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    ndone = 0
+    for t in range(2030):   # past steps_max = 2000 of the preset: every env ends an episode and is reset in-kernel
+        act = (torch.rand((4096, 3), device="cuda", generator=gen) * 2 - 1) * (2.5 if t % 11 == 0 else 1.0)
+        oa, ra, da = dense.step_device(act)
+        ob, rb, db = log.step_device(act)
+        assert torch.equal(da, db) and torch.equal(ra, rb)
+        assert torch.equal(oa.reshape(4096, 5, 12), ob), "step {}".format(t)
+        ndone += int(da.sum())
+    assert ndone >= 4096
