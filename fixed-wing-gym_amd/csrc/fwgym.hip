@@ -156,9 +156,25 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 
     // ---- phase C: gym-side bookkeeping (fixed_wing.py:360-417)
     if (c.metrics) {  // control_variation accumulator (fixed_wing.py:1109-1114)
-        if (E.steps > 0u) E.sdcmd += fabsf(cmd_c[0] - E.pcmd[0]) + fabsf(cmd_c[1] - E.pcmd[1]) + fabsf(cmd_c[2] - E.pcmd[2]);
+        if (E.steps > 0u) {   // the previous constrained command is recomputed from the previous raw action in the window
+            int sp_ = A.slot_act - 1; sp_ += (sp_ < 0) ? W : 0;
+            float pc[3];
+            if (c.use_cmd_ring) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) E.pcmd[i] = cmd_c[i];
+                for (int i = 0; i < 3; ++i) pc[i] = cring[sp_ * (4 * FWG_WAVE) + i];
+            } else {
+                float praw[3], psp[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float r_ = aring[sp_ * (4 * FWG_WAVE) + i];
+                    praw[i] = c.scale_actions ? (c.act_to_high[i] - c.act_to_low[i]) * (fclampf(r_, c.scale_low, c.scale_high) - c.scale_low) *
+                                                    c.inv_scale_span + c.act_to_low[i]
+                                              : r_;
+                }
+                constrain_commands(c, praw, pc, psp);
+            }
+            E.sdcmd += fabsf(cmd_c[0] - pc[0]) + fabsf(cmd_c[1] - pc[1]) + fabsf(cmd_c[2] - pc[2]);
+        }
     }
     E.steps += 1u;
     E.sft += 1u;
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     }
 
 #ifndef FWG_ABL_NO_GYMSTORE
-    if (valid) store_gym(c, A.S, A.N, e, E, A.bit_goal);
+    store_gym(c, A.S, A.N, e, E, A.bit_goal, valid, false);
 #endif
 
     // ---- phase D: observation (fixed_wing.py:776-846)
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         if (c.auto_reset && done && valid) {
             reset_env<TURB>(c, dc, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal);
             store_sim<TURB>(c, A.S, A.N, e, E);
-            store_gym(c, A.S, A.N, e, E, A.bit_goal);
+            store_gym(c, A.S, A.N, e, E, A.bit_goal, true, true);
         }
     }
 
@@ -489,7 +505,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     }
     if (sel) {
         store_sim<TURB>(c, A.S, A.N, e, E);
-        store_gym(c, A.S, A.N, e, E, A.bit_goal);
+        store_gym(c, A.S, A.N, e, E, A.bit_goal, true, true);
         if (A.tgt_out != nullptr) {
 #pragma unroll
             for (int k = 0; k < FWG_MAX_TARGETS; ++k)

@@ -229,7 +229,6 @@ struct Env {
     float tprop[FWG_MAX_TARGETS][4];  // slope|amplitude, period, phase, bias
     unsigned steps, sft, flags, episode;
     float psh[3];
-    float pcmd[3];
     unsigned gw;         // the word of the goal-window ring that holds this step's position (8 positions x 4 flags)
     unsigned wcnt;       // ones inside each of the 4 windows (target0..2, all), 4 x 8 bit
     unsigned gcnt[2];    // cumulative ones per window since reset, 4 x 16 bit
@@ -238,6 +237,8 @@ struct Env {
     unsigned settle[2];
     float perr[3];
     float sdcmd;
+    float was_emin[3], was_emax[3];   // values as loaded: the rarely-changing groups are written back only when they changed
+    unsigned was_rise[3];
 };
 
 // Arena addressing.  The arena is an array of 16-byte GROUPS [group][env]: word w of env e lives in group w>>2,
@@ -310,31 +311,31 @@ __device__ __forceinline__ void store_sim(const DevCfg& c, float* __restrict__ S
 }
 __device__ __forceinline__ void store_cold(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E) {
     GROUP(S, N, (c.L.cold >> 2), e) = make_float4(E.wind[0], E.wind[1], E.wind[2], u2f(E.episode));
-    GROUP(S, N, (c.L.cold >> 2) + 1, e) = make_float4(E.e0[0], E.e0[1], E.e0[2], 0.f);
 }
 
-// bookkeeping block, 9 groups (what changes every step):
-//  0: tgt0 tgt1 tgt2 steps|sft<<16 | 1: flags wcnt gcnt0 gcnt1 | 2: pcmd0 pcmd1 pcmd2 sdcmd | 3: settle0 settle1 rise0 rise1
-//  4: rise2 esum[0..2] | 5: eabs[0..2] perr0 | 6: emin[0..2] perr1 | 7: emax[0..2] perr2 | 8: psh[0..2] pad
-// then 3 groups of target properties (linear/sinusoidal targets only) and the goal-window ring as 16 plain word rows.
+// bookkeeping block, 9 groups.  Written every step: 0: tgt0 tgt1 tgt2 steps|sft<<16 | 1: flags wcnt gcnt0 gcnt1 and, with
+// metrics, 2: esum[0..2] perr0 | 3: eabs[0..2] perr1 | 4: sdcmd perr2 settle0 settle1.  Read every step but written
+// only when a lane of the wave changed them (running extremes, rise-time latches, the episode's initial errors):
+// 5: emin[0..2] rise0 | 6: emax[0..2] rise1 | 7: rise2 e0[0..2].  8: psh[0..2] (potential rewards only).
+// Then 3 groups of target properties (linear/sinusoidal targets only) and the goal-window ring as 16 plain word rows.
 __device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E, int goal_bit) {
     const int g0 = c.L.gym >> 2;
     float4 q[9];
 #pragma unroll
     for (int g = 0; g < 9; ++g)
-        if (g < 3 || (g < 8 && c.metrics) || (g == 8 && c.reward_potential)) q[g] = load_group(S, N, g0 + g, e);
+        if (g < 2 || (g < 8 && c.metrics) || (g == 8 && c.reward_potential)) q[g] = load_group(S, N, g0 + g, e);
     E.tgt[0] = q[0].x; E.tgt[1] = q[0].y; E.tgt[2] = q[0].z;
     E.steps = f2u(q[0].w) & 0xFFFFu; E.sft = f2u(q[0].w) >> 16;
     E.flags = f2u(q[1].x); E.wcnt = f2u(q[1].y); E.gcnt[0] = f2u(q[1].z); E.gcnt[1] = f2u(q[1].w);
-    E.pcmd[0] = q[2].x; E.pcmd[1] = q[2].y; E.pcmd[2] = q[2].z; E.sdcmd = q[2].w;
     if (c.metrics) {
-        E.settle[0] = f2u(q[3].x); E.settle[1] = f2u(q[3].y); E.rise[0] = f2u(q[3].z); E.rise[1] = f2u(q[3].w);
-        E.rise[2] = f2u(q[4].x); E.esum[0] = q[4].y; E.esum[1] = q[4].z; E.esum[2] = q[4].w;
-        E.eabs[0] = q[5].x; E.eabs[1] = q[5].y; E.eabs[2] = q[5].z; E.perr[0] = q[5].w;
-        E.emin[0] = q[6].x; E.emin[1] = q[6].y; E.emin[2] = q[6].z; E.perr[1] = q[6].w;
-        E.emax[0] = q[7].x; E.emax[1] = q[7].y; E.emax[2] = q[7].z; E.perr[2] = q[7].w;
-        const float4 z = CGROUP(S, N, (c.L.cold >> 2) + 1, e);
-        E.e0[0] = z.x; E.e0[1] = z.y; E.e0[2] = z.z;
+        E.esum[0] = q[2].x; E.esum[1] = q[2].y; E.esum[2] = q[2].z; E.perr[0] = q[2].w;
+        E.eabs[0] = q[3].x; E.eabs[1] = q[3].y; E.eabs[2] = q[3].z; E.perr[1] = q[3].w;
+        E.sdcmd = q[4].x; E.perr[2] = q[4].y; E.settle[0] = f2u(q[4].z); E.settle[1] = f2u(q[4].w);
+        E.emin[0] = q[5].x; E.emin[1] = q[5].y; E.emin[2] = q[5].z; E.rise[0] = f2u(q[5].w);
+        E.emax[0] = q[6].x; E.emax[1] = q[6].y; E.emax[2] = q[6].z; E.rise[1] = f2u(q[6].w);
+        E.rise[2] = f2u(q[7].x); E.e0[0] = q[7].y; E.e0[1] = q[7].z; E.e0[2] = q[7].w;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { E.was_emin[k] = E.emin[k]; E.was_emax[k] = E.emax[k]; E.was_rise[k] = E.rise[k]; }
     }
     if (c.reward_potential) { E.psh[0] = q[8].x; E.psh[1] = q[8].y; E.psh[2] = q[8].z; }
     if (c.any_dynamic_target) {
@@ -348,17 +349,29 @@ __device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restric
         E.gw = reinterpret_cast<const unsigned*>(S)[((unsigned)c.L.goal + (unsigned)(goal_bit >> 3)) * (unsigned)N + (unsigned)e];
 }
 
-__device__ __forceinline__ void store_gym(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E, int goal_bit) {
+// `all`: after a reset (every group is new; may be called by a subset of the lanes).  Otherwise EVERY lane of the wave
+// must call (the rarely-changing groups are written when any lane of the wave changed them -- a wave-wide vote);
+// `valid` gates the stores.
+__device__ __forceinline__ void store_gym(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E, int goal_bit,
+                                          bool valid, bool all) {
     const int g0 = c.L.gym >> 2;
+    bool d5 = true, d6 = true, d7 = true;
+    if (c.metrics && !all) {
+        const bool c5 = E.emin[0] != E.was_emin[0] || E.emin[1] != E.was_emin[1] || E.emin[2] != E.was_emin[2] || E.rise[0] != E.was_rise[0];
+        const bool c6 = E.emax[0] != E.was_emax[0] || E.emax[1] != E.was_emax[1] || E.emax[2] != E.was_emax[2] || E.rise[1] != E.was_rise[1];
+        const bool c7 = E.rise[2] != E.was_rise[2];
+        d5 = __ballot(c5 && valid) != 0ull; d6 = __ballot(c6 && valid) != 0ull; d7 = __ballot(c7 && valid) != 0ull;
+    }
+    if (!valid) return;
     GROUP(S, N, g0 + 0, e) = make_float4(E.tgt[0], E.tgt[1], E.tgt[2], u2f((E.steps & 0xFFFFu) | (E.sft << 16)));
     GROUP(S, N, g0 + 1, e) = make_float4(u2f(E.flags), u2f(E.wcnt), u2f(E.gcnt[0]), u2f(E.gcnt[1]));
-    GROUP(S, N, g0 + 2, e) = make_float4(E.pcmd[0], E.pcmd[1], E.pcmd[2], E.sdcmd);
     if (c.metrics) {
-        GROUP(S, N, g0 + 3, e) = make_float4(u2f(E.settle[0]), u2f(E.settle[1]), u2f(E.rise[0]), u2f(E.rise[1]));
-        GROUP(S, N, g0 + 4, e) = make_float4(u2f(E.rise[2]), E.esum[0], E.esum[1], E.esum[2]);
-        GROUP(S, N, g0 + 5, e) = make_float4(E.eabs[0], E.eabs[1], E.eabs[2], E.perr[0]);
-        GROUP(S, N, g0 + 6, e) = make_float4(E.emin[0], E.emin[1], E.emin[2], E.perr[1]);
-        GROUP(S, N, g0 + 7, e) = make_float4(E.emax[0], E.emax[1], E.emax[2], E.perr[2]);
+        GROUP(S, N, g0 + 2, e) = make_float4(E.esum[0], E.esum[1], E.esum[2], E.perr[0]);
+        GROUP(S, N, g0 + 3, e) = make_float4(E.eabs[0], E.eabs[1], E.eabs[2], E.perr[1]);
+        GROUP(S, N, g0 + 4, e) = make_float4(E.sdcmd, E.perr[2], u2f(E.settle[0]), u2f(E.settle[1]));
+        if (d5) GROUP(S, N, g0 + 5, e) = make_float4(E.emin[0], E.emin[1], E.emin[2], u2f(E.rise[0]));
+        if (d6) GROUP(S, N, g0 + 6, e) = make_float4(E.emax[0], E.emax[1], E.emax[2], u2f(E.rise[1]));
+        if (d7) GROUP(S, N, g0 + 7, e) = make_float4(u2f(E.rise[2]), E.e0[0], E.e0[1], E.e0[2]);
     }
     if (c.reward_potential) GROUP(S, N, g0 + 8, e) = make_float4(E.psh[0], E.psh[1], E.psh[2], 0.f);
     if (c.any_dynamic_target) {
@@ -788,7 +801,7 @@ __device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, con
     for (int k = 0; k < 3; ++k) {
         E.e0[k] = err[k]; E.esum[k] = err[k]; E.eabs[k] = fabsf(err[k]); E.emin[k] = err[k]; E.emax[k] = err[k];
         E.rise[k] = 0xFFFFFFFFu; E.perr[k] = err[k];
-        E.pcmd[k] = 0.f; E.psh[k] = 0.f;
+        E.psh[k] = 0.f;
     }
     E.settle[0] = 0xFFFFFFFFu; E.settle[1] = 0xFFFFFFFFu;
     E.sdcmd = 0.f;

@@ -44,7 +44,9 @@ def timeit():
     res = {}
     for name in sorted(f[9:-3] for f in os.listdir(OUT) if f.endswith(".so")):
         vec = FixedWingVecEnv(cfg, num_envs=n, device=0, config_kw=ckw, sim_config_kw=skw, seed=1, derived_views=False,
+                              obs_log_rows=int(os.environ.get("FWG_ABL_LOG_ROWS", "0")),
                               _lib_path=os.path.join(OUT, "libfwgym_{}.so".format(name)))
+        assert vec.spec_index >= 0
         vec.reset()
         acts = [torch.rand((n, 3), device="cuda") * 2 - 1 for _ in range(16)]
         for t in range(100): vec.step_device(acts[t % 16])
