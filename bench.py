@@ -198,7 +198,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(args.workload)
+                traffic = json.load(f).get(args.workload + ("_log" if log_rows else ""))
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
