@@ -219,10 +219,12 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
     vec.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:   # last, so that library banners (RCCL prints one on teardown) do not follow the result line
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
