@@ -120,9 +120,8 @@ def main():
     gathered = torch.zeros(16 * world, device=dev) if use_dist else None
 
     def reduce_step():
-        red = vec.reduce_success()                 # local sums (syncs this rank's stream)
+        vec.reduce_success_device(red_dev)         # local sums, device to device, stream-ordered (no host sync)
         if use_dist:
-            red_dev.copy_(torch.as_tensor(red, dtype=torch.float32))
             dist.all_gather_into_tensor(gathered, red_dev)   # RCCL over xGMI: 64 B per rank
 
     fused = args.workload == "c5" and args.rollout != "none"
@@ -224,6 +223,11 @@ def main():
         dist.destroy_process_group()
     if rank == 0:   # last, so that library banners (RCCL prints one on teardown) do not follow the result line
         sys.stdout.flush()
+        try:   # RCCL's banner sits in the C stdio buffer until exit when stdout is a pipe: push it out first
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
 
 

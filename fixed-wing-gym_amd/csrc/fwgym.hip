@@ -919,6 +919,13 @@ int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream) {
     return FWG_OK;
 }
 
+int fwg_reduce_success_device(fwg_handle* h, float* out_dev, void* stream) {
+    if (!h || !out_dev) return fail_with(FWG_ERR_INVALID, "null argument");
+    HIP_TRY(hipMemcpyAsync(out_dev, h->d_reduce, sizeof(float) * FWG_N_REDUCE, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(h->d_reduce, 0, sizeof(float) * FWG_N_REDUCE, (hipStream_t)stream));
+    return FWG_OK;
+}
+
 int fwg_spec_index(const fwg_handle* h) { return h ? h->spec : -1; }
 
 int fwg_set_graph_mode(fwg_handle* h, int enable, void* stream) {

@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 11
+FWG_ABI_VERSION = 12
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -142,7 +142,7 @@ EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fw
            "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index", "fwg_set_graph_mode", "fwg_note_replayed_steps",
            "fwg_capture_begin", "fwg_capture_end", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
            "fwg_actor_set_stats", "fwg_actor_get_stats", "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe",
-           "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window"]
+           "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window", "fwg_reduce_success_device"]
 _libs = {}
 
 
@@ -176,6 +176,8 @@ def load_library(path=None):
     lib.fwg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.fwg_check_actions.argtypes = [vp, vp, vp]
     lib.fwg_reduce_success.argtypes = [vp, C.POINTER(C.c_float), vp]
+    lib.fwg_reduce_success_device.argtypes = [vp, vp, vp]
+    lib.fwg_reduce_success_device.restype = C.c_int
     lib.fwg_global_step.argtypes = [vp]
     lib.fwg_global_step.restype = i64
     lib.fwg_last_error.restype = C.c_char_p

@@ -30,11 +30,13 @@ def gather_success(vec, group=None):
     {"episodes": n, "success": {target.., "all"}, "control_variation": mean, ...} (means over episodes)."""
     import torch
     import torch.distributed as dist
-    local = vec.reduce_success()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dev = getattr(getattr(vec, "_mem", None), "device", None)
-        use_dev = dev is not None and dist.get_backend(group) == "nccl"
-        t = torch.as_tensor(local, dtype=torch.float32, device=dev if use_dev else "cpu")
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    dev = getattr(getattr(vec, "_mem", None), "device", None)
+    use_dev = multi and dev is not None and dist.get_backend(group) == "nccl"
+    local = None if use_dev else vec.reduce_success()
+    if multi:
+        # RCCL: the device-resident sums go straight into the all-gather, the only host read is the gathered result
+        t = vec.reduce_success_device() if use_dev else torch.as_tensor(local, dtype=torch.float32, device="cpu")
         out = torch.empty(dist.get_world_size(group) * t.numel(), dtype=torch.float32, device=t.device)
         dist.all_gather_into_tensor(out, t, group=group)
         total = out.view(-1, t.numel()).sum(dim=0).cpu().numpy().astype(np.float64)

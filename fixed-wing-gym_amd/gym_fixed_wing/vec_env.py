@@ -417,6 +417,12 @@ class FixedWingVecEnv(object):
         nat.check(self._lib, self._lib.fwg_reduce_success(self._handle, out, self._mem.stream()))
         return np.array(out[:], dtype=np.float64)
 
+    def reduce_success_device(self, out=None):
+        """The same sums as a device tensor [16], stream-ordered, no synchronisation (feed it to the all-gather)."""
+        out = self._mem.zeros((nat.N_REDUCE,)) if out is None else out
+        nat.check(self._lib, self._lib.fwg_reduce_success_device(self._handle, self._mem.ptr(out), self._mem.stream()))
+        return out
+
     # stable-baselines VecEnv surface used by the example scripts ---------------------------------------------------
     def get_attr(self, attr_name, indices=None):
         n = self.num_envs if indices is None else len(np.atleast_1d(indices))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 11
+#define FWG_ABI_VERSION 12
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -281,6 +281,9 @@ int fwg_check_actions(fwg_handle* h, const float* actions, void* stream);
  * examples/train_rl_controller.py:51-66,80-85; the caller all-gathers them over RCCL.  Synchronises the stream and
  * clears the accumulators. */
 int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream);
+/* The same sums into a DEVICE buffer (16 floats), stream-ordered and without synchronising: the form to hand to the
+ * RCCL all-gather directly, so that the rollout never drains the GPU for the success reduction. */
+int fwg_reduce_success_device(fwg_handle* h, float* out_dev, void* stream);
 
 /* Build-time specialisation support: writes the lowered STATIC configuration as 32-bit words (pure host function; the
  * build freezes such word lists into constexpr objects, see csrc/fwgym.hip "Specialisation").  Returns the number of

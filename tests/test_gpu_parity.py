@@ -132,13 +132,17 @@ def test_success_reduction_matches_infos():
     vec.reset()
     rng = np.random.default_rng(0)
     eps, succ = 0, np.zeros(4)
+    first = None
     for t in range(65):
         _, _, done, infos = vec.step(rng.uniform(-1, 1, size=(n, 3)).astype(np.float32))
         for i in np.nonzero(np.asarray(done))[0]:
             info = infos[int(i)]
             eps += 1
             succ += [info["success"][k] for k in ("roll", "pitch", "Va", "all")]
-    red = vec.reduce_success()
+        if t == 40:   # the device-resident form (no host sync) takes and clears the sums the same way
+            first = vec.reduce_success_device().cpu().numpy().astype(np.float64)
+    red = vec.reduce_success() + first
+    assert first[0] == n
     assert red[0] == eps == 2 * n
     np.testing.assert_array_equal(red[1:5], succ)
     assert np.all(vec.reduce_success() == 0)
