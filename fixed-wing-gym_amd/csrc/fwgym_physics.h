@@ -196,15 +196,27 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const f
         float a_half[5], a_full[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) a_half[i] = a[i];
+#ifdef FWG_ABL_ACT1
+        advance_actuators(c, a_half, sp);
+#else
         for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_half, sp);
+#endif
 #pragma unroll
         for (int i = 0; i < 5; ++i) a_full[i] = a_half[i];
+#ifdef FWG_ABL_ACT1
+        advance_actuators(c, a_full, sp);
+#else
         for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_full, sp);
+#endif
         float acc[NB], ys[NB], k[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) { acc[i] = 0.f; ys[i] = yb[i]; }
 #pragma unroll FWG_STAGE_UNROLL
+#ifdef FWG_ABL_RK1
+        for (int st = 0; st < 1; ++st) {
+#else
         for (int st = 0; st < 4; ++st) {
+#endif
             float act[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) act[i] = (st == 0) ? a[i] : ((st == 3) ? a_full[i] : a_half[i]);
