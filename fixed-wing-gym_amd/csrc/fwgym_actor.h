@@ -145,8 +145,19 @@ __device__ __forceinline__ void hidden_to_b(const f32x16& a0, const f32x16& a1, 
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         float x[8];
+#if !defined(FWG_EMU)
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {   // the add and the fma of 1 - 2 / (2^a + 1) on pairs (v_pk_add_f32 / v_pk_fma_f32)
+            const float u0 = kk < 2 ? a0[8 * kk + t] : a1[8 * (kk - 2) + t], u1 = kk < 2 ? a0[8 * kk + t + 1] : a1[8 * (kk - 2) + t + 1];
+            const fwg_f32x2 d = fwg_f32x2{fwg_exp2(u0), fwg_exp2(u1)} + fwg_f32x2{1.f, 1.f};
+            const fwg_f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            const fwg_f32x2 y = __builtin_elementwise_fma(r, fwg_f32x2{-2.f, -2.f}, fwg_f32x2{1.f, 1.f});
+            x[t] = y[0]; x[t + 1] = y[1];
+        }
+#else
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] = tanh_prescaled(kk < 2 ? a0[8 * kk + t] : a1[8 * (kk - 2) + t]);
+#endif
         split8(x, hi[kk], lo[kk]);
     }
 }
@@ -244,6 +255,30 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
                 dma_group(reinterpret_cast<const float4*>(A.frags + ((net * 2 + part) * nf + fr) * 64 + l),
                           reinterpret_cast<float*>(F + ((net * PARTS + part) * nf + fr) * 64));
 #endif
+    // raw observation entries of this lane (k-slots of the first layer), requested before the statistics are folded
+    const long e = (long)blockIdx.x * FWG_ACT_ENVS + wv * 32 + j;
+    const bool valid = e < A.N;
+    const bool vec4 = (A.D & 3) == 0;
+    float raw_x[NK1][8];
+#pragma unroll
+    for (int kk = 0; kk < NK1; ++kk) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f0 = k_input(kk, half, 4 * q);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid && f0 < A.D) {
+                if (vec4) {
+                    const float4 g = *reinterpret_cast<const float4*>(A.obs + e * A.D + f0);
+                    v[0] = g.x; v[1] = g.y; v[2] = g.z; v[3] = g.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (f0 + i < A.D) v[i] = A.obs[e * A.D + f0 + i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) raw_x[kk][4 * q + i] = v[i];
+        }
+    }
     {   // add the accumulator shards (integers: exact, order-free) and fold the batch into the running statistics (the
         // parallel-variance update of VecNormalize's RunningMeanStd).  Every block computes the same values; block 0
         // publishes them and clears the other parity's accumulators for the launches that follow
@@ -302,9 +337,6 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     }
     __syncthreads();
 
-    const long e = (long)blockIdx.x * FWG_ACT_ENVS + wv * 32 + j;
-    const bool valid = e < A.N;
-    const bool vec4 = (A.D & 3) == 0;
     frag_t bx_hi[NK1], bx_lo[NK1];
 #pragma unroll
     for (int kk = 0; kk < NK1; ++kk) {
@@ -312,16 +344,7 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int f0 = k_input(kk, half, 4 * q);
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (valid && f0 < A.D) {
-                if (vec4) {
-                    const float4 g = *reinterpret_cast<const float4*>(A.obs + e * A.D + f0);
-                    v[0] = g.x; v[1] = g.y; v[2] = g.z; v[3] = g.w;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (f0 + i < A.D) v[i] = A.obs[e * A.D + f0 + i];
-                }
-            }
+            float v[4] = {raw_x[kk][4 * q], raw_x[kk][4 * q + 1], raw_x[kk][4 * q + 2], raw_x[kk][4 * q + 3]};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {   // features >= D: mean 0, rstd 0 -> 0
                 v[i] = fminf(fmaxf((v[i] - mean_s[f0 + i]) * rstd_s[f0 + i], -A.clip_obs), A.clip_obs);

@@ -71,7 +71,10 @@ class DeviceActor(object):
 
     def close(self):
         if getattr(self, "_handle", None):
-            self.detach()
+            try:
+                self.detach()
+            except Exception:   # interpreter shutdown: module globals may already be gone
+                pass
             self._lib.fwg_actor_destroy(self._handle)
             self._handle = None
 
