@@ -207,6 +207,7 @@ class FixedWingVecEnv(object):
 
     def note_replayed_steps(self, n_steps):
         nat.check(self._lib, self._lib.fwg_note_replayed_steps(self._handle, int(n_steps)))
+        self._refresh_obs_view()   # row-log mode: the window moved with the replayed steps
 
     @property
     def spec_index(self):

@@ -126,3 +126,35 @@ def test_log_window_specialised_kernel_on_gpu():
         assert torch.equal(oa.reshape(4096, 5, 12), ob), "step {}".format(t)
         ndone += int(da.sum())
     assert ndone >= 4096
+
+
+@pytest.mark.gpu
+def test_log_window_under_graph_replay_on_gpu():
+    """Row-log positions come from the device-resident step counter under hipGraph replay; the host view follows."""
+    import torch
+    cfg = configs.reference_like("cnn")
+    kw = dict(config_kw={"observation": {"step": 2}, "steps_max": 50}, sim_config_kw=copy.deepcopy(TURB), seed=9)
+    dense = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=512, device=0, **copy.deepcopy(kw))
+    log = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=512, device=0, obs_log_rows=12, **copy.deepcopy(kw))
+    dense.reset(), log.reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    acts = [torch.rand((512, 3), device="cuda", generator=gen) * 2 - 1 for _ in range(8)]
+    log.set_graph_mode(True)
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for a in acts[:2]:
+            log.step_device(a)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    for a in acts[:2]:
+        dense.step_device(a)
+    g = torch.cuda.CUDAGraph()
+    log.capture_begin()
+    with torch.cuda.graph(g):
+        for a in acts:
+            log.step_device(a)
+    log.capture_end()
+    for rep in range(9):   # 72 steps: past steps_max = 50 and several wraps of the 12-row log
+        g.replay(); log.note_replayed_steps(8); torch.cuda.synchronize()
+        for a in acts:
+            od, _, _ = dense.step_device(a)
+        assert torch.equal(od.reshape(512, 5, 12), log._obs), "replay {}".format(rep)
