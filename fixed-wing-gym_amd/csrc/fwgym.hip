@@ -68,6 +68,38 @@ template <int SPEC> struct KernelTypes {  // generic kernel: lane-private LDS co
     };
 FWG_SPEC_LIST(FWG_SPEC_TYPES)
 
+// Attached rollout head (fwg_attach_observer): this wave's batch moments of the observation records and discounted
+// returns it produced, added to the head's accumulators (fwgym_env.h "batch-moment accumulators").  Called by all lanes.
+template <class OB>
+__device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, const OB& ob, float reward, bool done, bool valid,
+                                             int lane, long e) {
+#ifndef FWG_ABL_NO_ACC
+    const int D = c.obs_dim;
+    // VecNormalize.step_wait: ret = ret * gamma + r; ret_rms.update(ret); ret[done] = 0
+    float dr = 0.f;
+    if (valid) {
+        const float r = A.acc_ret[e] * A.acc_gamma + reward;
+        A.acc_ret[e] = done ? 0.f : r;
+        dr = r - *A.acc_ret_mean;
+    }
+#define FWG_OBS_AT(k) ob.get(k)
+#pragma unroll
+    for (int chunk = 0; chunk < (2 * FWG_MAX_OBS * FWG_MAX_ROWS + 4 + 31) / 32; ++chunk) {
+        if (32 * chunk < 2 * D + 4) {
+            float v[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = FWG_ACC_COLUMN(32 * chunk + i, D, valid, FWG_OBS_AT, A.acc_mean, dr, true, true);
+#ifdef FWG_ABL_NO_TOTALS
+            acc_flush(A.acc, A.acc_cols, blockIdx.x & (FWG_ACC_SHARDS - 1), chunk, lane, v[0] + v[7] + v[13] + v[27]);
+#else
+            acc_flush(A.acc, A.acc_cols, blockIdx.x & (FWG_ACC_SHARDS - 1), chunk, lane, wave_totals32(v, lane));
+#endif
+        }
+    }
+#undef FWG_OBS_AT
+#endif
+}
+
 template <bool TURB, int SPEC>
 __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -336,6 +368,9 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 
     // ---- phase E: episode end -- metrics block, success reduction, terminal observation, auto-reset
     const unsigned long long done_mask = __ballot(done && valid);
+    // waves in which no episode ends have their final observation records here: the moments for an attached rollout head
+    // go out before the remaining stores, whose issue then hides the round trip of the atomics
+    if (A.acc != nullptr && done_mask == 0ull) step_moments(c, A, ob, reward, done, valid, lane, e);
     if (done_mask != 0ull) {
         float red[FWG_N_REDUCE];
 #pragma unroll
@@ -414,6 +449,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         }
     }
 
+    if (A.acc != nullptr && done_mask != 0ull) step_moments(c, A, ob, reward, done, valid, lane, e);
     // ---- phase F: outputs and the state write-back
 #ifndef FWG_ABL_NO_OBSWRITE
     if (c.obs_log == 0) {
@@ -440,33 +476,6 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
                 if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
         }
     }
-#ifndef FWG_ABL_NO_ACC
-    if (A.acc != nullptr) {   // attached rollout head: this wave's batch moments (wave-uniform branch)
-        const int D = c.obs_dim;
-        // VecNormalize.step_wait: ret = ret * gamma + r; ret_rms.update(ret); ret[done] = 0
-        float dr = 0.f;
-        if (valid) {
-            const float r = A.acc_ret[e] * A.acc_gamma + reward;
-            A.acc_ret[e] = done ? 0.f : r;
-            dr = r - *A.acc_ret_mean;
-        }
-#define FWG_OBS_AT(k) ob.get(k)
-#pragma unroll
-        for (int chunk = 0; chunk < (2 * FWG_MAX_OBS * FWG_MAX_ROWS + 4 + 31) / 32; ++chunk) {
-            if (32 * chunk < 2 * D + 4) {
-                float v[32];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) v[i] = FWG_ACC_COLUMN(32 * chunk + i, D, valid, FWG_OBS_AT, A.acc_mean, dr, true, true);
-#ifdef FWG_ABL_NO_TOTALS
-                acc_flush(A.acc, A.acc_cols, blockIdx.x & (FWG_ACC_SHARDS - 1), chunk, lane, v[0] + v[7] + v[13] + v[27]);
-#else
-                acc_flush(A.acc, A.acc_cols, blockIdx.x & (FWG_ACC_SHARDS - 1), chunk, lane, wave_totals32(v, lane));
-#endif
-            }
-        }
-#undef FWG_OBS_AT
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -21,8 +21,10 @@ def build_emu(force=False):
         return EMU_LIB
     cmd = ["g++", "-x", "c++", "-std=c++17", "-O1", "-shared", "-fPIC", "-pthread", "-w", "-I" + HERE] + \
           (["-DFWG_WITH_SPECS"] if os.path.exists(inc) else []) + [
-           "-I" + os.path.join(ROOT, "include"), "-I" + SRC, "-o", EMU_LIB, os.path.join(SRC, "fwgym.hip")]
+           "-I" + os.path.join(ROOT, "include"), "-I" + SRC, "-o", EMU_LIB + ".tmp{}".format(os.getpid()),
+           os.path.join(SRC, "fwgym.hip")]
     subprocess.run(cmd, check=True)
+    os.replace(EMU_LIB + ".tmp{}".format(os.getpid()), EMU_LIB)   # atomic: parallel test workers may build at once
     return EMU_LIB
 
 
