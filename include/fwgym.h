@@ -344,7 +344,7 @@ int fwg_actor_seed(fwg_actor* a, uint64_t seed, int64_t env_id_base);
 /* Attaches the head to an env (NULL detaches): from then on every fwg_step also leaves the batch moments of the
  * observations it writes and advances the discounted returns with the rewards it writes -- what fwg_actor_observe
  * would do in a launch of its own -- so that a rollout step is two launches (fwg_step, fwg_actor_act).  Same n_envs,
- * obs_dim and device required. */
+ * obs_dim and device required.  The env keeps a plain pointer: detach (or destroy the env) before fwg_actor_destroy. */
 int fwg_attach_observer(fwg_handle* h, fwg_actor* a);
 /* Accumulates the batch moments of `obs` ([N][obs_dim]) and, when `reward` is not NULL, advances the discounted
  * returns (ret = ret * gamma + reward, zeroed where `done`) and accumulates their moments (VecNormalize.step_wait). */
