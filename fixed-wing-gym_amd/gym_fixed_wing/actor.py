@@ -67,6 +67,7 @@ class DeviceActor(object):
 
     @classmethod
     def for_env(cls, vec, **kw):
+        kw.setdefault("env_id_base", getattr(vec, "env_id_base", 0))
         return cls(vec.num_envs, vec.obs_dim, _backend=vec._mem, _lib=vec._lib, **kw)
 
     def close(self):

@@ -94,6 +94,7 @@ class FixedWingVecEnv(object):
         self.env_config = EnvConfig(config_path, sim_config_path, sim_parameter_path, config_kw, sim_config_kw)
         self.cfg = self.env_config.cfg
         self.num_envs = int(num_envs)
+        self.env_id_base = int(env_id_base)   # global id of env 0 (RNG streams are keyed by global ids)
         self.as_numpy = as_numpy
         self.auto_reset = auto_reset
         # derived_views=False drops the per-step write of roll/pitch/yaw/Va/alpha/beta into the arena (32 B/env-step);
