@@ -194,12 +194,6 @@ __device__ __forceinline__ f32x16 mlp_forward(const frag_t* F, int l, const frag
     return mma_bias<SPLIT>(F, nf, base3 + 4, l, ones, out);
 }
 
-__device__ __forceinline__ float actor_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // batch moments of an observation / reward batch that did not come out of an attached env step (the first observation
 // after reset(), evaluation loops): one thread = one environment, same accumulation as the tail of k_step
