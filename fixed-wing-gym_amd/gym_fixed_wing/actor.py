@@ -135,9 +135,19 @@ class DeviceActor(object):
     def _p(self, t):
         return ctypes.c_void_p() if t is None else self._mem.ptr(t)
 
+    @staticmethod
+    def _dense(t):
+        """Inputs must be dense: a row-log observation window (strided view) is materialised here."""
+        if t is None:
+            return None
+        if hasattr(t, "is_contiguous"):
+            return t if t.is_contiguous() else t.contiguous()
+        return np.ascontiguousarray(t)
+
     def observe(self, obs, reward=None, done=None):
         """VecNormalize.step_wait bookkeeping for a new batch: moments of `obs` ([N, obs_dim] or [N, L, n]); with
         `reward`/`done` also the discounted returns.  The statistics change at the next act()."""
+        obs, reward, done = self._dense(obs), self._dense(reward), self._dense(done)
         nat.check(self._lib, self._lib.fwg_actor_observe(self._handle, self._p(obs), self._p(reward), self._p(done),
                                                          self._mem.stream()))
         self._observed = True
@@ -147,6 +157,7 @@ class DeviceActor(object):
         """Normalised observation, action, value, log-probability for `obs`; `norm_reward` receives the normalised
         `reward` of the transition that led to `obs`.  Output arrays are allocated when not given."""
         m, N = self._mem, self.num_envs
+        obs, reward, done = self._dense(obs), self._dense(reward), self._dense(done)
         norm_obs = m.zeros((N, self.obs_dim)) if norm_obs is None else norm_obs
         action = m.zeros((N, self.act_dim)) if action is None else action
         value = m.zeros((N,)) if value is None else value

@@ -5,6 +5,7 @@ return normalisation (VecNormalize), a 64-64 tanh MLP policy + value net (the ar
 models/mlp_controller), and a rollout buffer filled without leaving the GPU.  The optimiser step is out of scope."""
 import math
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -178,7 +179,11 @@ class FusedRollout(object):
         self.last_value = self.cur["values"]
         self._primed = False
         self._graph = None
-        actor.attach(vec)      # the env step kernel leaves the batch moments itself: two launches per step
+        # the env step kernel leaves the batch moments itself (two launches per step) -- except with row-log observations,
+        # where the lagged rows never pass through the step kernel: then the head takes them in a launch of its own
+        self._attached = not getattr(vec, "obs_log_rows", 0)
+        if self._attached:
+            actor.attach(vec)
         if graph:
             self._capture()
 
@@ -189,15 +194,23 @@ class FusedRollout(object):
             self.actor.act(self.vec._obs, norm_obs=c["obs"], action=c["actions"], value=c["values"], logp=c["logp"])
             self._primed = True
 
+    def _step(self, action, nxt, reward_out=None, done_out=None):
+        """One env step under `action`, then the head on the new observation writing into the slices of `nxt`."""
+        vec, actor = self.vec, self.actor
+        o, r, d = vec.step_device(action)
+        if not self._attached:
+            o = o.contiguous() if hasattr(o, "contiguous") else np.ascontiguousarray(o)
+            actor.observe(o, r, d)
+        actor.act(o, reward=r, done=d, norm_obs=nxt["obs"], action=nxt["actions"], value=nxt["values"], logp=nxt["logp"],
+                  norm_reward=reward_out, done_out=done_out)
+
     def _body(self):
-        vec, actor, buf, cur, n = self.vec, self.actor, self.buf, self.cur, self.n_steps
+        buf, cur, n = self.buf, self.cur, self.n_steps
         for k in ("obs", "actions", "values", "logp"):
             buf[k][0][...] = cur[k]
         for t in range(n):
-            o, r, d = vec.step_device(buf["actions"][t])
             nxt = cur if t == n - 1 else {k: buf[k][t + 1] for k in cur}
-            actor.act(o, reward=r, done=d, norm_obs=nxt["obs"], action=nxt["actions"], value=nxt["values"], logp=nxt["logp"],
-                      norm_reward=buf["rewards"][t], done_out=buf["dones"][t])
+            self._step(buf["actions"][t], nxt, buf["rewards"][t], buf["dones"][t])
 
     def _capture(self):
         import torch
@@ -209,12 +222,8 @@ class FusedRollout(object):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):   # warm-up outside capture
-            o, r, d = vec.step_device(self.cur["actions"])
-            self.actor.act(o, reward=r, done=d, norm_obs=self.cur["obs"], action=self.cur["actions"], value=self.cur["values"],
-                           logp=self.cur["logp"])
-            o, r, d = vec.step_device(self.cur["actions"])
-            self.actor.act(o, reward=r, done=d, norm_obs=self.cur["obs"], action=self.cur["actions"], value=self.cur["values"],
-                           logp=self.cur["logp"])
+            self._step(self.cur["actions"], self.cur)
+            self._step(self.cur["actions"], self.cur)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self._graph = torch.cuda.CUDAGraph()

@@ -209,3 +209,24 @@ def test_fused_rollout_throughput_on_gpu():
         assert 128 * n / dt > (2e8 if graph else 1e7)   # the eager loop is bounded by host launch overhead (and by
         # whatever else the process did before: a floor, not a performance claim)
         vec.close()
+
+
+def test_fused_rollout_on_a_row_log_env_equals_the_dense_one():
+    """Row-log observations never pass through the step kernel, so the head takes its moments in a launch of its own;
+    the rollout must not depend on the observation layout."""
+    from emu.host_backend import HostBackend, build_emu
+    from gym_fixed_wing.actor import DeviceActor
+    from gym_fixed_wing.rollout import FusedRollout
+    cfg = configs.reference_like("cnn")
+    bufs = []
+    for rows in (0, 10):
+        vec = FixedWingVecEnv(cfg, num_envs=70, config_kw={"observation": {"step": 2}, "steps_max": 9}, as_numpy=True,
+                              _backend=HostBackend(), _lib_path=build_emu(), obs_log_rows=rows, seed=2)
+        vec.reset()
+        torch.manual_seed(0)
+        actor = DeviceActor.for_env(vec, seed=5)
+        actor.load_policy(MlpPolicy(60))
+        bufs.append({k: np.array(v) for k, v in FusedRollout(vec, actor, 12).run().items()})
+    for k in bufs[0]:
+        np.testing.assert_allclose(bufs[0][k], bufs[1][k], rtol=0, atol=2e-6, err_msg=k)
+    assert bufs[0]["dones"].sum() == 70
