@@ -216,6 +216,28 @@ def main():
                          "kernel": "k_step + k_actor_act" if fused else "k_step", "kernel_ms": region_ms, "kernel_ms_isolated": kern_ms,
                          "algorithmic_bytes_per_env_step": ALG_BYTES[args.workload]},
         }
+        if args.workload == "c3" and not log_rows and world == 1:
+            # side measurement (never `value`): the same workload with row-log observations, the opt-in layout that keeps
+            # the observation history once and hands out a zero-copy window
+            alt = FixedWingVecEnv(cfg, num_envs=n_envs, device=local, config_kw=ckw, sim_config_kw=skw, seed=0,
+                                  env_id_base=rank * n_envs, auto_reset=True, derived_views=False,
+                                  obs_log_rows=_presets.OBS_LOG_ROWS)
+            alt.reset()
+            for t in range(200):
+                alt.step_device(pool[t % len(pool)])
+            torch.cuda.synchronize(dev)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for t in range(1000):
+                alt.step_device(pool[t % len(pool)])
+            a1.record()
+            torch.cuda.synchronize(dev)
+            alt_ms = a0.elapsed_time(a1) / 1000
+            alt.close()
+            out["row_log_observations"] = {"ms_per_step": alt_ms, "value": n_envs / alt_ms * 1e3, "unit": "env-steps/s",
+                                           "roofline_frac": alg / (alt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "note": "opt-in obs_log_rows=32 (bench.py --obs-layout log); same observation values "
+                                                   "as a strided window, 697 B/env-step moved instead of 1 090"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
     vec.close()
