@@ -159,7 +159,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
 #ifndef FWG_ABL_NO_LAG
     if (c.obs_log == 0) stream_lag_rows(c, A, e, lds + M.lag);
-    else log_wrap(c, A.obs, A.N, e, A.gnow, valid);
+    else log_wrap(c, A.obs, A.N, e, A.gnow, valid, A.log_wrap_now);
 #endif
 #ifdef FWG_ABL_NO_SIM
     const int fail = 0;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     // end: terminal observation) read them back, and only early-episode / failed lanes compute rows of their own
     const bool early = c.obs_length > 1 && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
     const unsigned log_pad_t = E.steps;   // rows with lag >= this are padding (valid for lanes that do not finish)
-    const long long log_win = c.obs_log > 0 ? log_plane(c.obs_step, c.obs_log, c.obs_length, A.gnow, A.gnow) : 0;   // wave-uniform
+    const long long log_win = A.log_win;   // wave-uniform
     if (c.obs_log > 0 && __ballot((done || !ok) && valid) != 0ull) {
         if ((done || !ok) && valid) log_load_rows(c, A.obs, A.N, e, log_win, ob);
     }
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     if (c.obs_log == 0) {
         write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
     } else if (sel) {
-        const long long win = log_plane(c.obs_step, c.obs_log, c.obs_length, A.gnow, A.gnow);
+        const long long win = A.log_win;
 #pragma unroll
         for (int r = 0; r < FWG_MAX_ROWS; ++r)
             if (r < c.obs_length) log_store_row(c, A.obs, A.N, e, win, r, ob);
@@ -852,6 +852,10 @@ static inline int pmod(int64_t a, int m) { return m > 0 ? (int)(((a % m) + m) % 
 static void fill_slots(const fwg_handle* h, int64_t g, KArgs* A) {
     const DevCfg& d = h->h;
     A->gnow = g;
+    if (d.obs_log > 0) {
+        A->log_win = log_plane(d.obs_step, d.obs_log, d.obs_length, g, g);
+        A->log_wrap_now = log_pmod(log_fdiv(g, d.obs_step), d.obs_log - (d.obs_length - 1)) == 0;
+    }
     A->slot_act = pmod(g, d.L.window);
     A->slot_end = pmod(g, FWG_END_WINDOW);
     A->slot_lag = pmod(g, d.L.lag_depth);

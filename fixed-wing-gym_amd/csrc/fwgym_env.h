@@ -30,6 +30,8 @@ struct KArgs {
     long long* gstep_out;
     int reset_launch;                            // k_reset: positions refer to the LAST completed step (counter - 1)
     long long gnow;                              // global index of the step this launch refers to (row-log positions)
+    long long log_win;                           // row-log mode: first plane of this step's window, and whether the
+    int log_wrap_now;                            // parity's wrap copy is due (host-computed; recomputed in graph mode)
     // attached rollout head (fwg_attach_observer): every wave also adds the moments of its 64 observation records and
     // discounted returns to the head's accumulators (acc_*), so the head needs no pass over the batch
     unsigned long long* acc;                     // nullable [FWG_ACC_SHARDS][acc_cols] fixed-point sums
@@ -105,23 +107,6 @@ __device__ __forceinline__ void acc_flush(unsigned long long* acc, int cols, int
                                  : ((X((((col) - 4) >> 1))) - (MEAN)[(((col) - 4) >> 1)]) * ((X((((col) - 4) >> 1))) - (MEAN)[(((col) - 4) >> 1)])) \
            : 0.f)
 
-__device__ __forceinline__ int dev_pmod(long long a, int m) { return m > 0 ? (int)(((a % m) + m) % m) : 0; }
-// ring positions of this launch: host-computed kernel arguments, or derived from the device-resident counter
-__device__ __forceinline__ KArgs resolve_slots(const DevCfg& c, const KArgs& A0) {
-    KArgs A = A0;
-    if (A0.gstep_in != nullptr) {
-        const long long g = *A0.gstep_in - (A0.reset_launch ? 1 : 0);
-        A.gnow = g;
-        A.slot_act = dev_pmod(g, c.L.window);
-        A.slot_end = dev_pmod(g, FWG_END_WINDOW);
-        A.slot_lag = dev_pmod(g, c.L.lag_depth);
-        A.bit_goal = dev_pmod(g, c.streak_req);
-#pragma unroll
-        for (int r = 0; r < FWG_MAX_ROWS; ++r) A.lag_slots[r] = dev_pmod(g - (long long)r * c.obs_step, c.L.lag_depth);
-    }
-    return A;
-}
-
 // ---- observation row log (DevCfg::obs_log = L > 0, include/fwgym.h "Row-log observations"): float [obs_step][L][N][n_obs].
 // A parity (global step mod obs_step) appends its records in DESCENDING row order from row P - 1 down to 0,
 // P = L - (length - 1); the step that would run off the top first copies the length - 1 newest rows (0 .. length-2) to
@@ -136,6 +121,27 @@ __host__ __device__ inline long long log_plane(int S, int L, int len, long long 
     const long long qc = log_fdiv(g - log_pmod(g - p, S), S);   // newest step of that parity not after g
     return (long long)p * L + (P - 1 - log_pmod(qp, P)) + (long long)P * (log_fdiv(qc, P) - log_fdiv(qp, P));
 }
+__device__ __forceinline__ int dev_pmod(long long a, int m) { return m > 0 ? (int)(((a % m) + m) % m) : 0; }
+// ring positions of this launch: host-computed kernel arguments, or derived from the device-resident counter
+__device__ __forceinline__ KArgs resolve_slots(const DevCfg& c, const KArgs& A0) {
+    KArgs A = A0;
+    if (A0.gstep_in != nullptr) {
+        const long long g = *A0.gstep_in - (A0.reset_launch ? 1 : 0);
+        A.gnow = g;
+        if (c.obs_log > 0) {
+            A.log_win = log_plane(c.obs_step, c.obs_log, c.obs_length, g, g);
+            A.log_wrap_now = log_pmod(log_fdiv(g, c.obs_step), c.obs_log - (c.obs_length - 1)) == 0;
+        }
+        A.slot_act = dev_pmod(g, c.L.window);
+        A.slot_end = dev_pmod(g, FWG_END_WINDOW);
+        A.slot_lag = dev_pmod(g, c.L.lag_depth);
+        A.bit_goal = dev_pmod(g, c.streak_req);
+#pragma unroll
+        for (int r = 0; r < FWG_MAX_ROWS; ++r) A.lag_slots[r] = dev_pmod(g - (long long)r * c.obs_step, c.L.lag_depth);
+    }
+    return A;
+}
+
 __device__ __forceinline__ float* log_row(const DevCfg& c, float* log, long N, long e, long long plane) {
     return log + ((plane * N + e) * c.n_obs);
 }
@@ -169,9 +175,9 @@ __device__ __forceinline__ void log_load_rows(const DevCfg& c, const float* log,
     }
 }
 // the parity's wrap step: carry the length - 1 newest rows to the top of the log (all lanes, coalesced per row)
-__device__ __forceinline__ void log_wrap(const DevCfg& c, float* log, long N, long e, long long g, bool valid) {
+__device__ __forceinline__ void log_wrap(const DevCfg& c, float* log, long N, long e, long long g, bool valid, int due) {
     const int S = c.obs_step, L = c.obs_log, P = L - (c.obs_length - 1);
-    if (log_pmod(log_fdiv(g, S), P) != 0) return;   // wave-uniform
+    if (!due) return;   // wave-uniform
     const long long base = (long long)log_pmod(g, S) * L;
     if (valid) {
         for (int r = 0; r < c.obs_length - 1; ++r) {
