@@ -125,6 +125,23 @@ __device__ __forceinline__ void rhs(const DevCfg& c, const float (&y)[NB], const
 // the throttle), then the rate limit -- on the rate and on the travel over the micro-step -- and the value limits
 // (oracle/physics.py advance_actuators).  a = (elevon_r, elevon_l, throttle, elevon_r_rate, elevon_l_rate)
 __device__ __forceinline__ void advance_actuators(const DevCfg& c, float (&a)[5], const float (&sp)[3]) {
+#if !defined(FWG_EMU) && !defined(FWG_SCALAR_ACTUATORS)
+    // the two elevons side by side: the 2x2 transitions and the travel window as packed f32 operations
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 spv = {sp[0], sp[1]}, val = {a[0], a[1]}, rate = {a[3], a[4]};
+    const f2 x0 = val - spv;
+    const f2 p0 = {c.act_phi[0][0], c.act_phi[1][0]}, p1 = {c.act_phi[0][1], c.act_phi[1][1]};
+    const f2 p2 = {c.act_phi[0][2], c.act_phi[1][2]}, p3 = {c.act_phi[0][3], c.act_phi[1][3]};
+    const f2 v = spv + p0 * x0 + p1 * rate;
+    const f2 d = p2 * x0 + p3 * rate;
+    const f2 trav = {c.act_travel[0], c.act_travel[1]};
+    const f2 lo = val - trav, hi = val + trav;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        a[3 + k] = fclampf(d[k], -c.dot_max[k], c.dot_max[k]);
+        a[k] = fclampf(fclampf(v[k], lo[k], hi[k]), c.val_min[FWG_V_ELEVON_RIGHT + k], c.val_max[FWG_V_ELEVON_RIGHT + k]);
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float x0 = a[k] - sp[k], x1 = a[3 + k];
@@ -135,6 +152,7 @@ __device__ __forceinline__ void advance_actuators(const DevCfg& c, float (&a)[5]
         a[k] = fclampf(v, c.val_min[FWG_V_ELEVON_RIGHT + k], c.val_max[FWG_V_ELEVON_RIGHT + k]);
         a[3 + k] = d;
     }
+#endif
     a[2] = fclampf(sp[2] + c.act_ethr * (a[2] - sp[2]), c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
 }
 
