@@ -194,6 +194,15 @@ __device__ __forceinline__ Derived derive(const float (&y)[NY], const float (&wi
 
 // RK4 stage loop unrolled by two: measured -0.5...-0.7 us per step on every workload against the rolled loop (the stage
 // selectors fold), a full unroll is no better (code size)
+#ifndef FWG_MICRO_UNROLL
+#define FWG_MICRO_PRAGMA "unroll"
+#elif FWG_MICRO_UNROLL == 1
+#define FWG_MICRO_PRAGMA "unroll 1"
+#elif FWG_MICRO_UNROLL == 2
+#define FWG_MICRO_PRAGMA "unroll 2"
+#else
+#define FWG_MICRO_PRAGMA "unroll 4"
+#endif
 #ifndef FWG_STAGE_UNROLL
 #define FWG_STAGE_UNROLL 2
 #endif
@@ -219,14 +228,14 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const f
 #ifdef FWG_ABL_ACT1
         advance_actuators(c, a_half, sp);
 #else
-        for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_half, sp);
+        _Pragma(FWG_MICRO_PRAGMA) for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_half, sp);
 #endif
 #pragma unroll
         for (int i = 0; i < 5; ++i) a_full[i] = a_half[i];
 #ifdef FWG_ABL_ACT1
         advance_actuators(c, a_full, sp);
 #else
-        for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_full, sp);
+        _Pragma(FWG_MICRO_PRAGMA) for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_full, sp);
 #endif
         float acc[NB], ys[NB], k[NB];
 #pragma unroll

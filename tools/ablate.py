@@ -19,7 +19,7 @@ def build():
     procs = []
     for name, flags in VARIANTS.items():
         out = os.path.join(OUT, "libfwgym_{}.so".format(name))
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=fast",
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize",
                "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-DFWG_WITH_SPECS"] + flags + \
               ["-o", out, os.path.join(PKG, "csrc", "fwgym.hip")]
         procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
