@@ -4,17 +4,26 @@
 One "step" = one fused fwg_step launch advancing every env of this rank by one control step (dt = 0.01 s) including
 observation, reward, done, metrics and auto-reset, on synthetic raw actions already resident in HBM.
 
-Workload (BASELINE.json configs[2], the configuration the north-star target is quoted on): 65 536 envs per GPU, Dryden
-turbulence on ("moderate"), observation matrix 5 x 12 with lag step 2.  `--workload c2` selects configs[1]
-(4 096 envs, turbulence off, 14-vector).  Multi-GPU: one process per GPU (torchrun), envs sharded per rank with
-global env ids (weak scaling), the only collective is the RCCL all-gather of the 16-float success-metric vector every
-128 steps (examples/train_rl_controller.py:51-66,80-85 in the reference).
+Workloads (BASELINE.json configs): c3 (default; configs[2], the configuration the north-star target is quoted on):
+65 536 envs per GPU, Dryden turbulence on ("moderate"), observation matrix 5 x 12 with lag step 2.  c2 = configs[1]
+(4 096 envs, turbulence off, 14-vector).  c4 = configs[3]: the c3 settings at 32 768 envs per GPU (262 144 over 8 GPUs).
+c5 = configs[4]: the PPO rollout loop (env step + HIP rollout head).  --total-envs T shards a FIXED total over the ranks
+(strong scaling; `--total-envs 65536 --gpus 8` is the north-star headline).
 
-Prints ONE JSON line on rank 0 (see the contract in the task statement) with `roofline` and `cpu_baseline` objects.
+Multi-GPU: one process per GPU.  `python bench.py --gpus N` launches its own ranks through torch.distributed.run when it
+is not already running under one (before anything touches the GPU; the parent only waits and relays).  Envs are sharded
+per rank with global env ids, the only collective is the RCCL all-gather of the 16-float success-metric vector
+(examples/train_rl_controller.py:51-66,80-85 in the reference), once per replayed chunk of steps.
+
+The timed region replays the K launches from hipGraphs (no per-launch host work), bracketed by barrier + synchronize;
+`value` and `roofline` are both computed from that ONE wall-clock interval (max over ranks).  Prints ONE JSON line on
+rank 0 with `roofline` and (N = 1) `cpu_baseline` objects.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,15 +33,34 @@ for p in (ROOT, os.path.join(ROOT, "fixed-wing-gym_amd"), os.path.join(ROOT, "te
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
-ALG_BYTES = {"c3": 937, "c2": 417, "c5": 409}   # algorithmic bytes per env-step, SURVEY.md section 8(d)
-REDUCE_EVERY = 128
+ALG_BYTES = {"c3": 937, "c4": 937, "c2": 417, "c5": 409}   # algorithmic bytes per env-step, SURVEY.md section 8(d)
+MAX_CHUNK = 256                # steps per captured graph; the success reduction runs once per chunk
+STEADY_STATE_STEPS = 300       # untimed launches before the W warm-up steps (clocks / caches / code objects), disclosed in the line
 
 
 def workload(name):
     from gym_fixed_wing import presets
+    if name == "c4":
+        cfg, ckw, skw, _, _ = presets.workload("c3")
+        return cfg, ckw, skw, 32768, "C4: 32768 envs/GPU (262144 over 8 GPUs), Dryden turbulence moderate, obs 5x12 lag step 2, auto-reset, metrics on"
     return presets.workload(name)
 
 
+def source_hash():
+    """Identity of the kernel sources a profile / traffic figure belongs to."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "fixed-wing-gym_amd", "csrc")
+    for fn in sorted(os.listdir(base)):
+        fp = os.path.join(base, fn)
+        if os.path.isfile(fp):
+            with open(fp, "rb") as f:
+                h.update(fn.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baselines (reported next to the GPU number, never the thing measured)
+# ----------------------------------------------------------------------------------------------------------------------
 def _cpu_worker(args):
     """Bounded sample of the SAME workload on one host core with the float64 oracle ("port" of the reference's
     per-env Python step)."""
@@ -62,9 +90,43 @@ def cpu_baseline(wl, seconds):
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(wl, seconds, 100 + i) for i in range(cores)])
     total = sum(n / dt for n, dt in res)
-    return {"value": total, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "{} oracle processes (float64 NumPy restatement, 1 env each, same workload config) x {:.0f} s, "
-                      "{} env-steps in total".format(cores, seconds, sum(n for n, _ in res))}
+    out = {"value": total, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": "{} oracle processes (float64 NumPy restatement, 1 env each, same workload config) x {:.0f} s, "
+                     "{} env-steps in total".format(cores, seconds, sum(n for n, _ in res))}
+    try:   # second CPU number: the scalar C++ loop of oracle/cpu_step.cpp over OpenMP threads, when built
+        from oracle import cpu_native
+        nat = cpu_native.measure(wl, min(seconds, 8.0))
+        if nat is not None:
+            out["native"] = nat
+    except Exception as e:   # the baseline is optional reporting: never fail the bench line over it
+        out["native"] = {"error": str(e)[:200]}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def plan_chunks(k):
+    """K timed steps -> (chunk length, replays, single eager steps).  Captured chunks hold an even number of steps."""
+    even = k - (k % 2)
+    if even == 0:
+        return 0, 0, k
+    c = min(even, MAX_CHUNK)
+    c -= c % 2
+    while even % c:
+        c -= 2
+    return c, even // c, k % 2
+
+
+def spawn_ranks(args, argv):
+    """--gpus N without a launcher: start N ranks (one per GPU) before this process touches the GPU; relay rank 0's line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -72,178 +134,250 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"])
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
+    ap.add_argument("--total-envs", type=int, default=0, help="fixed TOTAL number of envs sharded over the ranks (strong scaling)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--obs-layout", default="dense", choices=["dense", "log"],
-                    help="c3: 'dense' = fwg_step writes the [N][5][12] batch (default); 'log' = observation history kept "
-                         "once as a row log, the observation is a zero-copy strided window of it (same values)")
+    ap.add_argument("--obs-layout", default="auto", choices=["auto", "dense", "log"],
+                    help="'auto' (default) = the env's default: lagged matrix observations are kept once as a row log and "
+                         "handed out as a zero-copy window / read in place by the rollout head; 'dense' = fwg_step writes "
+                         "the [N][5][12] batch every step")
     ap.add_argument("--rollout", default="auto", choices=["auto", "none", "fused"],
                     help="c5 only: 'fused' (default for c5) = env step + HIP rollout head (VecNormalize + MlpPolicy + "
-                         "sampling), replayed from one hipGraph per chunk of steps; 'none' = env step on stored actions")
+                         "sampling); 'none' = env step on stored actions")
+    ap.add_argument("--eager", action="store_true", help="launch every step from the host instead of replaying hipGraphs")
+    ap.add_argument("--emulate", action="store_true",
+                    help="TEST ONLY: host-emulation build of the kernels + gloo, tiny batch (exercises the launcher, the "
+                         "sharding and the collective on a machine without GPUs; the numbers are not measurements)")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus {} but launched with WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
+    from gym_fixed_wing import distributed as fd
     from gym_fixed_wing.vec_env import FixedWingVecEnv
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("FWG_BENCH_FORCE_DIST", "0") == "1"   # the latter: exercise RCCL on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        if args.emulate:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
 
     cfg, ckw, skw, n_envs, desc = workload(args.workload)
+    scaling = "weak"
     if args.envs:
         n_envs = args.envs
+    if args.emulate and not args.envs and not args.total_envs:
+        n_envs = 128
+    first = rank * n_envs
+    if args.total_envs:
+        first, n_envs = fd.shard(args.total_envs, rank, world)
+        scaling = "strong"
+        desc += " [{} envs in total, sharded]".format(args.total_envs)
+    log_rows = {"auto": None, "dense": 0, "log": None}[args.obs_layout]
+    if args.obs_layout == "log":
+        from gym_fixed_wing import presets as _presets
+        log_rows = _presets.OBS_LOG_ROWS
+    kw = {}
+    if args.emulate:
+        from emu.host_backend import HostBackend, build_emu
+        kw = {"_backend": HostBackend(), "_lib_path": build_emu()}
+        dev = None
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        kw = {"device": local}
     # derived_views=False: the rollout loop never reads roll/pitch/... back from the arena (they are in the
     # observations), so the kernel does not write those host-view rows
-    from gym_fixed_wing import presets as _presets
-    log_rows = _presets.OBS_LOG_ROWS if (args.obs_layout == "log" and args.workload == "c3") else 0
-    vec = FixedWingVecEnv(cfg, num_envs=n_envs, device=local, config_kw=ckw, sim_config_kw=skw, seed=0,
-                          env_id_base=rank * n_envs, auto_reset=True, derived_views=False, obs_log_rows=log_rows)
+    vec = FixedWingVecEnv(cfg, num_envs=n_envs, config_kw=ckw, sim_config_kw=skw, seed=0, env_id_base=first,
+                          auto_reset=True, derived_views=False, obs_log_rows=log_rows, **kw)
     vec.reset()
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    pool = [torch.rand((n_envs, 3), device=dev, generator=gen) * 2 - 1 for _ in range(32)]
-    red_dev = torch.zeros(16, device=dev)
-    gathered = torch.zeros(16 * world, device=dev) if use_dist else None
+    if args.emulate:
+        import numpy as np
+        rng = np.random.default_rng(1234 + rank)
+        pool = [rng.uniform(-1, 1, (n_envs, 3)).astype(np.float32) for _ in range(8)]
+        red_dev, gathered = None, None
+    else:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234 + rank)
+        pool = [torch.rand((n_envs, 3), device=dev, generator=gen) * 2 - 1 for _ in range(32)]
+        red_dev = torch.zeros(16, device=dev)
+        gathered = torch.zeros(16 * world, device=dev) if use_dist else None
+    seen = {"episodes": 0.0, "ranks": world}
 
     def reduce_step():
+        if args.emulate:
+            local_sums = torch.as_tensor(vec.reduce_success(), dtype=torch.float32)
+            if use_dist:
+                out = torch.empty(16 * world)
+                dist.all_gather_into_tensor(out, local_sums)
+                seen["episodes"] += float(out.view(world, 16)[:, 0].sum())
+            else:
+                seen["episodes"] += float(local_sums[0])
+            return
         vec.reduce_success_device(red_dev)         # local sums, device to device, stream-ordered (no host sync)
         if use_dist:
             dist.all_gather_into_tensor(gathered, red_dev)   # RCCL over xGMI: 64 B per rank
 
     fused = args.workload == "c5" and args.rollout != "none"
+    graphs = not (args.eager or args.emulate)
+    chunk, replays, singles = plan_chunks(args.steps) if graphs else (0, 0, args.steps)
+    wchunk, wreplays, wsingles = plan_chunks(args.warmup) if graphs else (0, 0, args.warmup)
     rollout = None
     if fused:   # BASELINE configs[4]: PPO rollout loop with a random-init 64-64 MlpPolicy, end to end
         from gym_fixed_wing.actor import DeviceActor
         from gym_fixed_wing.rollout import FusedRollout, MlpPolicy
-        chunk = next((c for c in (128, 64, 32, 16, 8, 4, 2) if args.steps % c == 0 and args.warmup % c == 0), 0)
-        if chunk == 0:
+        if args.steps % 2 or args.warmup % 2:
             raise SystemExit("--workload c5: --steps and --warmup must be even (hipGraph chunks)")
         torch.manual_seed(0)
-        actor = DeviceActor.for_env(vec, seed=7, env_id_base=rank * n_envs)
+        actor = DeviceActor.for_env(vec, seed=7, env_id_base=first)
         actor.load_policy(MlpPolicy(vec.obs_dim))
-        rollout = FusedRollout(vec, actor, chunk, graph=True)
+        rollout = {}
 
-    def run(k, t_offset):
-        if fused:
-            done_steps = 0
-            for _ in range(k // rollout.n_steps):
-                rollout.run()
-                done_steps += rollout.n_steps
-                if done_steps % REDUCE_EVERY == 0:
-                    reduce_step()
-            return
-        for t in range(k):
-            vec.step_device(pool[(t_offset + t) % len(pool)])
-            if (t + 1) % REDUCE_EVERY == 0:
-                reduce_step()
+        def get_rollout(n):
+            if n not in rollout:
+                rollout[n] = FusedRollout(vec, actor, n, graph=True)
+            return rollout[n]
 
-    run(args.warmup, 0)
-    torch.cuda.synchronize(dev)
+    step_graphs = {}
+
+    def step_graph(n, offset):
+        """hipGraph of n consecutive fwg_step launches on pool actions (n even)."""
+        key = (n, offset % len(pool))
+        if key not in step_graphs:
+            g = torch.cuda.CUDAGraph()
+            vec.capture_begin()
+            with torch.cuda.graph(g):
+                for t in range(n):
+                    vec.step_device(pool[(offset + t) % len(pool)], want_obs=False)
+            vec.capture_end()
+            step_graphs[key] = g
+        return step_graphs[key]
+
+    if graphs and not fused:
+        vec.set_graph_mode(True)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):            # lazy initialisation outside capture
+            vec.step_device(pool[0], want_obs=False), vec.step_device(pool[1], want_obs=False)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+
+    def run(c, r, s, offset):
+        """r replays of a c-step chunk (+ one success reduction / all-gather each), then s single launches."""
+        done_steps = 0
+        for _ in range(r):
+            if fused:
+                get_rollout(c).run()
+            else:
+                step_graph(c, offset).replay()
+                vec.note_replayed_steps(c)
+            done_steps += c
+            reduce_step()
+        for t in range(s):
+            vec.step_device(pool[(offset + done_steps + t) % len(pool)], want_obs=False)
+        if s and not r:
+            reduce_step()
+
+    # untimed: bring the device to its steady state (power state, caches, code objects, graph instantiation), then the
+    # W warm-up steps of the contract
+    extra = 0
+    if graphs:
+        pc = chunk if chunk else 2
+        while extra < STEADY_STATE_STEPS:
+            run(pc, 1, 0, 0)
+            extra += pc
+    run(wchunk, wreplays, wsingles, 0)
+    if not args.emulate:
+        torch.cuda.synchronize(dev)
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if not args.emulate:
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
-    run(args.steps, args.warmup)
-    ev1.record()
-    torch.cuda.synchronize(dev)
+    if not args.emulate:
+        ev0.record()
+    run(chunk, replays, singles, 0)
+    if not args.emulate:
+        ev1.record()
+        torch.cuda.synchronize(dev)
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    if not args.emulate:
+        torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([wall], device=dev, dtype=torch.float64)
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev if not args.emulate else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
+    event_ms = ev0.elapsed_time(ev1) / args.steps if not args.emulate else None
 
-    # dominant kernel: average fwg_step launch duration from HIP events on the launch stream, launches measured
-    # one by one in a separate short pass (no host work between the event pair)
-    durs = []
-    for t in range(64):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        vec.step_device(rollout.cur["actions"] if fused else pool[t % len(pool)])
-        b.record()
-        durs.append((a, b))
-    torch.cuda.synchronize(dev)
-    kern_ms = sorted(a.elapsed_time(b) for a, b in durs)
-    kern_ms = sum(kern_ms[8:-8]) / len(kern_ms[8:-8])
-    region_ms = ev0.elapsed_time(ev1) / args.steps
-
+    out = None
     if rank == 0:
-        total_envs = n_envs * world
+        total_envs = args.total_envs if args.total_envs else n_envs * world
         value = total_envs * args.steps / wall
-        # dominant kernel = k_step, one launch per step: its average duration is the HIP-event time of the timed region
-        # divided by the number of launches (back-to-back launches on one stream; includes the 1-in-128 reduction
-        # syncs).  `kernel_ms_isolated` (event pair around single launches, separate pass) is reported for comparison.
+        # ONE clock: the roofline figure is the same wall interval as `value`, for the dominant kernel (k_step, one launch
+        # per step; this rank's share of the envs).  kernel_ms_hip_events = HIP events around the same region, for reference.
         alg = ALG_BYTES[args.workload] * n_envs
-        achieved = alg / (region_ms * 1e-3) / 1e9
-        traffic = None
+        achieved = alg * args.steps / wall / 1e9
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        layout_log = bool(vec.obs_log_rows)
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(args.workload + ("_log" if log_rows else ""))
+                tj = json.load(f)
+            ent = tj.get(args.workload + ("_log" if layout_log else ""))
+            if ent and ent.get("source_hash") == source_hash():   # only a profile of THIS build counts
+                traffic, traffic_src = ent["bytes_per_launch"], ent["source"]
+            elif ent:
+                traffic_src = "profiles/traffic.json holds a figure for another build ({}): not reported".format(ent.get("source_hash"))
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "envs_per_gpu": n_envs, "total_envs": total_envs,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.emulate else "synthetic (HOST EMULATION: not a measurement)",
+            "config": {"workload": desc, "envs_per_gpu": n_envs, "total_envs": total_envs, "ranks": seen["ranks"],
                        "rk4_substeps": int(vec._c.n_substeps), "actuator_microsteps": int(vec._c.actuator_microsteps),
                        "specialised_kernel": vec.spec_index >= 0, "derived_views": False,
-                       "obs_layout": "row log [obs_step][{}][N][12] + zero-copy window".format(log_rows) if log_rows else "dense batch",
+                       "obs_layout": ("row log [obs_step][{}][N][12]: the observation is a zero-copy strided window of it "
+                                      "(FixedWingVecEnv default for lagged observations)".format(vec.obs_log_rows)) if layout_log else "dense batch",
+                       "launch": ("hipGraph replay: {} x {} steps + {} single".format(replays, chunk, singles)) if graphs else "one host launch per step",
+                       "steady_state_steps_before_warmup": extra,
                        "rollout_head": ("HIP VecNormalize + 64-64 MlpPolicy (bf16 MFMA, split operands) + sampling, "
-                                        "hipGraph chunks of {} steps".format(rollout.n_steps)) if fused else None,
-                       "success_allgather_every": REDUCE_EVERY},
+                                        "hipGraph chunks of {} steps".format(chunk)) if fused else None,
+                       "success_allgather_every": chunk if graphs and chunk else args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic["bytes_per_launch"] if traffic else None,
-                         "traffic_source": traffic["source"] if traffic else None,
-                         "kernel": "k_step + k_actor_act" if fused else "k_step", "kernel_ms": region_ms, "kernel_ms_isolated": kern_ms,
-                         "algorithmic_bytes_per_env_step": ALG_BYTES[args.workload]},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_step + k_actor_act" if fused else "k_step",
+                         "kernel_ms": wall / args.steps * 1e3, "kernel_ms_hip_events": event_ms,
+                         "clock": "wall clock of the timed region (the same interval as `value`)",
+                         "algorithmic_bytes_per_env_step": ALG_BYTES[args.workload], "source_hash": source_hash()},
         }
-        if args.workload == "c3" and not log_rows and world == 1:
-            # side measurement (never `value`): the same workload with row-log observations, the opt-in layout that keeps
-            # the observation history once and hands out a zero-copy window
-            alt = FixedWingVecEnv(cfg, num_envs=n_envs, device=local, config_kw=ckw, sim_config_kw=skw, seed=0,
-                                  env_id_base=rank * n_envs, auto_reset=True, derived_views=False,
-                                  obs_log_rows=_presets.OBS_LOG_ROWS)
-            alt.reset()
-            for t in range(200):
-                alt.step_device(pool[t % len(pool)])
-            torch.cuda.synchronize(dev)
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record()
-            for t in range(1000):
-                alt.step_device(pool[t % len(pool)])
-            a1.record()
-            torch.cuda.synchronize(dev)
-            alt_ms = a0.elapsed_time(a1) / 1000
-            alt.close()
-            out["row_log_observations"] = {"ms_per_step": alt_ms, "value": n_envs / alt_ms * 1e3, "unit": "env-steps/s",
-                                           "roofline_frac": alg / (alt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           "note": "opt-in obs_log_rows=32 (bench.py --obs-layout log); same observation values "
-                                                   "as a strided window, 697 B/env-step moved instead of 1 090"}
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+        if args.emulate:
+            out["emulated_episodes_seen"] = seen["episodes"]
     vec.close()
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:   # last, so that library banners (RCCL prints one on teardown) do not follow the result line
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and not args.emulate:   # after the process group is gone
+            out["cpu_baseline"] = cpu_baseline("c3" if args.workload == "c4" else args.workload, args.cpu_seconds)
         sys.stdout.flush()
         try:   # RCCL's banner sits in the C stdio buffer until exit when stdout is a pipe: push it out first
             import ctypes

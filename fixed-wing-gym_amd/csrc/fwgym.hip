@@ -106,11 +106,13 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     typedef KernelTypes<SPEC> KT;
     const DevCfg& c = SpecCfg<SPEC>::get(cp);
     const KArgs A = resolve_slots(c, A0);
-    if (A0.gstep_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *A0.gstep_out = *A0.gstep_in + 1;
+    if (A0.slots_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        *A0.slots_out = next_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, *A0.slots_in);
 #ifdef FWG_ABL_EMPTY  // FWG_ABL_*: measurement-only switches (tools/ablate.py), never defined in the product build
     return;
 #endif
     const DynCfg& dc = *dp;
+    FWG_TL(A, 0);
     const int lane = threadIdx.x;
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
@@ -165,8 +167,10 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     const int fail = 0;
     E.d = derive<TURB>(E.y, E.wind, gust);
 #else
+    FWG_TL(A, 1);
     const int fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
 #endif
+    FWG_TL(A, 2);
     const bool ok = fail == 0;
     if (!ok) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
     if (TURB && ok) {
@@ -178,8 +182,10 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 #ifndef FWG_ABL_NO_SIMSTORE
     if (valid) store_sim<TURB>(c, A.S, A.N, e, E);
 #endif
+    FWG_TL(A, 3);
     // everything streamed HBM -> LDS at kernel start is needed from here on; the integration above hid its latency
     dma_wait();
+    FWG_TL(A, 4);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         aring[A.slot_act * (4 * FWG_WAVE) + i] = raw[i];
@@ -346,9 +352,11 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
         }
     }
 
+    FWG_TL(A, 5);
 #ifndef FWG_ABL_NO_GYMSTORE
     store_gym(c, A.S, A.N, e, E, A.bit_goal, valid, false);
 #endif
+    FWG_TL(A, 6);
 
     // ---- phase D: observation (fixed_wing.py:776-846)
 #ifndef FWG_ABL_NO_LAG
@@ -366,6 +374,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     if (c.obs_length > 1 && (!ok || early)) fix_lagged_rows(c, A, e, E, T, ob, ok);
     if (c.obs_noise) add_obs_noise(c, A, e, E, ob);
 
+    FWG_TL(A, 7);
     // ---- phase E: episode end -- metrics block, success reduction, terminal observation, auto-reset
     const unsigned long long done_mask = __ballot(done && valid);
     // waves in which no episode ends have their final observation records here: the moments for an attached rollout head
@@ -450,6 +459,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     }
 
     if (A.acc != nullptr && done_mask != 0ull) step_moments(c, A, ob, reward, done, valid, lane, e);
+    FWG_TL(A, 8);
     // ---- phase F: outputs and the state write-back
 #ifndef FWG_ABL_NO_OBSWRITE
     if (c.obs_log == 0) {
@@ -476,6 +486,10 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
                 if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
         }
     }
+    FWG_TL(A, 9);
+#ifdef FWG_TIMELINE
+    if (A.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FWG_TL(A, 10); }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -528,6 +542,18 @@ __global__ void k_check_nan(const float* __restrict__ a, long n, int* flag) {
     if (i < n && a[i] != a[i]) atomicOr(flag, 1);
 }
 
+// row-log observations -> dense [N][length * n_obs] batch (fwg_obs_gather): one thread per 16-byte piece of the output
+__global__ void k_obs_gather(const float* __restrict__ log, float* __restrict__ out, const StepSlots* slots, long long win_host,
+                             long N, int n_obs, int length) {
+    const long long win = slots != nullptr ? slots->log_win : win_host;
+    const int q_per_row = n_obs >> 2, q_per_env = q_per_row * length;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * q_per_env) return;
+    const long e = i / q_per_env;
+    const int q = (int)(i - e * q_per_env), r = q / q_per_row, j4 = q - r * q_per_row;
+    reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(log + ((win + r) * N + e) * n_obs)[j4];
+}
+
 // =====================================================================================================================
 // host side: config lowering, handle, C ABI
 // =====================================================================================================================
@@ -554,11 +580,14 @@ struct fwg_handle {
     int device;
     uint64_t seed;
     int64_t gstep;  // number of env steps taken so far (drives the ring slots)
-    int graph_mode; // the counter lives on the device (d_gstep[2], double-buffered by the parity of the host count)
+    int graph_mode; // the ring positions live on the device (d_slots[2], double-buffered by the parity of the host count)
     int64_t gstep_at_capture;
-    long long* d_gstep;
+    StepSlots* d_slots;
     size_t lds_bytes;
     struct fwg_actor* observer;   // attached rollout head (fwg_attach_observer) or null
+#ifdef FWG_TIMELINE
+    long long* trace;
+#endif
 };
 
 static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) {
@@ -803,8 +832,8 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     HIP_TRY(hipMemcpy(h->d_dyn, &h->hd, sizeof(DynCfg), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->d_reduce, sizeof(float) * FWG_N_REDUCE));
     HIP_TRY(hipMalloc((void**)&h->d_flag, sizeof(int)));
-    HIP_TRY(hipMalloc((void**)&h->d_gstep, 2 * sizeof(long long)));
-    HIP_TRY(hipMemset(h->d_gstep, 0, 2 * sizeof(long long)));
+    HIP_TRY(hipMalloc((void**)&h->d_slots, 2 * sizeof(StepSlots)));
+    HIP_TRY(hipMemset(h->d_slots, 0, 2 * sizeof(StepSlots)));
     h->graph_mode = 0;
     HIP_TRY(hipMemcpy(h->d_cfg, &h->h, sizeof(DevCfg), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->d_reduce, 0, sizeof(float) * FWG_N_REDUCE));
@@ -816,7 +845,7 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
 int fwg_destroy(fwg_handle* h) {
     if (!h) return FWG_OK;
     (void)hipSetDevice(h->device);
-    (void)hipFree(h->d_cfg); (void)hipFree(h->d_dyn); (void)hipFree(h->d_reduce); (void)hipFree(h->d_flag); (void)hipFree(h->d_gstep);
+    (void)hipFree(h->d_cfg); (void)hipFree(h->d_dyn); (void)hipFree(h->d_reduce); (void)hipFree(h->d_flag); (void)hipFree(h->d_slots);
     delete h;
     return FWG_OK;
 }
@@ -847,20 +876,15 @@ int fwg_seed(fwg_handle* h, uint64_t seed) {
 
 int64_t fwg_global_step(const fwg_handle* h) { return h ? h->gstep : -1; }
 
-static inline int pmod(int64_t a, int m) { return m > 0 ? (int)(((a % m) + m) % m) : 0; }
-
-static void fill_slots(const fwg_handle* h, int64_t g, KArgs* A) {
+static StepSlots host_slots(const fwg_handle* h, int64_t g) {
     const DevCfg& d = h->h;
-    A->gnow = g;
-    if (d.obs_log > 0) {
-        A->log_win = log_plane(d.obs_step, d.obs_log, d.obs_length, g, g);
-        A->log_wrap_now = log_pmod(log_fdiv(g, d.obs_step), d.obs_log - (d.obs_length - 1)) == 0;
-    }
-    A->slot_act = pmod(g, d.L.window);
-    A->slot_end = pmod(g, FWG_END_WINDOW);
-    A->slot_lag = pmod(g, d.L.lag_depth);
-    A->bit_goal = pmod(g, d.streak_req);
-    for (int r = 0; r < FWG_MAX_ROWS; ++r) A->lag_slots[r] = pmod(g - (int64_t)r * d.obs_step, d.L.lag_depth);
+    return make_slots(d.obs_step, d.obs_log, d.obs_length, d.L.window, d.L.lag_depth, d.streak_req, (long long)g);
+}
+static void fill_slots(const fwg_handle* h, int64_t g, KArgs* A) {
+    const StepSlots s = host_slots(h, g);
+    A->gnow = s.gnow; A->log_win = s.log_win; A->log_wrap_now = s.log_wrap_now;
+    A->slot_act = s.slot_act; A->slot_end = s.slot_end; A->slot_lag = s.slot_lag; A->bit_goal = s.bit_goal;
+    for (int r = 0; r < FWG_MAX_ROWS; ++r) A->lag_slots[r] = s.lag_slots[r];
 }
 
 static void base_args(const fwg_handle* h, KArgs* A) {
@@ -877,7 +901,7 @@ int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const
     base_args(h, &A);
     A.mask = mask; A.init_state = init_state; A.init_target = init_target; A.obs = obs_out;
     fill_slots(h, h->gstep - 1, &A);  // initial records take the ring position of the last completed step
-    if (h->graph_mode) { A.gstep_in = h->d_gstep + (h->gstep & 1); A.reset_launch = 1; }
+    if (h->graph_mode) { A.slots_in = h->d_slots + (h->gstep & 1); A.reset_launch = 1; }
     launch<false>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return FWG_OK;
@@ -891,8 +915,11 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
     A.actions = actions; A.obs = obs_out; A.rew = reward_out; A.done = done_out; A.term = term_code_out;
     A.term_obs = terminal_obs_out; A.metrics = metrics_out; A.tgt_out = target_out;
     fill_slots(h, h->gstep, &A);
-    if (h->graph_mode) { A.gstep_in = h->d_gstep + (h->gstep & 1); A.gstep_out = h->d_gstep + ((h->gstep + 1) & 1); }
+    if (h->graph_mode) { A.slots_in = h->d_slots + (h->gstep & 1); A.slots_out = h->d_slots + ((h->gstep + 1) & 1); }
     observer_args(h, &A);
+#ifdef FWG_TIMELINE
+    A.trace = h->trace;
+#endif
     launch<true>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     h->gstep += 1;
@@ -907,8 +934,20 @@ int64_t fwg_obs_log_floats(const fwg_config* cfg, int64_t n_envs) {
 int fwg_obs_window(const fwg_handle* h, int64_t* plane) {
     if (!h || !plane) return fail_with(FWG_ERR_INVALID, "fwg_obs_window: null argument");
     if (h->h.obs_log <= 0) return fail_with(FWG_ERR_INVALID, "fwg_obs_window: the env writes the dense observation batch");
-    const long long g = h->gstep - 1;   // last completed step
-    *plane = log_plane(h->h.obs_step, h->h.obs_log, h->h.obs_length, g, g);
+    *plane = host_slots(h, h->gstep - 1).log_win;   // last completed step
+    return FWG_OK;
+}
+
+int fwg_obs_gather(const fwg_handle* h, const float* obs_log, float* obs_out, void* stream) {
+    if (!h || !obs_log || !obs_out) return fail_with(FWG_ERR_INVALID, "fwg_obs_gather: null argument");
+    if (h->h.obs_log <= 0) return fail_with(FWG_ERR_INVALID, "fwg_obs_gather: the env writes the dense observation batch");
+    if (h->h.n_obs & 3) return fail_with(FWG_ERR_INVALID, "fwg_obs_gather: n_obs must be a multiple of 4");
+    const long total = (long)h->n_envs * (h->h.n_obs >> 2) * h->h.obs_length;
+    // graph mode: the window of the last completed step is read from the device-resident positions (replay-safe)
+    const StepSlots* slots = h->graph_mode ? h->d_slots + ((h->gstep - 1) & 1) : nullptr;
+    hipLaunchKernelGGL(k_obs_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs_log, obs_out, slots,
+                       host_slots(h, h->gstep - 1).log_win, (long)h->n_envs, h->h.n_obs, h->h.obs_length);
+    HIP_TRY(hipGetLastError());
     return FWG_OK;
 }
 
@@ -940,17 +979,22 @@ int fwg_reduce_success_device(fwg_handle* h, float* out_dev, void* stream) {
 }
 
 int fwg_spec_index(const fwg_handle* h) { return h ? h->spec : -1; }
+#ifdef FWG_TIMELINE
+int fwg_debug_set_trace(fwg_handle* h, long long* trace_dev) { if (!h) return FWG_ERR_INVALID; h->trace = trace_dev; return FWG_OK; }
+#endif
 
 int fwg_set_graph_mode(fwg_handle* h, int enable, void* stream) {
     if (!h) return fail_with(FWG_ERR_INVALID, "null handle");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    if (enable) {
-        const long long g[2] = {(long long)h->gstep, (long long)h->gstep};
-        HIP_TRY(hipMemcpy(h->d_gstep, g, sizeof(g), hipMemcpyHostToDevice));
+    if (enable) {   // the launch for step g reads copy [g & 1]; the other copy still describes step g - 1 (what a reader
+        StepSlots s[2];   // of the LAST completed step's window wants, see fwg_actor_set_obs_log)
+        s[h->gstep & 1] = host_slots(h, h->gstep);
+        s[(h->gstep + 1) & 1] = host_slots(h, h->gstep - 1);
+        HIP_TRY(hipMemcpy(h->d_slots, s, sizeof(s), hipMemcpyHostToDevice));
     } else if (h->graph_mode) {
-        long long g[2];
-        HIP_TRY(hipMemcpy(g, h->d_gstep, sizeof(g), hipMemcpyDeviceToHost));
-        h->gstep = g[0] > g[1] ? g[0] : g[1];
+        StepSlots s[2];
+        HIP_TRY(hipMemcpy(s, h->d_slots, sizeof(s), hipMemcpyDeviceToHost));
+        h->gstep = s[0].gnow > s[1].gnow ? s[0].gnow : s[1].gnow;
     }
     h->graph_mode = enable ? 1 : 0;
     return FWG_OK;
@@ -1037,6 +1081,7 @@ struct fwg_actor {
     float* d_log_std;
     float* d_ret;
     size_t lds_act[2];     // dynamic LDS of k_actor_act<1>, <3>
+    const fwg_handle* log_env;   // fwg_actor_set_obs_log: `obs` arguments are this env's row log
 };
 
 static size_t actor_lds_bytes(int nk1, int parts) {
@@ -1053,6 +1098,12 @@ static ActorArgs actor_args(const fwg_actor* a) {
     A.D = a->D; A.nk1 = a->nk1; A.act_dim = a->act_dim; A.parity = a->parity; A.training = a->training;
     A.gamma = a->gamma; A.clip_obs = a->clip_obs; A.clip_rew = a->clip_rew; A.eps = a->eps;
     A.seed_lo = (unsigned)(a->seed & 0xFFFFFFFFull); A.seed_hi = (unsigned)(a->seed >> 32);
+    if (a->log_env != nullptr) {   // the window of the env's LAST completed step; read on the device in graph mode
+        const fwg_handle* h = a->log_env;
+        A.obs_n = h->h.n_obs;
+        A.obs_win = host_slots(h, h->gstep - 1).log_win;
+        A.obs_slots = h->graph_mode ? h->d_slots + ((h->gstep - 1) & 1) : nullptr;
+    }
     return A;
 }
 
@@ -1073,6 +1124,17 @@ int fwg_attach_observer(fwg_handle* h, fwg_actor* a) {
     if (a && (a->n_envs != h->n_envs || a->D != h->h.obs_dim || a->device != h->device))
         return fail_with(FWG_ERR_INVALID, "fwg_attach_observer: the head was created for another batch size / observation size / device");
     h->observer = a;
+    return FWG_OK;
+}
+
+int fwg_actor_set_obs_log(fwg_actor* a, const fwg_handle* env) {
+    if (!a) return fail_with(FWG_ERR_INVALID, "fwg_actor_set_obs_log: null actor");
+    if (env != nullptr) {
+        if (env->h.obs_log <= 0) return fail_with(FWG_ERR_INVALID, "fwg_actor_set_obs_log: the env writes the dense observation batch");
+        if (env->n_envs != a->n_envs || env->h.obs_dim != a->D || env->device != a->device || (env->h.n_obs & 3))
+            return fail_with(FWG_ERR_INVALID, "fwg_actor_set_obs_log: batch size / observation size / device mismatch (n_obs must be a multiple of 4)");
+    }
+    a->log_env = env;
     return FWG_OK;
 }
 

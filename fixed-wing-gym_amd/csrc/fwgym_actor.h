@@ -36,6 +36,9 @@ struct alignas(16) frag_t { unsigned x, y, z, w; };   // 8 bf16 = the A or B ope
 
 struct ActorArgs {
     const float* obs; const float* rew; const uint8_t* done;
+    // obs_n > 0: `obs` is an env's observation ROW LOG (fwgym_env.h): feature f = r obs_n + j of env e sits at
+    // obs[((win + r) N + e) obs_n + j], win = obs_slots->log_win (graph mode: read on the device) or obs_win (host value)
+    const StepSlots* obs_slots; long long obs_win; int obs_n;
     float* ret;
     ActorStats* stats;                  // [2], indexed by parity
     unsigned long long* acc; int acc_cols;   // [2][FWG_ACC_SHARDS][acc_cols]
@@ -75,6 +78,14 @@ __host__ __device__ inline float bf16_to_f32(unsigned h) {
     float f; memcpy(&f, &u, 4); return f;
 #endif
 }
+
+// address of features [f0, f0 + 4) of env e (f0 a multiple of 4; in log mode obs_n is a multiple of 4 too)
+__device__ __forceinline__ const float* actor_obs_at(const ActorArgs& A, long long win, long e, int f0) {
+    if (A.obs_n == 0) return A.obs + e * A.D + f0;
+    const int r = f0 / A.obs_n, j = f0 - r * A.obs_n;
+    return A.obs + ((win + r) * A.N + e) * A.obs_n + j;
+}
+__device__ __forceinline__ long long actor_obs_win(const ActorArgs& A) { return A.obs_slots != nullptr ? A.obs_slots->log_win : A.obs_win; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifdef FWG_EMU
@@ -214,8 +225,9 @@ __global__ __launch_bounds__(FWG_ACT_BLOCK) void k_actor_stats(const ActorArgs A
         dr = r - S.ret_mean;
     }
     unsigned long long* acc = A.acc + (size_t)A.parity * FWG_ACC_SHARDS * A.acc_cols;
-    const float* row = A.obs + (valid ? e : 0) * D;
-#define FWG_OBS_AT(k) row[k]
+    const long long win = actor_obs_win(A);
+    const long er = valid ? e : 0;
+#define FWG_OBS_AT(k) (actor_obs_at(A, win, er, (k) & ~3)[(k) & 3])
     for (int chunk = 0; 32 * chunk < 2 * D + 4; ++chunk) {
         float v[32];
 #pragma unroll
@@ -252,7 +264,8 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     // raw observation entries of this lane (k-slots of the first layer), requested before the statistics are folded
     const long e = (long)blockIdx.x * FWG_ACT_ENVS + wv * 32 + j;
     const bool valid = e < A.N;
-    const bool vec4 = (A.D & 3) == 0;
+    const bool vec4 = (A.D & 3) == 0 && (A.obs_n & 3) == 0;
+    const long long win = actor_obs_win(A);
     float raw_x[NK1][8];
 #pragma unroll
     for (int kk = 0; kk < NK1; ++kk) {
@@ -262,11 +275,11 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (valid && f0 < A.D) {
                 if (vec4) {
-                    const float4 g = *reinterpret_cast<const float4*>(A.obs + e * A.D + f0);
+                    const float4 g = *reinterpret_cast<const float4*>(actor_obs_at(A, win, e, f0));
                     v[0] = g.x; v[1] = g.y; v[2] = g.z; v[3] = g.w;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (f0 + i < A.D) v[i] = A.obs[e * A.D + f0 + i];
+                    for (int i = 0; i < 4; ++i) if (f0 + i < A.D) v[i] = A.obs[e * A.D + f0 + i];   // dense only (log: obs_n % 4 == 0)
                 }
             }
 #pragma unroll

@@ -24,10 +24,11 @@ struct KArgs {
     unsigned seed_lo, seed_hi;
     int slot_act, slot_end, slot_lag, bit_goal;  // ring positions of the CURRENT global step
     int lag_slots[FWG_MAX_ROWS];                 // ring slot holding the row pushed r*obs_step steps ago
-    // graph mode (fwg_set_graph_mode): the global step counter lives on the device so that a captured launch sequence
-    // can be replayed; double-buffered -- a step launch reads gstep_in and block 0 publishes gstep_in+1 to gstep_out
-    const long long* gstep_in;
-    long long* gstep_out;
+    // graph mode (fwg_set_graph_mode): the ring positions live on the device (StepSlots below), double-buffered -- a step
+    // launch reads *slots_in and its block 0 publishes the positions of the NEXT step to *slots_out, so that a captured
+    // launch sequence can be replayed
+    const struct StepSlots* slots_in;
+    struct StepSlots* slots_out;
     int reset_launch;                            // k_reset: positions refer to the LAST completed step (counter - 1)
     long long gnow;                              // global index of the step this launch refers to (row-log positions)
     long long log_win;                           // row-log mode: first plane of this step's window, and whether the
@@ -40,7 +41,16 @@ struct KArgs {
     float* acc_ret;                              // [N] discounted returns (VecNormalize.ret)
     float acc_gamma;
     int acc_cols;
+#ifdef FWG_TIMELINE   /* measurement builds only (tools/ablate.py): per-wave phase time stamps [block][16] */
+    long long* trace;
+#endif
 };
+#ifdef FWG_TIMELINE
+#define FWG_TL(A, i) do { if ((A).trace != nullptr) { const long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); \
+        if (threadIdx.x == 0) (A).trace[blockIdx.x * 16 + (i)] = t_; } } while (0)
+#else
+#define FWG_TL(A, i) do { } while (0)
+#endif
 
 // ---- batch-moment accumulators shared by k_step, k_actor_stats and k_actor_act.  Columns: 0 / 1 sum and sum of
 // squares of the return deviations (from the running mean), 2 / 3 number of observations / returns, 4 + 2k / 5 + 2k the
@@ -121,23 +131,72 @@ __host__ __device__ inline long long log_plane(int S, int L, int len, long long 
     const long long qc = log_fdiv(g - log_pmod(g - p, S), S);   // newest step of that parity not after g
     return (long long)p * L + (P - 1 - log_pmod(qp, P)) + (long long)P * (log_fdiv(qc, P) - log_fdiv(qp, P));
 }
-__device__ __forceinline__ int dev_pmod(long long a, int m) { return m > 0 ? (int)(((a % m) + m) % m) : 0; }
-// ring positions of this launch: host-computed kernel arguments, or derived from the device-resident counter
+// Ring positions of one global step g (graph mode keeps them on the device): everything here is g modulo something,
+// so the next step's positions follow from this step's by increments with wrap-around -- no division on the device.
+struct StepSlots {
+    long long gnow;                              // the global step index g
+    long long log_win;                           // row log: first plane of step g's window
+    int log_wrap_now;                            // row log: the parity's wrap copy is due at step g
+    int slot_act, slot_end, slot_lag, bit_goal;
+    int gmod_s, qmod_p;                          // row log: g mod obs_step, (g div obs_step) mod P
+    int lag_slots[FWG_MAX_ROWS];
+    int pad_;
+};
+__host__ __device__ inline int slots_pmod(long long a, int m) { return m > 0 ? (int)(((a % m) + m) % m) : 0; }
+// positions of step g from scratch (host; k_reset)
+__host__ __device__ inline StepSlots make_slots(int obs_step, int obs_log, int obs_length, int window, int lag_depth, int streak_req,
+                                                long long g) {
+    StepSlots s;
+    s.gnow = g;
+    s.log_win = 0; s.log_wrap_now = 0; s.gmod_s = 0; s.qmod_p = 0; s.pad_ = 0;
+    if (obs_log > 0) {
+        const int P = obs_log - (obs_length - 1);
+        s.gmod_s = log_pmod(g, obs_step);
+        s.qmod_p = log_pmod(log_fdiv(g, obs_step), P);
+        s.log_win = (long long)s.gmod_s * obs_log + (P - 1 - s.qmod_p);   // = log_plane(obs_step, obs_log, obs_length, g, g)
+        s.log_wrap_now = s.qmod_p == 0;
+    }
+    s.slot_act = slots_pmod(g, window);
+    s.slot_end = slots_pmod(g, FWG_END_WINDOW);
+    s.slot_lag = slots_pmod(g, lag_depth);
+    s.bit_goal = slots_pmod(g, streak_req);
+    for (int r = 0; r < FWG_MAX_ROWS; ++r) s.lag_slots[r] = slots_pmod(g - (long long)r * obs_step, lag_depth);
+    return s;
+}
+__host__ __device__ inline int slots_inc(int v, int m) { return (m > 0 && v + 1 < m) ? v + 1 : 0; }
+// positions of step g + 1 from those of step g
+__host__ __device__ inline StepSlots next_slots(int obs_step, int obs_log, int obs_length, int window, int lag_depth, int streak_req,
+                                                const StepSlots& c) {
+    StepSlots s = c;
+    s.gnow = c.gnow + 1;
+    if (obs_log > 0) {
+        const int P = obs_log - (obs_length - 1);
+        s.gmod_s = c.gmod_s + 1;
+        if (s.gmod_s >= obs_step) { s.gmod_s = 0; s.qmod_p = slots_inc(c.qmod_p, P); }
+        s.log_win = (long long)s.gmod_s * obs_log + (P - 1 - s.qmod_p);
+        s.log_wrap_now = s.qmod_p == 0;
+    }
+    s.slot_act = slots_inc(c.slot_act, window);
+    s.slot_end = slots_inc(c.slot_end, FWG_END_WINDOW);
+    s.slot_lag = slots_inc(c.slot_lag, lag_depth);
+    s.bit_goal = slots_inc(c.bit_goal, streak_req);
+    for (int r = 0; r < FWG_MAX_ROWS; ++r) s.lag_slots[r] = slots_inc(c.lag_slots[r], lag_depth);
+    return s;
+}
+// ring positions of this launch: host-computed kernel arguments, or read from the device-resident StepSlots
+__device__ __forceinline__ void apply_slots(KArgs& A, const StepSlots& s) {
+    A.gnow = s.gnow; A.log_win = s.log_win; A.log_wrap_now = s.log_wrap_now;
+    A.slot_act = s.slot_act; A.slot_end = s.slot_end; A.slot_lag = s.slot_lag; A.bit_goal = s.bit_goal;
+#pragma unroll
+    for (int r = 0; r < FWG_MAX_ROWS; ++r) A.lag_slots[r] = s.lag_slots[r];
+}
 __device__ __forceinline__ KArgs resolve_slots(const DevCfg& c, const KArgs& A0) {
     KArgs A = A0;
-    if (A0.gstep_in != nullptr) {
-        const long long g = *A0.gstep_in - (A0.reset_launch ? 1 : 0);
-        A.gnow = g;
-        if (c.obs_log > 0) {
-            A.log_win = log_plane(c.obs_step, c.obs_log, c.obs_length, g, g);
-            A.log_wrap_now = log_pmod(log_fdiv(g, c.obs_step), c.obs_log - (c.obs_length - 1)) == 0;
-        }
-        A.slot_act = dev_pmod(g, c.L.window);
-        A.slot_end = dev_pmod(g, FWG_END_WINDOW);
-        A.slot_lag = dev_pmod(g, c.L.lag_depth);
-        A.bit_goal = dev_pmod(g, c.streak_req);
-#pragma unroll
-        for (int r = 0; r < FWG_MAX_ROWS; ++r) A.lag_slots[r] = dev_pmod(g - (long long)r * c.obs_step, c.L.lag_depth);
+    if (A0.slots_in != nullptr) {
+        if (A0.reset_launch)   // k_reset: positions of the LAST completed step (rare launch: computed from scratch)
+            apply_slots(A, make_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, A0.slots_in->gnow - 1));
+        else
+            apply_slots(A, *A0.slots_in);
     }
     return A;
 }

@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 12
+FWG_ABI_VERSION = 13
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -142,7 +142,8 @@ EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fw
            "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index", "fwg_set_graph_mode", "fwg_note_replayed_steps",
            "fwg_capture_begin", "fwg_capture_end", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
            "fwg_actor_set_stats", "fwg_actor_get_stats", "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe",
-           "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window", "fwg_reduce_success_device"]
+           "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window", "fwg_reduce_success_device",
+           "fwg_obs_gather", "fwg_actor_set_obs_log"]
 _libs = {}
 
 
@@ -208,6 +209,10 @@ def load_library(path=None):
     lib.fwg_obs_log_floats.restype = i64
     lib.fwg_obs_window.argtypes = [vp, C.POINTER(i64)]
     lib.fwg_obs_window.restype = C.c_int
+    lib.fwg_obs_gather.argtypes = [vp, vp, vp, vp]
+    lib.fwg_obs_gather.restype = C.c_int
+    lib.fwg_actor_set_obs_log.argtypes = [vp, vp]
+    lib.fwg_actor_set_obs_log.restype = C.c_int
     lib.fwg_attach_observer.argtypes = [vp, vp]
     lib.fwg_attach_observer.restype = C.c_int
     lib.fwg_actor_act.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]

@@ -74,6 +74,8 @@ class DeviceActor(object):
         if getattr(self, "_handle", None):
             try:
                 self.detach()
+                if getattr(self, "_log_env", None) is not None:
+                    self._lib.fwg_actor_set_obs_log(self._handle, ctypes.c_void_p())
             except Exception:   # interpreter shutdown: module globals may already be gone
                 pass
             self._lib.fwg_actor_destroy(self._handle)
@@ -131,6 +133,13 @@ class DeviceActor(object):
         if vec is not None and getattr(vec, "_handle", None):
             nat.check(self._lib, self._lib.fwg_attach_observer(vec._handle, ctypes.c_void_p()))
         self._attached = None
+
+    def set_obs_log(self, vec):
+        """Row-log observations: from now on the `obs` given to observe()/act() is `vec`'s observation row log
+        (vec._obs_buf) and the head reads the current window out of it in place -- no dense copy, and safe under hipGraph
+        replay because the window position is read on the device (fwg_actor_set_obs_log).  None: dense batches again."""
+        nat.check(self._lib, self._lib.fwg_actor_set_obs_log(self._handle, vec._handle if vec is not None else ctypes.c_void_p()))
+        self._log_env = vec
 
     def _p(self, t):
         return ctypes.c_void_p() if t is None else self._mem.ptr(t)

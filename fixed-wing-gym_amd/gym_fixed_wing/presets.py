@@ -88,6 +88,7 @@ SPECIALISED = [
     ("c5_examples_lean", "examples", None, None),
     # "_log": observation history as a row log + zero-copy window (FixedWingVecEnv(obs_log_rows=OBS_LOG_ROWS))
     ("c3_cnn_step2_dryden_lean_log", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),
+    ("c3_cnn_step2_dryden_log", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),
 ]
 OBS_LOG_ROWS = 32
 

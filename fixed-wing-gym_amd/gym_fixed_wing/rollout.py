@@ -180,26 +180,30 @@ class FusedRollout(object):
         self._primed = False
         self._graph = None
         # the env step kernel leaves the batch moments itself (two launches per step) -- except with row-log observations,
-        # where the lagged rows never pass through the step kernel: then the head takes them in a launch of its own
+        # where the lagged rows never pass through the step kernel: then the head reads the window out of the log in place
+        # (fwg_actor_set_obs_log: position read on the device, replay-safe) and takes the moments in a launch of its own
         self._attached = not getattr(vec, "obs_log_rows", 0)
         if self._attached:
             actor.attach(vec)
+        else:
+            actor.set_obs_log(vec)
         if graph:
             self._capture()
 
     def _prime(self):
         if not self._primed:   # first observation after reset(): no transition led here
             c = self.cur
-            self.actor.observe(self.vec._obs)
-            self.actor.act(self.vec._obs, norm_obs=c["obs"], action=c["actions"], value=c["values"], logp=c["logp"])
+            o = self.vec._obs if self._attached else self.vec._obs_buf
+            self.actor.observe(o)
+            self.actor.act(o, norm_obs=c["obs"], action=c["actions"], value=c["values"], logp=c["logp"])
             self._primed = True
 
     def _step(self, action, nxt, reward_out=None, done_out=None):
         """One env step under `action`, then the head on the new observation writing into the slices of `nxt`."""
         vec, actor = self.vec, self.actor
-        o, r, d = vec.step_device(action)
+        o, r, d = vec.step_device(action, want_obs=self._attached)
         if not self._attached:
-            o = o.contiguous() if hasattr(o, "contiguous") else np.ascontiguousarray(o)
+            o = vec._obs_buf    # the row log itself: the head windows it on the device
             actor.observe(o, r, d)
         actor.act(o, reward=r, done=d, norm_obs=nxt["obs"], action=nxt["actions"], value=nxt["values"], logp=nxt["logp"],
                   norm_reward=reward_out, done_out=done_out)

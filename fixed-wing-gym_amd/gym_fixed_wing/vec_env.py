@@ -90,7 +90,7 @@ class LazyInfos(object):
 class FixedWingVecEnv(object):
     def __init__(self, config_path=None, num_envs=1, device=0, sim_config_path=None, sim_parameter_path=None,
                  config_kw=None, sim_config_kw=None, auto_reset=True, as_numpy=False, env_id_base=0, seed=0,
-                 derived_views=True, specialize=None, obs_log_rows=0, _backend=None, _lib_path=None):
+                 derived_views=True, specialize=None, obs_log_rows=None, _backend=None, _lib_path=None):
         self.env_config = EnvConfig(config_path, sim_config_path, sim_parameter_path, config_kw, sim_config_kw)
         self.cfg = self.env_config.cfg
         self.num_envs = int(num_envs)
@@ -111,9 +111,14 @@ class FixedWingVecEnv(object):
         self.target_names = list(ec.target_names)
         self.dt = ec.dt
 
-        # obs_log_rows = L > 0 (matrix observations, no observation noise): the observation history is kept once, as a
+        # obs_log_rows = L > 0 (lagged observations, no observation noise): the observation history is kept once, as a
         # row log, and the observation handed out is a zero-copy strided view of it (include/fwgym.h "Row-log
         # observations"): same values, 432 B/env-step less traffic at C3.  .contiguous() gives the dense batch.
+        # None (default) = row log wherever it applies (lagged rows, no observation noise, records of whole 16-byte
+        # groups), dense batch otherwise; 0 = always the dense batch.
+        if obs_log_rows is None:
+            from . import presets as _presets
+            obs_log_rows = _presets.OBS_LOG_ROWS if self._row_log_applies() else 0
         self.obs_log_rows = int(obs_log_rows)
         self._c = ec.compile(auto_reset=auto_reset, store_derived=self.derived_views, obs_log_rows=self.obs_log_rows)
         # configurations outside the build-time presets run the generic kernel unless a specialised copy of the
@@ -132,6 +137,8 @@ class FixedWingVecEnv(object):
         # state arena: 16-byte groups [rows/4][env][4] (word w of env e = state[w >> 2, e, w & 3]); zero = "never reset"
         self.state = m.zeros((self.layout.rows // 4, N, 4))
         self._obs = m.zeros((N, self.obs_dim))
+        self._obs_dense = self._obs        # dense [N][obs_dim] buffer (row-log mode: target of fwg_obs_gather)
+        self._graph_mode = False
         self._obs_buf = self._obs          # what fwg_reset / fwg_step write: the dense batch, or the row log
         if self.obs_log_rows:
             n_log = int(self._lib.fwg_obs_log_floats(ctypes.byref(self._c), N))
@@ -148,6 +155,12 @@ class FixedWingVecEnv(object):
         self.check_actions = False
         self._pending = None
         self.seed(seed)
+
+    def _row_log_applies(self):
+        ob = self.cfg["observation"]
+        noise = ob.get("noise", None)
+        noisy = noise is not None and (noise.get("var", 0) != 0 or noise.get("mean", 0) != 0)
+        return int(ob.get("length", 1)) > 1 and not noisy and len(ob["states"]) % 4 == 0
 
     # ------------------------------------------------------------------------------------------------------------------
     def close(self):
@@ -199,6 +212,8 @@ class FixedWingVecEnv(object):
         """Keeps the global step counter on the device so that a captured sequence of step launches (hipGraph /
         torch.cuda.CUDAGraph) can be replayed; see fwg_set_graph_mode in include/fwgym.h for the rules."""
         nat.check(self._lib, self._lib.fwg_set_graph_mode(self._handle, int(bool(enable)), self._mem.stream()))
+        self._graph_mode = bool(enable)
+        self._refresh_obs_view()
 
     def capture_begin(self):
         nat.check(self._lib, self._lib.fwg_capture_begin(self._handle))
@@ -208,7 +223,7 @@ class FixedWingVecEnv(object):
 
     def note_replayed_steps(self, n_steps):
         nat.check(self._lib, self._lib.fwg_note_replayed_steps(self._handle, int(n_steps)))
-        self._refresh_obs_view()   # row-log mode: the window moved with the replayed steps
+        self._refresh_obs_view(want_obs=False)   # row-log mode, direct calls: the window moved with the replayed steps
 
     @property
     def spec_index(self):
@@ -216,7 +231,8 @@ class FixedWingVecEnv(object):
         return int(self._lib.fwg_spec_index(self._handle))
 
     def _upload(self):
-        self._c = self.env_config.compile(auto_reset=self.auto_reset, store_derived=self.derived_views)
+        self._c = self.env_config.compile(auto_reset=self.auto_reset, store_derived=self.derived_views,
+                                          obs_log_rows=self.obs_log_rows)
         nat.check(self._lib, self._lib.fwg_update_config(self._handle, ctypes.byref(self._c)))
 
     def set_simulator_attr(self, key, value):
@@ -275,10 +291,26 @@ class FixedWingVecEnv(object):
         del n_sel
         return self._out(self._obs, (N,) + self.obs_shape)
 
-    def _refresh_obs_view(self):
-        """Row-log mode: the current observation is the window [plane, plane + length) of the log, env-major view
-        [N, length, n_obs] (zero-copy; valid until the next step/reset)."""
+    def obs_dense(self, out=None):
+        """Dense [N, obs_dim] copy of the current observation.  Row-log mode: gathered on the device from the window of
+        the last completed step (fwg_obs_gather; the position is read on the device in graph mode, so the call may be
+        captured and replayed)."""
         if not self.obs_log_rows:
+            return self._obs
+        out = self._obs_dense if out is None else out
+        nat.check(self._lib, self._lib.fwg_obs_gather(self._handle, self._mem.ptr(self._obs_buf), self._mem.ptr(out),
+                                                      self._mem.stream()))
+        return out
+
+    def _refresh_obs_view(self, want_obs=True):
+        """Row-log mode: the current observation is the window [plane, plane + length) of the log, env-major view
+        [N, length, n_obs] (zero-copy; valid until the next step/reset).  In graph mode a host-computed window would go
+        stale under replay, so the observation handed out is the dense copy gathered on the device instead."""
+        if not self.obs_log_rows:
+            return
+        if self._graph_mode:
+            if want_obs:
+                self._obs = self.obs_dense()
             return
         plane = ctypes.c_int64()
         nat.check(self._lib, self._lib.fwg_obs_window(self._handle, ctypes.byref(plane)))
@@ -305,14 +337,37 @@ class FixedWingVecEnv(object):
         self.step_async(actions)
         return self.step_wait()
 
-    def step_device(self, actions):
-        """Fast path for on-device rollouts: no info objects; returns the (obs, reward, done) device tensors."""
+    def step_device(self, actions, want_obs=True):
+        """Fast path for on-device rollouts: no info objects; returns the (obs, reward, done) device tensors.
+        `actions`: float32, contiguous, [N, 3], on this env's device.  want_obs=False (row-log mode): the caller reads
+        the observation out of the log itself (the HIP rollout head does, fwg_actor_set_obs_log), so no view/gather."""
         m = self._mem
+        actions = self._checked_actions(actions)
         nat.check(self._lib, self._lib.fwg_step(self._handle, m.ptr(actions), m.ptr(self._obs_buf), m.ptr(self._rew), m.ptr(self._done),
                                                 m.ptr(self._term), m.ptr(self._term_obs), m.ptr(self._metrics),
                                                 ctypes.c_void_p(), m.stream()))   # targets stay in the state arena
-        self._refresh_obs_view()
+        if want_obs:
+            self._refresh_obs_view()
         return self._obs, self._rew, self._done
+
+    def _checked_actions(self, actions):
+        """step_device hands the raw pointer to the kernel: anything but a float32 contiguous [N, 3] batch on this device
+        would be read as garbage, so it is rejected here (cheap attribute checks, no synchronisation)."""
+        shape = tuple(getattr(actions, "shape", ()))
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if n != self.num_envs * 3:
+            raise ValueError("step_device: actions must hold {} x 3 values, got shape {}".format(self.num_envs, shape))
+        if hasattr(actions, "is_contiguous"):   # torch tensor
+            import torch
+            if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self._mem.device:
+                raise ValueError("step_device: actions must be a contiguous float32 tensor on {} (got {} {} contiguous={})"
+                                 .format(self._mem.device, actions.dtype, actions.device, actions.is_contiguous()))
+        elif isinstance(actions, np.ndarray):
+            if actions.dtype != np.float32 or not actions.flags["C_CONTIGUOUS"]:
+                raise ValueError("step_device: actions must be a C-contiguous float32 array")
+        return actions
 
     # ------------------------------------------------------------------------------------------------------------------
     def _host(self, name, t):

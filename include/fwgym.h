@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 12
+#define FWG_ABI_VERSION 13
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -271,6 +271,10 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
  * fwg_step / fwg_reset.  Values are identical to the dense batch.  `plane` refers to the last completed step. */
 int64_t fwg_obs_log_floats(const fwg_config* cfg_host, int64_t n_envs);
 int fwg_obs_window(const fwg_handle* h, int64_t* plane);
+/* Dense copy [N][obs_length * n_obs] of the current window of `obs_log` (the buffer fwg_step writes), for consumers that
+ * need contiguous rows.  Stream-ordered; in graph mode the window position is read on the DEVICE, so the call may be
+ * captured and replayed (a host-side view from fwg_obs_window is only valid for direct calls).  n_obs % 4 == 0. */
+int fwg_obs_gather(const fwg_handle* h, const float* obs_log, float* obs_out, void* stream);
 
 /* Debug-mode check for NaN actions (fixed_wing.py:347); synchronises the stream. */
 int fwg_check_actions(fwg_handle* h, const float* actions, void* stream);
@@ -346,6 +350,11 @@ int fwg_actor_seed(fwg_actor* a, uint64_t seed, int64_t env_id_base);
  * would do in a launch of its own -- so that a rollout step is two launches (fwg_step, fwg_actor_act).  Same n_envs,
  * obs_dim and device required.  The env keeps a plain pointer: detach (or destroy the env) before fwg_actor_destroy. */
 int fwg_attach_observer(fwg_handle* h, fwg_actor* a);
+/* Row-log observations: after this call the `obs` argument of fwg_actor_observe / fwg_actor_act is `env`'s observation
+ * row log and the head reads the window of the env's last completed step out of it (strided, no dense copy; position
+ * taken from the host count for direct calls and from the device-resident positions in graph mode, so captured
+ * sequences replay correctly).  NULL switches back to dense [N][obs_dim] batches.  The head keeps a plain pointer. */
+int fwg_actor_set_obs_log(fwg_actor* a, const fwg_handle* env);
 /* Accumulates the batch moments of `obs` ([N][obs_dim]) and, when `reward` is not NULL, advances the discounted
  * returns (ret = ret * gamma + reward, zeroed where `done`) and accumulates their moments (VecNormalize.step_wait). */
 int fwg_actor_observe(fwg_actor* a, const float* obs, const float* reward, const uint8_t* done, void* stream);

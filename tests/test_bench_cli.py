@@ -1,0 +1,55 @@
+"""bench.py launches its own ranks for --gpus N (CPU dry run: host-emulation kernels + gloo; the GPU runs use the same
+launcher, sharding and reduction code with RCCL) and prints ONE JSON line whose fields follow the driver contract."""
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _bench(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, env=e, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_them():
+    p, out = _bench("--gpus", "2", "--emulate", "--steps", "6", "--warmup", "2", "--no-cpu-baseline")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2
+    assert out["config"]["total_envs"] == 2 * out["config"]["envs_per_gpu"] and out["scaling"] == "weak"
+    assert out["steps"] == 6 and out["warmup"] == 2 and out["metric"] == "env-steps/sec"
+    # one clock: value and the roofline figure describe the same interval
+    frac = out["value"] / out["n_gpus"] * out["roofline"]["algorithmic_bytes_per_env_step"] / 1e9 / out["roofline"]["peak"]
+    assert abs(frac - out["roofline"]["frac"]) <= 1e-9 + 1e-6 * frac
+    assert abs(out["ms_per_step"] - out["roofline"]["kernel_ms"]) < 1e-12
+
+
+def test_total_envs_is_strong_scaling():
+    p, out = _bench("--gpus", "2", "--emulate", "--total-envs", "96", "--steps", "4", "--warmup", "0", "--no-cpu-baseline",
+                    "--workload", "c2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["scaling"] == "strong" and out["config"]["total_envs"] == 96 and out["config"]["envs_per_gpu"] == 48
+
+
+def test_rank_count_mismatch_is_an_error():
+    p, out = _bench("--gpus", "4", "--emulate", "--steps", "2", "--warmup", "0", "--no-cpu-baseline",
+                    env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode == 2 and out is None
+
+
+def test_chunk_plan():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.plan_chunks(20) == (20, 1, 0)
+    assert bench.plan_chunks(2000) == (250, 8, 0)
+    assert bench.plan_chunks(5) == (4, 1, 1)
+    assert bench.plan_chunks(1) == (0, 0, 1)
+    c, r, s = bench.plan_chunks(1022)
+    assert c * r + s == 1022 and c % 2 == 0 and c <= bench.MAX_CHUNK

@@ -57,6 +57,22 @@ def test_gym_rollout_matches_oracle(case):
     vec.close()
 
 
+@pytest.mark.parametrize("case", [c for c in configs.CASES if c[1] == "cnn"], ids=[c[0] + "_dense" for c in configs.CASES if c[1] == "cnn"])
+def test_gym_rollout_matches_oracle_dense_batch(case):
+    """Lagged matrix observations default to the row log (zero-copy window); the dense [N][5][12] batch written by the
+    step kernel is the other layout of the same values and must hold the same parity."""
+    name, kind, ckw, skw = case
+    cfg = configs.reference_like(kind)
+    n, steps = 6, 130
+    vec = _vec(cfg, n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True, obs_log_rows=0)
+    assert vec.obs_log_rows == 0 and (vec.spec_index >= 0) == (name in configs.SPECIALISED_CASES)
+    orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
+    acts = _actions(5, steps, n)
+    res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3)
+    print(name, "dense", res)
+    vec.close()
+
+
 @pytest.mark.parametrize("turb", [False, True], ids=["calm", "dryden"])
 @pytest.mark.parametrize("n", [64, 4096, 65536])
 def test_single_step_state_parity_1e5(n, turb):

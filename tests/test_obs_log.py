@@ -109,7 +109,7 @@ def test_log_window_specialised_kernel_on_gpu():
     from gym_fixed_wing import presets
     cfg, ckw, skw, _, _ = presets.workload("c3")
     dense = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=4096, device=0, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw),
-                            derived_views=False, seed=2)
+                            derived_views=False, seed=2, obs_log_rows=0)
     log = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=4096, device=0, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw),
                           derived_views=False, seed=2, obs_log_rows=presets.OBS_LOG_ROWS)
     assert dense.spec_index >= 0 and log.spec_index >= 0 and dense.spec_index != log.spec_index
@@ -134,7 +134,7 @@ def test_log_window_under_graph_replay_on_gpu():
     import torch
     cfg = configs.reference_like("cnn")
     kw = dict(config_kw={"observation": {"step": 2}, "steps_max": 50}, sim_config_kw=copy.deepcopy(TURB), seed=9)
-    dense = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=512, device=0, **copy.deepcopy(kw))
+    dense = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=512, device=0, obs_log_rows=0, **copy.deepcopy(kw))
     log = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=512, device=0, obs_log_rows=12, **copy.deepcopy(kw))
     dense.reset(), log.reset()
     gen = torch.Generator(device="cuda"); gen.manual_seed(1)
@@ -157,4 +157,75 @@ def test_log_window_under_graph_replay_on_gpu():
         g.replay(); log.note_replayed_steps(8); torch.cuda.synchronize()
         for a in acts:
             od, _, _ = dense.step_device(a)
-        assert torch.equal(od.reshape(512, 5, 12), log._obs), "replay {}".format(rep)
+        assert torch.equal(od.reshape(512, 5, 12), log.obs_dense().reshape(512, 5, 12)), "replay {}".format(rep)
+
+
+def test_row_log_env_accepts_curriculum_and_simulator_updates_emulated():
+    """set_curriculum_level / set_simulator_attr re-upload the configuration: the row-log layout must survive that
+    (the re-compile has to carry obs_log_rows, otherwise fwg_update_config sees another state layout)."""
+    cfg = configs.reference_like("cnn")
+    vec = _emu_env(cfg, 5, 10, config_kw={"observation": {"step": 2}, "steps_max": 30}, sim_config_kw=copy.deepcopy(TURB))
+    dense = _emu_env(cfg, 5, 0, config_kw={"observation": {"step": 2}, "steps_max": 30}, sim_config_kw=copy.deepcopy(TURB))
+    for v in (vec, dense):
+        v.reset()
+        v.set_curriculum_level(0.5)
+        v.set_simulator_attr("turbulence_intensity", "severe")
+    rng = np.random.default_rng(0)
+    for t in range(45):
+        act = rng.uniform(-1, 1, (5, 3)).astype(np.float32)
+        oa, ra, da, _ = dense.step(act)
+        ob, rb, db, _ = vec.step(act)
+        np.testing.assert_array_equal(oa, ob)
+        np.testing.assert_array_equal(ra, rb)
+    assert vec.obs_log_rows == 10
+    vec.close(), dense.close()
+
+
+def test_default_layout_is_the_row_log_where_it_applies_emulated():
+    from emu.host_backend import HostBackend, build_emu
+    from gym_fixed_wing import presets
+    mk = lambda kind, **kw: FixedWingVecEnv(configs.reference_like(kind), num_envs=3, as_numpy=True, _backend=HostBackend(),
+                                            _lib_path=build_emu(), **kw)
+    assert mk("cnn").obs_log_rows == presets.OBS_LOG_ROWS            # lagged matrix observation, no noise
+    assert mk("cnn", obs_log_rows=0).obs_log_rows == 0               # explicit dense batch
+    assert mk("examples").obs_log_rows == 0                          # nothing to stack
+    assert mk("default").obs_log_rows == 0                           # observation noise re-draws every row each step
+    noisy = configs.reference_like("cnn")
+    noisy["observation"]["noise"] = {"mean": 0, "var": 0.1}
+    assert FixedWingVecEnv(noisy, num_envs=3, as_numpy=True, _backend=HostBackend(), _lib_path=build_emu()).obs_log_rows == 0
+
+
+@pytest.mark.parametrize("kind,rows,ckw", [("cnn", 10, {"observation": {"step": 2}, "steps_max": 23}),
+                                           ("cnn", 0, {"observation": {"step": 2}, "steps_max": 23}),
+                                           ("default", 0, {"steps_max": 17})])
+def test_device_resident_positions_equal_host_positions_emulated(kind, rows, ckw):
+    """Graph mode keeps the ring positions on the device and advances them by increments (no division); a run in that
+    mode must be indistinguishable from a run with host-computed positions -- incl. the row-log window that consumers
+    gather on the device (fwg_obs_gather) -- over many wraps of every ring and through resets."""
+    cfg = configs.reference_like(kind)
+    a = _emu_env(cfg, 6, rows, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(TURB))
+    b = _emu_env(cfg, 6, rows, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(TURB))
+    oa, ob = a.reset(), b.reset()
+    rng = np.random.default_rng(3)
+    for t in range(7):   # an odd number of direct steps first: the device copy starts at an odd parity
+        act = rng.uniform(-1, 1, (6, 3)).astype(np.float32)
+        a.step(act), b.step(act)
+    b.set_graph_mode(True)
+    np.testing.assert_array_equal(np.asarray(a._obs).reshape(6, -1), np.asarray(b._obs).reshape(6, -1))
+    for t in range(131):
+        act = rng.uniform(-1, 1, (6, 3)).astype(np.float32) * (2.5 if t % 13 == 0 else 1.0)
+        oa, ra, da, ia = a.step(act)
+        ob, rb, db, ib = b.step(act)
+        np.testing.assert_array_equal(da, db)
+        np.testing.assert_array_equal(ra, rb)
+        np.testing.assert_array_equal(np.asarray(oa).reshape(6, -1), np.asarray(ob).reshape(6, -1), err_msg="step {}".format(t))
+        if t == 60:   # a masked reset in the middle (k_reset derives the positions of the last completed step itself)
+            oa, ob = a.reset(indices=[1, 4]), b.reset(indices=[1, 4])
+            np.testing.assert_array_equal(np.asarray(oa).reshape(6, -1), np.asarray(ob).reshape(6, -1))
+    b.set_graph_mode(False)   # back to host positions: the host count is taken from the device
+    for t in range(9):
+        act = rng.uniform(-1, 1, (6, 3)).astype(np.float32)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        np.testing.assert_array_equal(np.asarray(oa).reshape(6, -1), np.asarray(ob).reshape(6, -1))
+    a.close(), b.close()

@@ -119,8 +119,8 @@ def _fused_vs_torch(vec, mk_actor, n_steps, graph=False):
     raw = []   # raw (obs, rew, done) per step, recorded through the env's step_device
     orig = vec.step_device
 
-    def spy(a):
-        o, r, d = orig(a)
+    def spy(a, want_obs=True):
+        o, r, d = orig(a)   # always with the observation: row-log envs hand out the window view here
         if not graph:
             raw.append((np.array(_to_np(o)), np.array(_to_np(r)), np.array(_to_np(d))))
         return o, r, d
@@ -230,3 +230,63 @@ def test_fused_rollout_on_a_row_log_env_equals_the_dense_one():
     for k in bufs[0]:
         np.testing.assert_allclose(bufs[0][k], bufs[1][k], rtol=0, atol=2e-6, err_msg=k)
     assert bufs[0]["dones"].sum() == 70
+
+
+@pytest.mark.gpu
+def test_graphed_rollout_on_row_log_env_matches_dense_over_replays_on_gpu():
+    """A captured rollout on a row-log env must keep reading the CURRENT window on every replay: the window position has
+    period obs_step * (L - length + 1) = 56 steps for L = 32, the captured chunk is 10 steps, so replays 2.. would read
+    stale planes if the position were baked in at capture time.  The head reads it on the device (fwg_actor_set_obs_log)."""
+    import copy
+    from gym_fixed_wing.actor import DeviceActor
+    from gym_fixed_wing.rollout import FusedRollout
+    cfg = configs.reference_like("cnn")
+    turb = {"turbulence": True, "turbulence_intensity": "moderate"}
+    runs = []
+    for rows in (0, 32):
+        vec = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=2048, device=0, config_kw={"observation": {"step": 2}, "steps_max": 37},
+                              sim_config_kw=copy.deepcopy(turb), obs_log_rows=rows, seed=4, derived_views=False)
+        vec.reset()
+        torch.manual_seed(0)
+        actor = DeviceActor.for_env(vec, seed=5)
+        actor.load_policy(MlpPolicy(60))
+        ro = FusedRollout(vec, actor, 10, graph=True)
+        reps = []
+        for rep in range(7):   # 70 steps: past one period of the window position and past steps_max
+            buf = ro.run()
+            torch.cuda.synchronize()
+            reps.append({k: v.detach().cpu().numpy().copy() for k, v in buf.items()})
+        dense_obs = vec.obs_dense().detach().cpu().numpy().copy()
+        runs.append((reps, dense_obs))
+        vec.close()
+    for rep, (a, b) in enumerate(zip(runs[0][0], runs[1][0])):
+        for k in a:
+            np.testing.assert_allclose(a[k], b[k], rtol=0, atol=2e-6, err_msg="replay {} {}".format(rep, k))
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])   # fwg_obs_gather after the replays == the dense batch
+    assert sum(int(r["dones"].sum()) for r in runs[0][0]) >= 2048
+
+
+@pytest.mark.gpu
+def test_actor_reads_the_row_log_window_in_place_on_gpu():
+    """fwg_actor_act on the row log (strided window, no dense copy) == the same head on the dense batch."""
+    import copy
+    from gym_fixed_wing.actor import DeviceActor
+    cfg = configs.reference_like("cnn")
+    vec = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=4096, device=0, config_kw={"observation": {"step": 2}, "steps_max": 50}, seed=1)
+    assert vec.obs_log_rows > 0
+    vec.reset()
+    torch.manual_seed(1)
+    pol = MlpPolicy(60)
+    a_log, a_dense = DeviceActor.for_env(vec, seed=3, training=False), DeviceActor.for_env(vec, seed=3, training=False)
+    a_log.load_policy(pol), a_dense.load_policy(pol)
+    a_log.set_obs_log(vec)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    for t in range(75):
+        act = torch.rand((4096, 3), device="cuda", generator=gen) * 2 - 1
+        o, r, d = vec.step_device(act)
+        if t % 5 == 0:
+            x = a_log.act(vec._obs_buf, deterministic=True)
+            y = a_dense.act(o.contiguous().reshape(4096, -1), deterministic=True)
+            for u, v in zip(x[:3], y[:3]):
+                assert torch.equal(u, v), "step {}".format(t)
+    vec.close()
