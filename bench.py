@@ -147,6 +147,10 @@ def main():
                     help="c5 only: 'fused' (default for c5) = env step + HIP rollout head (VecNormalize + MlpPolicy + "
                          "sampling); 'none' = env step on stored actions")
     ap.add_argument("--eager", action="store_true", help="launch every step from the host instead of replaying hipGraphs")
+    ap.add_argument("--stagger", type=int, default=0,
+                    help="S > 0: before the warm-up, reset 1/S of the envs every steps_max/S steps, so that episode ends (metrics, "
+                         "success reduction, in-kernel auto-reset) are spread evenly over the timed steps instead of all envs "
+                         "hitting steps_max at the same step")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: host-emulation build of the kernels + gloo, tiny batch (exercises the launcher, the "
                          "sharding and the collective on a machine without GPUs; the numbers are not measurements)")
@@ -208,6 +212,17 @@ def main():
     vec = FixedWingVecEnv(cfg, num_envs=n_envs, config_kw=ckw, sim_config_kw=skw, seed=0, env_id_base=first,
                           auto_reset=True, derived_views=False, obs_log_rows=log_rows, **kw)
     vec.reset()
+    if args.stagger and not args.emulate:
+        import numpy as _np
+        gen0 = torch.Generator(device=dev)
+        gen0.manual_seed(99 + rank)
+        a0 = torch.rand((n_envs, 3), device=dev, generator=gen0) * 2 - 1
+        per = max(1, int(vec.cfg["steps_max"]) // args.stagger)
+        for k in range(args.stagger):
+            vec.reset(indices=_np.arange(k, n_envs, args.stagger))
+            for _ in range(per):
+                vec.step_device(a0, want_obs=False)
+        torch.cuda.synchronize(dev)
     if args.emulate:
         import numpy as np
         rng = np.random.default_rng(1234 + rank)
@@ -358,7 +373,7 @@ def main():
                        "obs_layout": ("row log [obs_step][{}][N][12]: the observation is a zero-copy strided window of it "
                                       "(FixedWingVecEnv default for lagged observations)".format(vec.obs_log_rows)) if layout_log else "dense batch",
                        "launch": ("hipGraph replay: {} x {} steps + {} single".format(replays, chunk, singles)) if graphs else "one host launch per step",
-                       "steady_state_steps_before_warmup": extra,
+                       "steady_state_steps_before_warmup": extra, "staggered_episode_ages": args.stagger,
                        "rollout_head": ("HIP VecNormalize + 64-64 MlpPolicy (bf16 MFMA, split operands) + sampling, "
                                         "hipGraph chunks of {} steps".format(chunk)) if fused else None,
                        "success_allgather_every": chunk if graphs and chunk else args.steps},

@@ -100,20 +100,34 @@ __device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, co
 #endif
 }
 
-template <bool TURB, int SPEC>
-__global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A0) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// One env step for the 64 environments of a wave.  ROLE 0: the whole step in one wave (k_step).  ROLES 1 / 2: the step
+// split over the two waves of a 128-thread workgroup (k_step2), which then run on two SIMDs of the CU at the same time
+// -- a single wave issues at most one vector instruction every ~5 cycles however much is independent
+// (tools/ub_valu.hip), so the only way to shorten the step's dependent chain is to put its independent parts on
+// different waves:
+//   role 1 ("physics"): actions + simulator rows -> integration -> hands the new state to its partner through LDS,
+//                       then advances the Dryden filter and writes the simulator rows back;
+//   role 2 ("gym"):     bookkeeping rows, action windows, the turbulence noise (Philox + Box-Muller, handed to the
+//                       physics wave through LDS) while the integration runs; then goal / reward / targets / observation
+//                       / metrics / auto-reset on the state it receives.
+// Workgroup barriers: A = state and noise handed over; B = the physics wave's simulator rows are written (the gym wave's
+// auto-reset then overwrites them for lanes that end an episode).
+#define FWG_HAND_WORDS 20   /* y[4..15] | roll pitch yaw Va alpha beta | failure code | pad: five 16-byte LDS accesses per lane */
+
+template <bool TURB, int SPEC, int ROLE>
+__device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs& A0, float* lds) {
     typedef KernelTypes<SPEC> KT;
+    constexpr bool PHYS = ROLE != 2, GYM = ROLE != 1, SPLIT = ROLE != 0;
     const DevCfg& c = SpecCfg<SPEC>::get(cp);
     const KArgs A = resolve_slots(c, A0);
-    if (A0.slots_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    if (PHYS && A0.slots_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
         *A0.slots_out = next_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, *A0.slots_in);
 #ifdef FWG_ABL_EMPTY  // FWG_ABL_*: measurement-only switches (tools/ablate.py), never defined in the product build
     return;
 #endif
     const DynCfg& dc = *dp;
     FWG_TL(A, 0);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (FWG_WAVE - 1);
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
     const long e = valid ? env0 + lane : A.N - 1;
@@ -124,6 +138,8 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     typename KT::Obs ob = KT::obs(lds, M, lane);
     float* aring = lds + M.aring + lane * 4;   // this lane's entries of the raw-action window [slot][lane][4]
     float* cring = lds + M.cring + lane * 4;   // ... of the constrained-command window (only when observations need it)
+    float* hand = lds + M.total + lane * FWG_HAND_WORDS;                       // split kernel: physics -> gym
+    float* noise = lds + M.total + FWG_WAVE * FWG_HAND_WORDS + lane * 4;       // split kernel: gym -> physics
 
     // ---- phase A: issue every load up front.  The action windows stream HBM -> LDS (global_load_lds, no VGPRs, they
     // are addressed by the run-time ring slot); everything else goes to registers.
@@ -131,11 +147,12 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 #pragma unroll
     for (int i = 0; i < 3; ++i) raw[i] = A.actions[e * 3 + i];   // [N][3]: a wave reads 768 contiguous bytes
     Env E;
-    load_sim<TURB>(c, A.S, A.N, e, E);
+    if (PHYS) load_sim<TURB>(c, A.S, A.N, e, E);
+    load_cold(c, A.S, A.N, e, E);
 
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
     // LDS copy once the streamed window has landed, i.e. after the integration)
-    if (valid) GROUP(A.S, A.N, (L.act_ring >> 2) + A.slot_act, e) = make_float4(raw[0], raw[1], raw[2], 0.f);
+    if (GYM && valid) GROUP(A.S, A.N, (L.act_ring >> 2) + A.slot_act, e) = make_float4(raw[0], raw[1], raw[2], 0.f);
 
     // ---- phase B: action scaling (fixed_wing.py:349-354,439-459) and the simulator step (fixed_wing.py:358)
     float cmd[3];
@@ -148,77 +165,165 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     }
     float cmd_c[3], sp[3];
     constrain_commands(c, cmd, cmd_c, sp);
-    if (c.use_cmd_ring && valid)
+    if (GYM && c.use_cmd_ring && valid)
         GROUP(A.S, A.N, (L.cmd_ring >> 2) + A.slot_act, e) = make_float4(cmd_c[0], cmd_c[1], cmd_c[2], 0.f);
     float gust[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (TURB) dryden_output(c, E.dry, gust);
-    // second wave of requests: bookkeeping rows to registers, action windows and lagged observation rows HBM -> LDS;
-    // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
-    // order = order of need (returns are in order): bookkeeping rows, action windows, lagged observation rows
-    load_gym(c, A.S, A.N, e, E, A.bit_goal);
-    for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.act_ring >> 2) + s, e), lds + M.aring + s * (4 * FWG_WAVE));
-    if (c.use_cmd_ring)
-        for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
+    if (PHYS && TURB) dryden_output(c, E.dry, gust);
+    if (GYM) {
+        // second wave of requests: bookkeeping rows to registers, action windows and lagged observation rows HBM -> LDS;
+        // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
+        // order = order of need (returns are in order): bookkeeping rows, action windows, lagged observation rows
+        load_gym(c, A.S, A.N, e, E, A.bit_goal);
+        for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.act_ring >> 2) + s, e), lds + M.aring + s * (4 * FWG_WAVE));
+        if (c.use_cmd_ring)
+            for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
 #ifndef FWG_ABL_NO_LAG
-    if (c.obs_log == 0) stream_lag_rows(c, A, e, lds + M.lag);
-    else log_wrap(c, A.obs, A.N, e, A.gnow, valid, A.log_wrap_now);
+        if (c.obs_log == 0) stream_lag_rows(c, A, e, lds + M.lag);
+        else log_wrap(c, A.obs, A.N, e, A.gnow, valid, A.log_wrap_now);
 #endif
+    }
+    int fail = 0;
+    if (PHYS) {
 #ifdef FWG_ABL_NO_SIM
-    const int fail = 0;
-    E.d = derive<TURB>(E.y, E.wind, gust);
+        E.d = derive<TURB>(E.y, E.wind, gust);
 #else
-    FWG_TL(A, 1);
-    const int fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
+        FWG_TL(A, 1);
+        fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
 #endif
-    FWG_TL(A, 2);
-    const bool ok = fail == 0;
-    if (!ok) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
-    if (TURB && ok) {
+        FWG_TL(A, 2);
+        if (fail != 0) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
+    }
+    if (SPLIT && PHYS) {   // hand the committed state to the gym wave
+        float4* h4 = reinterpret_cast<float4*>(hand);
+        h4[0] = make_float4(E.y[4], E.y[5], E.y[6], E.y[7]);
+        h4[1] = make_float4(E.y[8], E.y[9], E.y[10], E.y[11]);
+        h4[2] = make_float4(E.y[12], E.y[13], E.y[14], E.y[15]);
+        h4[3] = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
+        h4[4] = make_float4(E.d.alpha, E.d.beta, u2f((unsigned)fail), 0.f);
+    }
+    float n[4] = {0.f, 0.f, 0.f, 0.f};   // the step's four standard normals for the Dryden filter
+    if (TURB && GYM) {   // (counters: the step and episode indices BEFORE this step; independent of the integration)
         const u4 b = philox4x32((unsigned)(A.env_base + e), E.steps, E.episode, FWG_STREAM_TURB, A.seed_lo, A.seed_hi);
-        float n[4];
         box_muller(b, n);
-        dryden_advance(c, E.dry, n);
+        if (SPLIT) *reinterpret_cast<float4*>(noise) = make_float4(n[0], n[1], n[2], n[3]);
     }
-#ifndef FWG_ABL_NO_SIMSTORE
-    if (valid) store_sim<TURB>(c, A.S, A.N, e, E);
-#endif
-    FWG_TL(A, 3);
-    // everything streamed HBM -> LDS at kernel start is needed from here on; the integration above hid its latency
-    dma_wait();
-    FWG_TL(A, 4);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        aring[A.slot_act * (4 * FWG_WAVE) + i] = raw[i];
-        if (c.use_cmd_ring) cring[A.slot_act * (4 * FWG_WAVE) + i] = cmd_c[i];
-    }
-
-    // ---- phase C: gym-side bookkeeping (fixed_wing.py:360-417)
-    if (c.metrics) {  // control_variation accumulator (fixed_wing.py:1109-1114)
-        if (E.steps > 0u) {   // the previous constrained command is recomputed from the previous raw action in the window
-            int sp_ = A.slot_act - 1; sp_ += (sp_ < 0) ? W : 0;
-            float pc[3];
-            if (c.use_cmd_ring) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) pc[i] = cring[sp_ * (4 * FWG_WAVE) + i];
-            } else {
-                float praw[3], psp[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float r_ = aring[sp_ * (4 * FWG_WAVE) + i];
-                    praw[i] = c.scale_actions ? (c.act_to_high[i] - c.act_to_low[i]) * (fclampf(r_, c.scale_low, c.scale_high) - c.scale_low) *
-                                                    c.inv_scale_span + c.act_to_low[i]
-                                              : r_;
-                }
-                constrain_commands(c, praw, pc, psp);
-            }
-            E.sdcmd += fabsf(cmd_c[0] - pc[0]) + fabsf(cmd_c[1] - pc[1]) + fabsf(cmd_c[2] - pc[2]);
-        }
-    }
-    E.steps += 1u;
-    E.sft += 1u;
+    // ---- the part of the gym bookkeeping that does not depend on this step's integration (it needs the streamed action
+    // windows only): in the split kernel the gym wave does it while the physics wave integrates
     bool done = false;
     unsigned term = FWG_TERM_NONE;
-    if (c.steps_max > 0 && E.steps >= (unsigned)c.steps_max) { done = true; term = FWG_TERM_STEPS; }
+    float fval_action[FWG_MAX_FACTORS];   // values of the reward factors of class "action" (fixed_wing.py:686-700)
+    float obs_action[FWG_MAX_OBS];        // "action" entries of the newest observation row (fixed_wing.py:813-828)
+    float tgt_next[3] = {0.f, 0.f, 0.f};  // targets propagated by one step, valid unless the target is resampled
+    auto gym_prework = [&]() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {   // the own action enters the LDS copy of the windows
+            aring[A.slot_act * (4 * FWG_WAVE) + i] = raw[i];
+            if (c.use_cmd_ring) cring[A.slot_act * (4 * FWG_WAVE) + i] = cmd_c[i];
+        }
+        if (c.metrics) {  // control_variation accumulator (fixed_wing.py:1109-1114)
+            if (E.steps > 0u) {   // the previous constrained command is recomputed from the previous raw action in the window
+                int sp_ = A.slot_act - 1; sp_ += (sp_ < 0) ? W : 0;
+                float pc[3];
+                if (c.use_cmd_ring) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) pc[i] = cring[sp_ * (4 * FWG_WAVE) + i];
+                } else {
+                    float praw[3], psp[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float r_ = aring[sp_ * (4 * FWG_WAVE) + i];
+                        praw[i] = c.scale_actions ? (c.act_to_high[i] - c.act_to_low[i]) * (fclampf(r_, c.scale_low, c.scale_high) - c.scale_low) *
+                                                        c.inv_scale_span + c.act_to_low[i]
+                                                  : r_;
+                    }
+                    constrain_commands(c, praw, pc, psp);
+                }
+                E.sdcmd += fabsf(cmd_c[0] - pc[0]) + fabsf(cmd_c[1] - pc[1]) + fabsf(cmd_c[2] - pc[2]);
+            }
+        }
+        E.steps += 1u;
+        E.sft += 1u;
+        if (c.steps_max > 0 && E.steps >= (unsigned)c.steps_max) { done = true; term = FWG_TERM_STEPS; }
+#pragma unroll
+        for (int f = 0; f < FWG_MAX_FACTORS; ++f) {
+            fval_action[f] = 0.f;
+            if (f >= c.n_factors) continue;
+            const DevFactor& F = c.factor[f];
+            if (F.cls != FWG_RC_ACTION) continue;
+            float val = 0.f;
+            if (F.type == FWG_RT_VALUE) val = fabsf(raw[0]) + fabsf(raw[1]) + fabsf(raw[2]);
+            else if (F.type == FWG_RT_DELTA) {
+                if (E.steps > 1u) {
+                    const int m = (int)min(E.steps, (unsigned)F.window);
+#pragma unroll
+                    for (int k = FWG_MAX_WINDOW - 2; k >= 0; --k) {
+                        if (k <= W - 2 && k <= m - 2) {
+                            int s_new = A.slot_act - k; s_new += (s_new < 0) ? W : 0;
+                            int s_old = A.slot_act - k - 1; s_old += (s_old < 0) ? W : 0;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i)
+                                val += fabsf(aring[s_new * (4 * FWG_WAVE) + i] - aring[s_old * (4 * FWG_WAVE) + i]);
+                        }
+                    }
+                }
+            } else {  // bound
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    val += raw[i] > c.act_bound_max[i] ? raw[i] - c.act_bound_max[i] : 0.f;
+                    val += raw[i] < c.act_bound_min[i] ? c.act_bound_min[i] - raw[i] : 0.f;
+                }
+            }
+            fval_action[f] = val;
+        }
+#pragma unroll
+        for (int j = 0; j < FWG_MAX_OBS; ++j) {
+            obs_action[j] = 0.f;
+            if (j < c.n_obs && c.obs[j].type == FWG_OBS_ACTION)   // E.steps >= 1 here: never the "no action yet" branch
+                obs_action[j] = action_obs(c, c.use_cmd_ring ? cring : aring, c.obs[j].src, c.obs[j].window, E.steps, A.slot_act, 0.f);
+        }
+        {   // targets advanced by one step (fixed_wing.py:401-404) for the common case that none is resampled this step
+            float keep[3] = {E.tgt[0], E.tgt[1], E.tgt[2]};
+            next_targets(c, E);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { tgt_next[k] = E.tgt[k]; E.tgt[k] = keep[k]; }
+        }
+    };
+    if (SPLIT && GYM) {
+        FWG_DMA_DRAIN();   // this wave's own streamed windows have landed (no other wave reads them)
+        FWG_WAVE_SYNC();
+        gym_prework();
+    }
+    if (SPLIT) __syncthreads();          // barrier A
+    if (SPLIT && PHYS && TURB) {
+        const float4 q = *reinterpret_cast<const float4*>(noise);
+        n[0] = q.x; n[1] = q.y; n[2] = q.z; n[3] = q.w;
+    }
+    if (SPLIT && GYM) {
+        const float4* h4 = reinterpret_cast<const float4*>(hand);
+        const float4 a = h4[0], b = h4[1], g = h4[2], d0 = h4[3], d1 = h4[4];
+        E.y[4] = a.x; E.y[5] = a.y; E.y[6] = a.z; E.y[7] = a.w; E.y[8] = b.x; E.y[9] = b.y; E.y[10] = b.z; E.y[11] = b.w;
+        E.y[12] = g.x; E.y[13] = g.y; E.y[14] = g.z; E.y[15] = g.w;
+        E.d.roll = d0.x; E.d.pitch = d0.y; E.d.yaw = d0.z; E.d.Va = d0.w; E.d.alpha = d1.x; E.d.beta = d1.y;
+        fail = (int)f2u(d1.z);
+    }
+    const bool ok = fail == 0;
+    if (PHYS) {
+        if (TURB && ok) dryden_advance(c, E.dry, n);
+#ifndef FWG_ABL_NO_SIMSTORE
+        if (valid) store_sim<TURB>(c, A.S, A.N, e, E);
+#endif
+        FWG_TL(A, 3);
+    }
+    if (SPLIT && PHYS) {   // barrier B: the simulator rows are written before the gym wave may overwrite them (auto-reset)
+        FWG_DMA_DRAIN();   // s_waitcnt vmcnt(0): covers stores as well
+        __syncthreads();
+        return;
+    }
+    // everything streamed HBM -> LDS at kernel start is needed from here on; the integration above hid its latency
+    if (!SPLIT) { dma_wait(); gym_prework(); }
+    FWG_TL(A, 4);
+
+    // ---- phase C: gym-side bookkeeping (fixed_wing.py:360-417)
     fill_vars(E, T);
     float err[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -247,28 +352,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
             const DevFactor& F = c.factor[f];
             float val = 0.f;
             if (F.cls == FWG_RC_ACTION) {
-                if (F.type == FWG_RT_VALUE) val = fabsf(raw[0]) + fabsf(raw[1]) + fabsf(raw[2]);
-                else if (F.type == FWG_RT_DELTA) {
-                    if (E.steps > 1u) {
-                        const int m = (int)min(E.steps, (unsigned)F.window);
-#pragma unroll
-                        for (int k = FWG_MAX_WINDOW - 2; k >= 0; --k) {
-                            if (k <= W - 2 && k <= m - 2) {
-                                int s_new = A.slot_act - k; s_new += (s_new < 0) ? W : 0;
-                                int s_old = A.slot_act - k - 1; s_old += (s_old < 0) ? W : 0;
-#pragma unroll
-                                for (int i = 0; i < 3; ++i)
-                                    val += fabsf(aring[s_new * (4 * FWG_WAVE) + i] - aring[s_old * (4 * FWG_WAVE) + i]);
-                            }
-                        }
-                    }
-                } else {  // bound
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        val += raw[i] > c.act_bound_max[i] ? raw[i] - c.act_bound_max[i] : 0.f;
-                        val += raw[i] < c.act_bound_min[i] ? c.act_bound_min[i] - raw[i] : 0.f;
-                    }
-                }
+                val = fval_action[f];
             } else if (F.cls == FWG_RC_STATE) {
                 val = (F.type == FWG_RT_VALUE) ? T.get(F.src) : (F.src == 0 ? err[0] : (F.src == 1 ? err[1] : err[2]));
             } else if (F.cls == FWG_RC_SUCCESS) {
@@ -319,9 +403,13 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
             }
         }
         // ---- target resampling / propagation (fixed_wing.py:397-404)
-        if (resample || (c.resample_every > 0 && E.sft >= (unsigned)c.resample_every))
+        if (resample || (c.resample_every > 0 && E.sft >= (unsigned)c.resample_every)) {
             sample_targets(c, dc, A, e, E, T, nullptr);
-        next_targets(c, E);
+            next_targets(c, E);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) E.tgt[k] = tgt_next[k];
+        }
 #pragma unroll
         for (int k = 0; k < FWG_MAX_TARGETS; ++k)
             if (k < c.n_targets) err[k] = target_error(c.target[k], E.tgt[k], T.get(c.target[k].var));
@@ -356,13 +444,25 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 #ifndef FWG_ABL_NO_GYMSTORE
     store_gym(c, A.S, A.N, e, E, A.bit_goal, valid, false);
 #endif
+    // the step's scalar outputs are final here: issued now, their write latency hides behind the observation build
+    // (info["target"] of a lane that ends its episode is the target BEFORE the reset, fixed_wing.py:435)
+    if (valid) {
+        A.rew[e] = reward;
+        A.done[e] = done ? 1 : 0;
+        A.term[e] = (uint8_t)term;
+        if (A.tgt_out != nullptr) {
+#pragma unroll
+            for (int k = 0; k < FWG_MAX_TARGETS; ++k)
+                if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
+        }
+    }
     FWG_TL(A, 6);
 
     // ---- phase D: observation (fixed_wing.py:776-846)
 #ifndef FWG_ABL_NO_LAG
     if (c.obs_log == 0) load_lag_rows(c, lds + M.lag + lane * 4, ob);
 #endif
-    build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid && c.obs_log == 0, A.slot_act);
+    build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid && c.obs_log == 0, A.slot_act, obs_action);
     // row-log mode: the lagged rows stay where they are; only lanes that need the COMPLETE record in registers (episode
     // end: terminal observation) read them back, and only early-episode / failed lanes compute rows of their own
     const bool early = c.obs_length > 1 && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
@@ -380,6 +480,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     // waves in which no episode ends have their final observation records here: the moments for an attached rollout head
     // go out before the remaining stores, whose issue then hides the round trip of the atomics
     if (A.acc != nullptr && done_mask == 0ull) step_moments(c, A, ob, reward, done, valid, lane, e);
+    if (SPLIT) __syncthreads();   // barrier B (the physics wave arrived long ago: its rows are in memory)
     if (done_mask != 0ull) {
         float red[FWG_N_REDUCE];
 #pragma unroll
@@ -443,7 +544,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
                 red[0] = 1.f;
             }
         }
-        if (A.term_obs != nullptr) write_obs(c, A.term_obs, env0, A.N, ob, lds + M.stage, lane, done_mask);
+        if (A.term_obs != nullptr) write_obs<ROLE>(c, A.term_obs, env0, A.N, ob, lds + M.stage, lane, done_mask);
         // per-wave reduction by shuffles, one atomic per value per wave (the per-GPU part of the success reduction of
         // examples/train_rl_controller.py:51-66,80-85)
 #pragma unroll
@@ -463,7 +564,7 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
     // ---- phase F: outputs and the state write-back
 #ifndef FWG_ABL_NO_OBSWRITE
     if (c.obs_log == 0) {
-        write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull);
+        write_obs<ROLE>(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull);
     } else {
         if (valid) log_store_row(c, A.obs, A.N, e, log_win, 0, ob);   // the new record: 64 consecutive rows per wave
         if (__ballot((done || early) && valid) != 0ull) {
@@ -476,20 +577,25 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 #else
     if (ob.get(0) == 1.2345e30f) A.obs[e] = ob.get(1) + ob.get(c.obs_dim - 1);
 #endif
-    if (valid) {
-        A.rew[e] = reward;
-        A.done[e] = done ? 1 : 0;
-        A.term[e] = (uint8_t)term;
-        if (A.tgt_out != nullptr) {
-#pragma unroll
-            for (int k = 0; k < FWG_MAX_TARGETS; ++k)
-                if (k < c.n_targets) A.tgt_out[e * c.n_targets + k] = E.tgt[k];
-        }
-    }
     FWG_TL(A, 9);
 #ifdef FWG_TIMELINE
     if (A.trace != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FWG_TL(A, 10); }
 #endif
+}
+
+template <bool TURB, int SPEC>
+__global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    step_wave<TURB, SPEC, 0>(cp, dp, A0, lds);
+}
+
+// the same step on two waves per 64 environments (specialised configurations only: the generic kernel keeps its tables
+// in lane-private LDS columns of ONE wave)
+template <bool TURB, int SPEC>
+__global__ __launch_bounds__(2 * FWG_WAVE, 2) void k_step2(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (threadIdx.x < FWG_WAVE) step_wave<TURB, SPEC, 1>(cp, dp, A0, lds);
+    else step_wave<TURB, SPEC, 2>(cp, dp, A0, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -519,7 +625,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     }
     if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane * 4, A.slot_end, A.slot_lag, A.bit_goal);
     if (c.obs_log == 0) {
-        write_obs(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
+        write_obs<0>(c, A.obs, env0, A.N, ob, lds + M.stage, lane, sel_mask);
     } else if (sel) {
         const long long win = A.log_win;
 #pragma unroll
@@ -540,6 +646,14 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
 __global__ void k_check_nan(const float* __restrict__ a, long n, int* flag) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && a[i] != a[i]) atomicOr(flag, 1);
+}
+
+// known-answer hook for the device Philox4x32-10 (fwg_selftest_philox): in[i] = counter[4] | key[2]
+__global__ void k_selftest_philox(const unsigned* __restrict__ in, unsigned* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u4 r = philox4x32(in[6 * i], in[6 * i + 1], in[6 * i + 2], in[6 * i + 3], in[6 * i + 4], in[6 * i + 5]);
+    out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
 }
 
 // row-log observations -> dense [N][length * n_obs] batch (fwg_obs_gather): one thread per 16-byte piece of the output
@@ -585,6 +699,7 @@ struct fwg_handle {
     StepSlots* d_slots;
     size_t lds_bytes;
     struct fwg_actor* observer;   // attached rollout head (fwg_attach_observer) or null
+    int split;                    // specialised configurations: the step runs as k_step2 (two waves per 64 envs)
 #ifdef FWG_TIMELINE
     long long* trace;
 #endif
@@ -820,6 +935,10 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     std::string why;
     if (lower_config(*cfg, &h->h, &h->hd, &why) != 0) { delete h; return fail_with(FWG_ERR_INVALID, why); }
     h->spec = match_spec(h->h);
+    {   // FWGYM_SPLIT=0 keeps the one-wave kernel (A/B measurements)
+        const char* env = getenv("FWGYM_SPLIT");
+        h->split = !(env != nullptr && env[0] == '0');
+    }
     h->n_envs = n_envs; h->env_base = env_id_base; h->device = device; h->seed = 0; h->gstep = 0;
     h->arena = (float*)state_arena;
     if ((int64_t)h->h.L.rows * n_envs >= (int64_t)1 << 30) { delete h; return fail_with(FWG_ERR_INVALID, "rows*n_envs must be < 2^30"); }
@@ -951,6 +1070,13 @@ int fwg_obs_gather(const fwg_handle* h, const float* obs_log, float* obs_out, vo
     return FWG_OK;
 }
 
+int fwg_selftest_philox(const uint32_t* ctr_key_dev, uint32_t* out_dev, int64_t n, void* stream) {
+    if (!ctr_key_dev || !out_dev || n < 1) return fail_with(FWG_ERR_INVALID, "fwg_selftest_philox: bad argument");
+    hipLaunchKernelGGL(k_selftest_philox, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctr_key_dev, out_dev, (long)n);
+    HIP_TRY(hipGetLastError());
+    return FWG_OK;
+}
+
 int fwg_check_actions(fwg_handle* h, const float* actions, void* stream) {
     if (!h || !actions) return fail_with(FWG_ERR_INVALID, "null argument");
     const long n = (long)h->n_envs * 3;
@@ -1045,8 +1171,16 @@ template <bool IS_STEP, bool TURB, int SPEC>
 static void launch_one(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
     const dim3 grid((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), block(FWG_WAVE);
     const size_t lds_bytes = (size_t)lds_map(h->h.obs_dim, h->h.n_obs, h->h.L.window, h->h.use_cmd_ring, SPEC < 0).total * sizeof(float);
-    if (IS_STEP) hipLaunchKernelGGL((k_step<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
-    else hipLaunchKernelGGL((k_reset<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
+    if (IS_STEP) {
+#ifndef FWG_NO_SPLIT
+        if (SPEC >= 0 && h->split) {
+            const size_t lds2 = lds_bytes + (size_t)FWG_WAVE * (FWG_HAND_WORDS + 4) * sizeof(float);
+            hipLaunchKernelGGL((k_step2<TURB, (SPEC >= 0 ? SPEC : 0)>), grid, dim3(2 * FWG_WAVE), lds2, stream, h->d_cfg, h->d_dyn, A);
+            return;
+        }
+#endif
+        hipLaunchKernelGGL((k_step<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
+    } else hipLaunchKernelGGL((k_reset<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
 }
 
 template <bool IS_STEP>

@@ -170,6 +170,17 @@ __device__ __forceinline__ void dma_group_once(const float4* src_lane_ptr, float
 #ifndef FWG_DMA_DRAIN
 #define FWG_DMA_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
+// ordering of LDS traffic between the lanes of ONE wave (k_step2: the other wave of the workgroup is not involved)
+#ifdef FWG_EMU
+#define FWG_WAVE_SYNC() emu_wave_sync()
+#else
+#define FWG_WAVE_SYNC()                                          \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+    } while (0)
+#endif
 __device__ __forceinline__ void dma_wait() {
     FWG_DMA_DRAIN();
     __syncthreads();

@@ -47,7 +47,7 @@ struct KArgs {
 };
 #ifdef FWG_TIMELINE
 #define FWG_TL(A, i) do { if ((A).trace != nullptr) { const long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); \
-        if (threadIdx.x == 0) (A).trace[blockIdx.x * 16 + (i)] = t_; } } while (0)
+        if ((threadIdx.x & 63) == 0) (A).trace[(blockIdx.x * 2 + (threadIdx.x >> 6)) * 16 + (i)] = t_; } } while (0)
 #else
 #define FWG_TL(A, i) do { } while (0)
 #endif
@@ -350,7 +350,9 @@ __device__ __forceinline__ void load_sim(const DevCfg& c, const float* __restric
 #pragma unroll
         for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = f[NY + i];
     }
-    // per-episode constants (written by reset only): steady wind + episode counter | initial errors
+}
+// per-episode constants (written by reset only): steady wind + episode counter
+__device__ __forceinline__ void load_cold(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
     const float4 w = CGROUP(S, N, (c.L.cold >> 2), e);
     E.wind[0] = w.x; E.wind[1] = w.y; E.wind[2] = w.z; E.episode = f2u(w.w);
 }
@@ -628,7 +630,8 @@ __device__ __forceinline__ float action_obs(const DevCfg& c, const float* ring, 
 // newest observation row (un-noised, normalised) into ob[0, n_obs) and, when `push`, into the lag ring (AoS record)
 template <class TAB, class OB>
 __device__ __forceinline__ void build_row0(const DevCfg& c, const KArgs& A, long e, const Env& E, const TAB& T, OB& ob,
-                                           const float* ring, int ring_slot, bool push, int act_slot) {
+                                           const float* ring, int ring_slot, bool push, int act_slot,
+                                           const float* pre_action = nullptr) {
 #pragma unroll
     for (int j = 0; j < FWG_MAX_OBS; ++j) {
         if (j < c.n_obs) {
@@ -637,7 +640,8 @@ __device__ __forceinline__ void build_row0(const DevCfg& c, const KArgs& A, long
             if (o.type == FWG_OBS_STATE) v = T.get(o.src);
             else if (o.type == FWG_OBS_TARGET_RELATIVE) v = T.get(FWG_TAB_ERR + o.src);
             else if (o.type == FWG_OBS_TARGET_ABSOLUTE) v = T.get(FWG_TAB_TGT + o.src);
-            else v = action_obs(c, ring, o.src, o.window, E.steps, act_slot, T.get(FWG_V_ELEVATOR + o.src));
+            else v = pre_action != nullptr ? pre_action[j]   // already summed while the integration ran (step kernel)
+                                           : action_obs(c, ring, o.src, o.window, E.steps, act_slot, T.get(FWG_V_ELEVATOR + o.src));
             if (o.norm) v = (v - o.mean) * o.inv_var;
             ob.put(j, v);
         }
@@ -762,17 +766,21 @@ __device__ __forceinline__ void stream_store4(float4* p, float4 v) {
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
     __builtin_nontemporal_store(x, reinterpret_cast<fwg_v4f*>(p));
 }
-template <class OB>
+// ROLE 0: the workgroup is one wave and uses the workgroup barrier; otherwise (k_step2) only THIS wave touches the staging area
+template <int ROLE> __device__ __forceinline__ void obs_sync() {
+    if (ROLE == 0) __syncthreads(); else FWG_WAVE_SYNC();
+}
+template <int ROLE, class OB>
 __device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ out, long env0, long N, const OB& ob,
                                           float* stage, int lane, unsigned long long lanes) {
     const int D = c.obs_dim;
-    __syncthreads();  // the staging area may still be read by a previous call
+    obs_sync<ROLE>();  // the staging area may still be read by a previous call
     if (obs_vec4(D)) {
         float4* mine = reinterpret_cast<float4*>(stage + lane * D);
 #pragma unroll
         for (int q = 0; q < (FWG_MAX_OBS * FWG_MAX_ROWS) / 4; ++q)
             if (q * 4 < D) mine[q] = make_float4(ob.get(4 * q), ob.get(4 * q + 1), ob.get(4 * q + 2), ob.get(4 * q + 3));
-        __syncthreads();
+        obs_sync<ROLE>();
         const float4* all = reinterpret_cast<const float4*>(stage);
         float4* o4 = reinterpret_cast<float4*>(out + env0 * D);
         const int total4 = FWG_WAVE * D / 4;
@@ -786,7 +794,7 @@ __device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ o
 #pragma unroll
         for (int k = 0; k < FWG_MAX_OBS * FWG_MAX_ROWS; ++k)
             if (k < D) stage[lane * Ds + k] = ob.get(k);
-        __syncthreads();
+        obs_sync<ROLE>();
         int l = lane / D, k = lane - l * D;
         const int l_inc = FWG_WAVE / D, k_inc = FWG_WAVE - l_inc * D;
 #pragma unroll 4

@@ -143,7 +143,7 @@ EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fw
            "fwg_capture_begin", "fwg_capture_end", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
            "fwg_actor_set_stats", "fwg_actor_get_stats", "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe",
            "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window", "fwg_reduce_success_device",
-           "fwg_obs_gather", "fwg_actor_set_obs_log"]
+           "fwg_obs_gather", "fwg_actor_set_obs_log", "fwg_selftest_philox"]
 _libs = {}
 
 
@@ -209,6 +209,8 @@ def load_library(path=None):
     lib.fwg_obs_log_floats.restype = i64
     lib.fwg_obs_window.argtypes = [vp, C.POINTER(i64)]
     lib.fwg_obs_window.restype = C.c_int
+    lib.fwg_selftest_philox.argtypes = [vp, vp, i64, vp]
+    lib.fwg_selftest_philox.restype = C.c_int
     lib.fwg_obs_gather.argtypes = [vp, vp, vp, vp]
     lib.fwg_obs_gather.restype = C.c_int
     lib.fwg_actor_set_obs_log.argtypes = [vp, vp]

@@ -276,6 +276,11 @@ int fwg_obs_window(const fwg_handle* h, int64_t* plane);
  * captured and replayed (a host-side view from fwg_obs_window is only valid for direct calls).  n_obs % 4 == 0. */
 int fwg_obs_gather(const fwg_handle* h, const float* obs_log, float* obs_out, void* stream);
 
+/* Known-answer hook: runs the device's Philox4x32-10 (the generator behind every sampled reset state, target, noise
+ * and turbulence sample) on n inputs {counter[4], key[2]} (uint32 [n][6], device) -> uint32 [n][4] (device), so that
+ * tests can check it against the published Random123 vectors.  Not used by the product path. */
+int fwg_selftest_philox(const uint32_t* ctr_key_dev, uint32_t* out_dev, int64_t n, void* stream);
+
 /* Debug-mode check for NaN actions (fixed_wing.py:347); synchronises the stream. */
 int fwg_check_actions(fwg_handle* h, const float* actions, void* stream);
 

@@ -59,24 +59,49 @@ static uint32_t emu_xchg[1024];
 alignas(16) float lds[160 * 1024 / 4];  // the block's dynamic LDS (`extern __shared__ float lds[]` in the kernels)
 static emu_idx emu_block_idx, emu_block_dim;
 
-static inline void __syncthreads() {
+// Barriers: a lane that arrives yields until everybody of its scope (its 64-lane wave, or the workgroup) has arrived
+// -- lanes that already returned from the kernel do not count.  Generation counters make the barriers reusable.
+static unsigned emu_nwaves = 1;
+static unsigned emu_wave_live[16], emu_wave_wait[16], emu_wave_gen[16];
+static unsigned emu_block_live, emu_block_wait, emu_block_gen;
+static inline void emu_yield() {
     emu_lanes[emu_cur].state = 1;
     swapcontext(&emu_lanes[emu_cur].ctx, &emu_sched_ctx);
 }
+static inline void emu_wave_sync() {
+    const unsigned w = emu_cur >> 6;
+    const unsigned my = emu_wave_gen[w];
+    if (++emu_wave_wait[w] >= emu_wave_live[w]) { emu_wave_wait[w] = 0; ++emu_wave_gen[w]; return; }
+    while (emu_wave_gen[w] == my) emu_yield();
+}
+static inline void __syncthreads() {
+    const unsigned my = emu_block_gen;
+    if (++emu_block_wait >= emu_block_live) { emu_block_wait = 0; ++emu_block_gen; return; }
+    while (emu_block_gen == my) emu_yield();
+}
+static inline void emu_lane_exit() {   // a finished lane releases barriers the others are already waiting at
+    const unsigned w = emu_cur >> 6;
+    --emu_wave_live[w];
+    --emu_block_live;
+    if (emu_wave_live[w] > 0 && emu_wave_wait[w] >= emu_wave_live[w]) { emu_wave_wait[w] = 0; ++emu_wave_gen[w]; }
+    if (emu_block_live > 0 && emu_block_wait >= emu_block_live) { emu_block_wait = 0; ++emu_block_gen; }
+}
+// wave-scope collectives (64 lanes): exchange through a per-lane slot, two wave barriers around the read
 static inline unsigned long long __ballot(int pred) {
     emu_xchg[threadIdx.x] = pred ? 1u : 0u;
-    __syncthreads();
+    emu_wave_sync();
+    const unsigned w0 = threadIdx.x & ~63u;
     unsigned long long m = 0;
-    for (unsigned i = 0; i < blockDim.x && i < 64; ++i) m |= (unsigned long long)emu_xchg[i] << i;
-    __syncthreads();
+    for (unsigned i = 0; i < 64 && w0 + i < blockDim.x; ++i) m |= (unsigned long long)emu_xchg[w0 + i] << i;
+    emu_wave_sync();
     return m;
 }
 static inline float __shfl_xor(float v, int mask, int) {
     memcpy(&emu_xchg[threadIdx.x], &v, 4);
-    __syncthreads();
+    emu_wave_sync();
     float r;
     memcpy(&r, &emu_xchg[threadIdx.x ^ (unsigned)mask], 4);
-    __syncthreads();
+    emu_wave_sync();
     return r;
 }
 static std::mutex emu_atomic_mutex;
@@ -113,7 +138,7 @@ static inline ACC emu_mfma_f32_32x32x16_bf16(const FRAG& a, const FRAG& b, ACC c
     const unsigned tid = threadIdx.x;
     memcpy(emu_mfma_a[tid], &a, 16);
     memcpy(emu_mfma_b[tid], &b, 16);
-    __syncthreads();
+    emu_wave_sync();
     const unsigned w0 = tid & ~63u, l = tid & 63u, j = l & 31u, half = l >> 5;
     for (unsigned r = 0; r < 16; ++r) {
         const unsigned i = (r & 3u) + 8u * (r >> 2) + 4u * half;
@@ -122,13 +147,14 @@ static inline ACC emu_mfma_f32_32x32x16_bf16(const FRAG& a, const FRAG& b, ACC c
             s += emu_bf16(emu_mfma_a[w0 + i + 32u * (k >> 3)][k & 7u]) * emu_bf16(emu_mfma_b[w0 + j + 32u * (k >> 3)][k & 7u]);
         c[r] += s;
     }
-    __syncthreads();
+    emu_wave_sync();
     return c;
 }
 
 static std::function<void()> emu_body;
 static void emu_trampoline() {
     emu_body();
+    emu_lane_exit();
     emu_lanes[emu_cur].state = 2;
     swapcontext(&emu_lanes[emu_cur].ctx, &emu_sched_ctx);
 }
@@ -147,6 +173,12 @@ static void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
             L.state = 0;
             makecontext(&L.ctx, emu_trampoline, 0);
         }
+        emu_nwaves = (block.x + 63) / 64;
+        for (unsigned w = 0; w < emu_nwaves; ++w) {
+            const unsigned first = w * 64, last = first + 64 < block.x ? first + 64 : block.x;
+            emu_wave_live[w] = last - first; emu_wave_wait[w] = 0;
+        }
+        emu_block_live = block.x; emu_block_wait = 0;
         for (;;) {
             unsigned alive = 0;
             for (unsigned t = 0; t < block.x; ++t) {

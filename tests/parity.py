@@ -80,6 +80,9 @@ def run_gym_parity(vec, oracles, n_steps, action_fn, rtol=2e-3, atol=2e-3, check
                 t, bad[:8], done[bad[:8]], w_done[bad[:8]], [w_info[b].get("termination") for b in bad[:8]]))
         worst["reward"] = max(worst["reward"], close(rew, np.array(w_rew, dtype=np.float64), rtol, atol, "step {} reward".format(t)))
         tgt = np.array([[infos[i]["target"][n] for n in names] for i in range(N)]) if N <= 512 else None
+        # info["target"] is the target at the END of the step (fixed_wing.py:435), i.e. for an env that ends its episode
+        # the target BEFORE the VecEnv's auto-reset samples a new one
+        w_tgt = np.array([[w_info[i]["target"][n] for n in names] for i in range(N)])
         for i in np.nonzero(done)[0]:
             info = infos[int(i)]
             episodes += 1
@@ -106,7 +109,6 @@ def run_gym_parity(vec, oracles, n_steps, action_fn, rtol=2e-3, atol=2e-3, check
             if vec.auto_reset:
                 w_obs[i] = oracles[i].reset()
         if tgt is not None:
-            w_tgt = np.array([[o.target[n] for n in names] for o in oracles])
             worst["target"] = max(worst["target"], close(tgt, w_tgt, rtol, atol, "step {} target".format(t)))
         worst["obs"] = max(worst["obs"], close(obs.reshape(N, -1), np.stack(w_obs).reshape(N, -1), rtol, atol, "step {} obs".format(t)))
         if log is not None and t % 20 == 0:

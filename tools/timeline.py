@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "fixed-wing-gym_amd")
 OUT = os.path.join(PKG, "gym_fixed_wing", "_abl")
 LIB = os.path.join(OUT, "libfwgym_timeline.so")
+# (table of phase names kept for reference; the run prints the stamps of each wave relative to the block's start)
 NAMES = ["entry->loads issued", "integration (incl. wait for state)", "store sim rows", "wait streamed windows (vmcnt0)",
          "gym logic", "store gym rows", "observation build", "episode-end branch", "outputs issued", "stores acknowledged"]
 
@@ -44,7 +45,7 @@ def run():
                               obs_log_rows=log_rows, _lib_path=LIB)
         assert vec.spec_index >= 0
         vec.reset()
-        trace = torch.zeros((n // 64, 16), dtype=torch.int64, device="cuda")
+        trace = torch.zeros((n // 64 * 2, 16), dtype=torch.int64, device="cuda")
         vec._lib.fwg_debug_set_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         vec._lib.fwg_debug_set_trace(vec._handle, ctypes.c_void_p(trace.data_ptr()))
         acts = [torch.rand((n, 3), device="cuda") * 2 - 1 for _ in range(16)]
@@ -53,30 +54,32 @@ def run():
         torch.cuda.synchronize()
         rows = []
         for rep in range(20):
+            trace.zero_()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
             vec.step_device(acts[rep % 16])
             e1.record()
             torch.cuda.synchronize()
-            t = trace.cpu().numpy().astype(np.float64)
+            t = trace.cpu().numpy().astype(np.float64).reshape(n // 64, 2, 16)
             rows.append((t, e0.elapsed_time(e1) * 1e3))
-        T = np.stack([r[0] for r in rows])                    # [rep][block][16]
-        span_ticks = (T[:, :, 10].max(axis=1) - T[:, :, 0].min(axis=1))
+        T = np.stack([r[0] for r in rows])                    # [rep][block][wave][16]
+        T = np.where(T == 0, np.nan, T)
+        t0 = np.nanmin(T[:, :, :, 0], axis=2, keepdims=True)[..., None]     # the block's first stamp
+        rel = T - t0                                          # ticks since the block started
         key = "{}{}".format(wl, "_log" if log_rows else "")
-        d = np.diff(T[:, :, :11], axis=2)                      # [rep][block][10]
-        # s_memtime ticks at a constant 100 MHz on this part: report ticks and the implied microseconds
-        med = np.median(d.reshape(-1, 10), axis=0)
-        p90 = np.percentile(d.reshape(-1, 10), 90, axis=0)
-        start_spread = np.median(T[:, :, 0].max(axis=1) - T[:, :, 0].min(axis=1))
-        wave_total = np.median((T[:, :, 10] - T[:, :, 0]).reshape(-1))
-        res[key] = {"phase_ticks_median": med.tolist(), "phase_ticks_p90": p90.tolist(), "first_to_last_wave_start_ticks": float(start_spread),
-                    "wave_lifetime_ticks_median": float(wave_total), "kernel_span_ticks_median": float(np.median(span_ticks)),
+        med = np.nanmedian(rel.reshape(-1, 2, 16), axis=0)    # [wave][stamp]
+        start_spread = float(np.nanmedian(np.nanmax(T[:, :, :, 0], axis=(1, 2)) - np.nanmin(T[:, :, :, 0], axis=(1, 2))))
+        life = np.nanmedian(np.nanmax(rel, axis=(2, 3)))
+        res[key] = {"stamp_ticks_median": [[None if np.isnan(x) else float(x) for x in w] for w in med],
+                    "first_to_last_wave_start_ticks": start_spread, "block_lifetime_ticks_median": float(life),
                     "event_us_median": float(np.median([r[1] for r in rows]))}
-        print("== {} ({}): event {:.2f} us; ticks: kernel span {:.0f}, wave lifetime {:.0f}, start spread {:.0f}".format(
-            key, desc, res[key]["event_us_median"], np.median(span_ticks), wave_total, start_spread))
-        for i, nm in enumerate(NAMES):
-            print("   {:38s} median {:8.1f}  p90 {:8.1f} ticks".format(nm, med[i], p90[i]))
+        print("== {} ({}): event {:.2f} us; ticks: block lifetime {:.0f}, start spread {:.0f}".format(
+            key, desc, res[key]["event_us_median"], life, start_spread))
+        for w in range(2):
+            if np.all(np.isnan(med[w])):
+                continue
+            print("   wave {}: ".format(w) + "  ".join("{}:{:.0f}".format(i, med[w][i]) for i in range(11) if not np.isnan(med[w][i])))
         vec.close()
     print(json.dumps(res))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
