@@ -147,10 +147,11 @@ def main():
                     help="c5 only: 'fused' (default for c5) = env step + HIP rollout head (VecNormalize + MlpPolicy + "
                          "sampling); 'none' = env step on stored actions")
     ap.add_argument("--eager", action="store_true", help="launch every step from the host instead of replaying hipGraphs")
-    ap.add_argument("--stagger", type=int, default=0,
-                    help="S > 0: before the warm-up, reset 1/S of the envs every steps_max/S steps, so that episode ends (metrics, "
-                         "success reduction, in-kernel auto-reset) are spread evenly over the timed steps instead of all envs "
-                         "hitting steps_max at the same step")
+    ap.add_argument("--stagger", type=int, default=32,
+                    help="S > 0 (default 32): before the warm-up, reset 1/S of the envs every steps_max/S steps, so that episode "
+                         "ends (metrics, success reduction, in-kernel auto-reset) are spread evenly over the timed steps -- the "
+                         "steady state of a long run -- instead of all envs hitting steps_max at the same step; 0 = all envs "
+                         "start together (no episode ends inside a short timed region)")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: host-emulation build of the kernels + gloo, tiny batch (exercises the launcher, the "
                          "sharding and the collective on a machine without GPUs; the numbers are not measurements)")

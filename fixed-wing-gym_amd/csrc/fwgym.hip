@@ -214,6 +214,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     float fval_action[FWG_MAX_FACTORS];   // values of the reward factors of class "action" (fixed_wing.py:686-700)
     float obs_action[FWG_MAX_OBS];        // "action" entries of the newest observation row (fixed_wing.py:813-828)
     float tgt_next[3] = {0.f, 0.f, 0.f};  // targets propagated by one step, valid unless the target is resampled
+    // episodes that end at steps_max are known before the integration: their reset draw (the Philox-heavy half of reset)
+    // and the sum of the previous end-error records are prepared here too, off the step's critical path
+    bool pre_reset = false;
+    ResetDraw RD;
+    float end_prev[3] = {0.f, 0.f, 0.f};
     auto gym_prework = [&]() {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {   // the own action enters the LDS copy of the windows
@@ -286,6 +291,28 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             next_targets(c, E);
 #pragma unroll
             for (int k = 0; k < 3; ++k) { tgt_next[k] = E.tgt[k]; E.tgt[k] = keep[k]; }
+        }
+        if (c.auto_reset && c.steps_max > 0) {
+            const bool will_end = valid && done;   // E.steps reached steps_max
+            if (__ballot(will_end) != 0ull) {
+                if (will_end) {
+                    reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);
+                    pre_reset = true;
+                    // row log: the lagged rows of the terminal observation are records of earlier steps -- fetched now
+                    if (c.obs_log > 0) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
+                    if (c.metrics) {   // records 1 .. cnt - 1 steps back (the current one is added when it exists)
+                        const int cnt = (int)min(E.steps + 1u, (unsigned)FWG_END_WINDOW);
+#pragma unroll
+                        for (int q = 1; q < FWG_END_WINDOW; ++q) {
+                            if (q < cnt) {
+                                int slot = A.slot_end - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
+                                const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                                end_prev[0] += r.x; end_prev[1] += r.y; end_prev[2] += r.z;
+                            }
+                        }
+                    }
+                }
+            }
         }
     };
     if (SPLIT && GYM) {
@@ -468,8 +495,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     const bool early = c.obs_length > 1 && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
     const unsigned log_pad_t = E.steps;   // rows with lag >= this are padding (valid for lanes that do not finish)
     const long long log_win = A.log_win;   // wave-uniform
-    if (c.obs_log > 0 && __ballot((done || !ok) && valid) != 0ull) {
-        if ((done || !ok) && valid) log_load_rows(c, A.obs, A.N, e, log_win, ob);
+    if (c.obs_log > 0 && __ballot((done || !ok) && valid && !pre_reset) != 0ull) {
+        if ((done || !ok) && valid && !pre_reset) log_load_rows(c, A.obs, A.N, e, log_win, ob);
     }
     if (c.obs_length > 1 && (!ok || early)) fix_lagged_rows(c, A, e, E, T, ob, ok);
     if (c.obs_noise) add_obs_noise(c, A, e, E, ob);
@@ -491,6 +518,28 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #pragma unroll
             for (int i = 0; i < FWG_N_METRICS; ++i) mt[i] = NAN;
             if (c.metrics) {
+                // end_error: |mean of the last <= 50 errors|.  Foreseen ends: the older records were summed before the
+                // barrier; otherwise the whole ring is requested at once (one 16-byte record per slot, 49 independent
+                // loads) -- the newest record is this step's error, still in registers
+                const int end_cnt = (int)min(n_rec, (unsigned)FWG_END_WINDOW);
+                float end_sum[3] = {0.f, 0.f, 0.f};
+                if (pre_reset && ok) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) end_sum[k] = end_prev[k] + err[k];
+                } else {
+                    const int first = ok ? 1 : 0;   // ok: ages 1.. + the register copy; failed step: nothing was stored for it
+                    int p = ok ? A.slot_end : A.slot_end - 1;
+                    p += (p < 0) ? FWG_END_WINDOW : 0;
+                    if (ok) { end_sum[0] = err[0]; end_sum[1] = err[1]; end_sum[2] = err[2]; }
+#pragma unroll
+                    for (int q = 0; q < FWG_END_WINDOW; ++q) {
+                        if (q >= first && q < end_cnt) {
+                            int slot = p - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
+                            const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                            end_sum[0] += r.x; end_sum[1] += r.y; end_sum[2] += r.z;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
                     if (k >= c.n_targets) continue;
@@ -500,16 +549,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                     mt[FWG_M_OVERSHOOT + k] = (fsignf(ext) == fsignf(E.e0[k])) ? NAN : fabsf(ext / E.e0[k]);
                     mt[FWG_M_TOTAL_ERROR + k] = E.eabs[k];
                     mt[FWG_M_AVG_ERROR + k] = fabsf(E.e0[k]) >= 0.01f ? fabsf((E.esum[k] / (float)n_rec) / E.e0[k]) : NAN;
-                    // end_error: |mean of the last <=50 errors| from the ring
-                    const int cnt = (int)min(n_rec, (unsigned)FWG_END_WINDOW);
-                    int p = ok ? A.slot_end : A.slot_end - 1;
-                    p += (p < 0) ? FWG_END_WINDOW : 0;
-                    float s = 0.f;
-                    for (int q = 0; q < cnt; ++q) {
-                        int slot = p - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
-                        s += A.S[(((unsigned)(L.end_ring >> 2) + (unsigned)slot) * (unsigned)A.N + (unsigned)e) * 4u + (unsigned)k];
-                    }
-                    mt[FWG_M_END_ERROR + k] = fabsf(s / (float)cnt);
+                    mt[FWG_M_END_ERROR + k] = fabsf(end_sum[k] / (float)end_cnt);
                 }
                 mt[FWG_M_CONTROL_VARIATION] = E.sdcmd / (3.f * c.dt * (float)(E.steps - 1u));
                 if (c.goal_enabled) {
@@ -547,13 +587,16 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (A.term_obs != nullptr) write_obs<ROLE>(c, A.term_obs, env0, A.N, ob, lds + M.stage, lane, done_mask);
         // per-wave reduction by shuffles, one atomic per value per wave (the per-GPU part of the success reduction of
         // examples/train_rl_controller.py:51-66,80-85)
+        {
+            float v32[32];
 #pragma unroll
-        for (int i = 0; i < FWG_N_REDUCE; ++i) {
-            const float s = wave_sum(red[i]);
-            if (lane == 0 && s != 0.f) atomicAdd(A.reduce + i, s);
+            for (int i = 0; i < 32; ++i) v32[i] = i < FWG_N_REDUCE ? red[i] : 0.f;
+            const float tot = wave_totals32(v32, lane);   // lane l holds the total of value l & 31
+            if (lane < FWG_N_REDUCE && tot != 0.f) atomicAdd(A.reduce + lane, tot);
         }
         if (c.auto_reset && done && valid) {
-            reset_env<TURB>(c, dc, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal);
+            if (!pre_reset) reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);   // not foreseen (failure, success): drawn now
+            reset_finish<TURB>(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal, RD);
             store_sim<TURB>(c, A.S, A.N, e, E);
             store_gym(c, A.S, A.N, e, E, A.bit_goal, true, true);
         }

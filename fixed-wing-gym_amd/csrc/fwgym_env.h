@@ -806,20 +806,35 @@ __device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ o
     }
 }
 
-// FixedWingAircraft.reset (fixed_wing.py:287-336) for one lane; `g_*` are the ring positions of the LAST completed
-// global step.  Fills E, the observation record ob (all rows) and the ring slots that hold initial records.
-template <bool TURB, class TAB, class OB>
-__device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, Env& E, TAB& T, OB& ob,
-                                          const float* ring, int g_end, int g_lag, int g_bit) {
+// FixedWingAircraft.reset (fixed_wing.py:287-336) for one lane, in two parts:
+//   reset_sample : everything that depends only on (env id, episode index, seed) and the optional given values -- the
+//                  sampled initial state and targets, the derived angles, the per-row initial noise.  Pure (no memory
+//                  writes), Philox-heavy.  The step kernel runs it for lanes that reach steps_max WHILE the physics wave
+//                  still integrates (the draw does not depend on how the episode ends).
+//   reset_finish : installs the draw in E, initialises the bookkeeping, writes the ring slots that hold initial records
+//                  and builds the observation record ob (all rows).  `g_*` = ring positions of the LAST completed step.
+// reset_env = both back to back (reset kernel; episode ends that were not foreseen).
+struct ResetDraw {
+    float y[NY], wind[3];
+    Derived d;
+    float tgt[FWG_MAX_TARGETS], tprop[FWG_MAX_TARGETS][4];
+    unsigned flags, episode;
+    float row_noise[FWG_MAX_ROWS];
+};
+
+template <class TAB>
+__device__ __forceinline__ void reset_sample(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_old,
+                                             unsigned flags_old, TAB& T, ResetDraw& D) {
     const unsigned env_id = (unsigned)(A.env_base + e);
-    E.episode += 1u;
-    E.steps = 0u;
-    E.flags &= FWG_FLAG_GOAL_ACHIEVED;  // prev_shaping := None, resample counter := 0; goal_achieved is sticky
+    Env R;   // scratch: only the fields sample_targets / fill_vars touch
+    R.episode = episode_old + 1u;
+    R.steps = 0u;
+    R.flags = flags_old & FWG_FLAG_GOAL_ACHIEVED;  // prev_shaping := None, resample counter := 0; goal_achieved is sticky
     // ---- initial simulator state: given values or U(init_min, init_max)
     float v0[FWG_N_RESET_VARS];
 #pragma unroll
     for (int blk = 0; blk < 6; ++blk) {
-        const u4 b = philox4x32(env_id, E.episode, (unsigned)blk, FWG_STREAM_RESET_STATE, A.seed_lo, A.seed_hi);
+        const u4 b = philox4x32(env_id, R.episode, (unsigned)blk, FWG_STREAM_RESET_STATE, A.seed_lo, A.seed_hi);
         const unsigned bits[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -839,27 +854,70 @@ __device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, con
         sincosf(0.5f * v0[FWG_V_ROLL], &sr, &cr);
         sincosf(0.5f * v0[FWG_V_PITCH], &sp, &cp);
         sincosf(0.5f * v0[FWG_V_YAW], &sy, &cy);
-        E.y[0] = cy * cp * cr + sy * sp * sr; E.y[1] = cy * cp * sr - sy * sp * cr;
-        E.y[2] = cy * sp * cr + sy * cp * sr; E.y[3] = sy * cp * cr - cy * sp * sr;
+        R.y[0] = cy * cp * cr + sy * sp * sr; R.y[1] = cy * cp * sr - sy * sp * cr;
+        R.y[2] = cy * sp * cr + sy * cp * sr; R.y[3] = sy * cp * cr - cy * sp * sr;
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) E.y[4 + i] = v0[FWG_V_OMEGA_P + i];
+    for (int i = 0; i < 9; ++i) R.y[4 + i] = v0[FWG_V_OMEGA_P + i];
     {
         const float el = fclampf(v0[FWG_V_ELEVATOR], c.val_min[FWG_V_ELEVATOR], c.val_max[FWG_V_ELEVATOR]);
         const float ai = fclampf(v0[FWG_V_AILERON], c.val_min[FWG_V_AILERON], c.val_max[FWG_V_AILERON]);
-        E.y[13] = el - ai; E.y[14] = el + ai;
-        E.y[15] = fclampf(v0[FWG_V_THROTTLE], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
-        E.y[16] = 0.f; E.y[17] = 0.f;
+        R.y[13] = el - ai; R.y[14] = el + ai;
+        R.y[15] = fclampf(v0[FWG_V_THROTTLE], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
+        R.y[16] = 0.f; R.y[17] = 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) E.wind[i] = v0[FWG_V_WIND_N + i];
+    for (int i = 0; i < 3; ++i) R.wind[i] = v0[FWG_V_WIND_N + i];
+    const float gust0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    R.d = derive<false>(R.y, R.wind, gust0);
+    fill_vars(R, T);
+    // ---- targets
+    sample_targets(c, dc, A, e, R, T, A.init_target);
+#pragma unroll
+    for (int i = 0; i < NY; ++i) D.y[i] = R.y[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) D.wind[i] = R.wind[i];
+    D.d = R.d;
+#pragma unroll
+    for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+        D.tgt[k] = R.tgt[k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) D.tprop[k][i] = c.any_dynamic_target ? R.tprop[k][i] : 0.f;
+    }
+    D.flags = R.flags; D.episode = R.episode;
+    // per-row initial noise of the lagged rows (fixed_wing.py:792-795,831-832)
+#pragma unroll
+    for (int r = 0; r < FWG_MAX_ROWS; ++r) {
+        D.row_noise[r] = 0.f;
+        if (c.obs_length > 1 && r < c.obs_length) {
+            const u4 b = philox4x32(env_id, 0u, R.episode, FWG_STREAM_INIT_NOISE + 256u * (r >> 2), A.seed_lo, A.seed_hi);
+            const unsigned bits = (r & 3) == 0 ? b.x : ((r & 3) == 1 ? b.y : ((r & 3) == 2 ? b.z : b.w));
+            D.row_noise[r] = (2.f * u01(bits) - 1.f) * c.dt;
+        }
+    }
+}
+
+template <bool TURB, class TAB, class OB>
+__device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, long e, Env& E, TAB& T, OB& ob, const float* ring,
+                                             int g_end, int g_lag, int g_bit, const ResetDraw& D) {
+    E.episode = D.episode;
+    E.steps = 0u;
+    E.sft = 0u;
+    E.flags = (E.flags & FWG_FLAG_GOAL_ACHIEVED) | (D.flags & ~FWG_FLAG_GOAL_ACHIEVED);   // the sticky bit may date from this very step
+#pragma unroll
+    for (int i = 0; i < NY; ++i) E.y[i] = D.y[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) E.wind[i] = D.wind[i];
 #pragma unroll
     for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = 0.f;
-    const float gust0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    E.d = derive<false>(E.y, E.wind, gust0);
+    E.d = D.d;
+#pragma unroll
+    for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+        E.tgt[k] = D.tgt[k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) E.tprop[k][i] = D.tprop[k][i];
+    }
     fill_vars(E, T);
-    // ---- targets
-    sample_targets(c, dc, A, e, E, T, A.init_target);
     float err[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
@@ -893,13 +951,19 @@ __device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, con
 #pragma unroll
         for (int r = FWG_MAX_ROWS - 1; r >= 0; --r) {
             if (r >= c.obs_length) continue;
-            const u4 b = philox4x32(env_id, 0u, E.episode, FWG_STREAM_INIT_NOISE + 256u * (r >> 2), A.seed_lo, A.seed_hi);
-            const unsigned bits = (r & 3) == 0 ? b.x : ((r & 3) == 1 ? b.y : ((r & 3) == 2 ? b.z : b.w));
-            const float noise = (2.f * u01(bits) - 1.f) * c.dt;
+            const float noise = D.row_noise[r];
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j)
                 if (j < c.n_obs) ob.put(r * c.n_obs + j, ob.get(j) + noise * (c.obs[j].norm ? c.obs[j].inv_var : 1.f));
         }
     }
     if (c.obs_noise) add_obs_noise(c, A, e, E, ob);
+}
+
+template <bool TURB, class TAB, class OB>
+__device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, Env& E, TAB& T, OB& ob,
+                                          const float* ring, int g_end, int g_lag, int g_bit) {
+    ResetDraw D;
+    reset_sample(c, dc, A, e, E.episode, E.flags, T, D);
+    reset_finish<TURB>(c, A, e, E, T, ob, ring, g_end, g_lag, g_bit, D);
 }

@@ -19,10 +19,24 @@ def shard(total_envs, rank, world_size):
     return first, n
 
 
+def local_device(rank=0):
+    """GPU of this process: LOCAL_RANK when a launcher set it (multi-node: the global rank exceeds the GPUs of a node),
+    otherwise rank modulo the GPUs visible."""
+    import os
+    if "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"])
+    try:
+        import torch
+        n = torch.cuda.device_count()
+    except Exception:
+        n = 0
+    return rank % n if n > 0 else rank
+
+
 def make_sharded_env(config_path=None, total_envs=65536, rank=0, world_size=1, device=None, **kw):
     from .vec_env import FixedWingVecEnv
     first, n = shard(total_envs, rank, world_size)
-    return FixedWingVecEnv(config_path, num_envs=n, device=rank if device is None else device, env_id_base=first, **kw)
+    return FixedWingVecEnv(config_path, num_envs=n, device=local_device(rank) if device is None else device, env_id_base=first, **kw)
 
 
 def gather_success(vec, group=None):

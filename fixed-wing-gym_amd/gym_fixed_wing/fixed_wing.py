@@ -59,6 +59,34 @@ class _SimulatorView(object):
                 if record:
                     st.history.append(self._values[n])
 
+    def constrained_command(self, action):
+        """What PyFly stores in simulator.state[actuator].history["command"] (read by the reference at
+        fixed_wing.py:828 and :1110): the inputs after action scaling (fixed_wing.py:349-354,439-459), the value limits of
+        elevator / aileron / throttle and of the two elevons, mapped back to elevator / aileron -- the same arithmetic the
+        step kernel applies (csrc/fwgym_physics.h constrain_commands)."""
+        ec = self._env._vec.env_config
+        a = np.asarray(action, dtype=np.float64).reshape(3)
+        if self._env.cfg["action"].get("scale_space", False):
+            lo, hi = self._env.cfg["action"].get("scale_low", -1), self._env.cfg["action"].get("scale_high", 1)
+            to_lo, to_hi = ec.action_scale_to_low, ec.action_scale_to_high
+            a = (to_hi - to_lo) * (np.clip(a, lo, hi) - lo) / (hi - lo) + to_lo
+
+        def lim(x, name):
+            v = ec.state[name]
+            if getattr(v, "value_min", None) is not None:
+                x = max(x, v.value_min)
+            if getattr(v, "value_max", None) is not None:
+                x = min(x, v.value_max)
+            return x
+        e, al, t = lim(a[0], "elevator"), lim(a[1], "aileron"), lim(a[2], "throttle")
+        er, el = lim(e - al, "elevon_right"), lim(e + al, "elevon_left")
+        return {"elevator": 0.5 * (er + el), "aileron": 0.5 * (el - er), "throttle": t}
+
+    def record_command(self, action):
+        cmd = self.constrained_command(action)
+        for n, v in cmd.items():
+            self.state[n].history["command"].append(float(v))
+
     def get_states_vector(self, states, attribute="value"):
         return np.array([getattr(self.state[s], attribute) for s in states])
 
@@ -152,6 +180,7 @@ class FixedWingAircraft(Env):
         assert not np.any(np.isnan(action))
         self.history["action"].append(action)
         prev_target = dict(self.target)
+        self.simulator.record_command(action)   # PyFly appends the constrained command before it integrates
         obs, rew, done, infos = self._vec.step(action.reshape(1, 3).astype(np.float32))
         self.steps_count += 1
         info = dict(infos[0])

@@ -1,5 +1,5 @@
 """The reference-compatible single-env class (gym_fixed_wing.fixed_wing.FixedWingAircraft) and the VecEnv surface used
-by the reference's example scripts, exercised on the host-emulation build."""
+by the reference's example scripts, exercised on the host-emulation build and (-m gpu) on the MI355X."""
 import os
 
 import numpy as np
@@ -17,15 +17,21 @@ STATE = {"roll": 0.3, "pitch": -0.1, "yaw": 0.5, "omega_p": 0.0, "omega_q": 0.0,
 TARGET = {"roll": 0.0, "pitch": 0.05, "Va": 21.0}
 
 
-@pytest.fixture(scope="module")
-def emu_lib():
-    return build_emu()
+BACKENDS = [pytest.param("emu"), pytest.param("gpu", marks=pytest.mark.gpu)]
 
 
-def test_single_env_api_matches_oracle(emu_lib, tmp_path):
+def _kw(backend):
+    """Constructor keywords selecting where the kernels run: host emulation (CPU suite) or the real device."""
+    if backend == "emu":
+        return {"_backend": HostBackend(), "_lib_path": build_emu()}
+    return {"device": 0}
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_single_env_api_matches_oracle(backend, tmp_path):
     cfg = configs.default()
     ckw = {"steps_max": 40}
-    env = FixedWingAircraft(cfg, config_kw=ckw, _backend=HostBackend(), _lib_path=emu_lib)
+    env = FixedWingAircraft(cfg, config_kw=ckw, **_kw(backend))
     orc = parity.make_oracles(cfg, 1, 0, config_kw=ckw)[0]
     assert env.observation_space.shape == (14,) and env.action_space.shape == (3,)
     assert env.seed(0) == [0]
@@ -52,6 +58,14 @@ def test_single_env_api_matches_oracle(emu_lib, tmp_path):
     assert env.get_metric("total_error")["Va"] == pytest.approx(i2["total_error"]["Va"], rel=1e-2)
     assert len(env.history["action"]) == 40 and len(env.history["target"]["Va"]) == 41
     assert len(env.simulator.state["roll"].history) == 41
+    # PyFly's actuator histories: "value" one entry per record, "command" one constrained command per step
+    # (read by the reference at fixed_wing.py:828 and :1110)
+    for n, k in (("elevator", 0), ("aileron", 1), ("throttle", 2)):
+        h = env.simulator.state[n].history
+        assert len(h["value"]) == 41 and len(h["command"]) == 40
+        np.testing.assert_allclose(h["command"], orc.simulator.state[n].history["command"], atol=1e-6)
+    cv = np.sum(np.abs(np.diff([env.simulator.state[n].history["command"] for n in ("elevator", "aileron", "throttle")], axis=1)))
+    assert cv / (3 * env.simulator.dt * 39) == pytest.approx(env.get_metric("control_variation")["all"], rel=2e-3)
     with pytest.raises(AssertionError):
         env.step(np.array([np.nan, 0, 0]))
     png = str(tmp_path / "render" / "ep.png")
@@ -71,9 +85,10 @@ def test_single_env_api_matches_oracle(emu_lib, tmp_path):
     env.close()
 
 
-def test_vecenv_contract(emu_lib):
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_vecenv_contract(backend):
     cfg = configs.default()
-    vec = FixedWingVecEnv(cfg, num_envs=4, config_kw={"steps_max": 6}, as_numpy=True, _backend=HostBackend(), _lib_path=emu_lib)
+    vec = FixedWingVecEnv(cfg, num_envs=4, config_kw={"steps_max": 6}, as_numpy=True, **_kw(backend))
     assert vec.num_envs == 4 and vec.observation_space.shape == (14,)
     obs = vec.reset()
     assert obs.shape == (4, 14) and obs.dtype == np.float32

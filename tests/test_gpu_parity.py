@@ -198,3 +198,110 @@ def test_runtime_specialisation_matches_generic_kernel():
         np.testing.assert_allclose(r1, r2, rtol=2e-4, atol=2e-4)
         assert np.array_equal(d1, d2)
     print("generic {:.1f} us/step, run-time specialised {:.1f} us/step at {} envs".format(rates[0], rates[1], n))
+
+
+def _one_step_errors(vec, spec, raw, turb):
+    """One env step on the device vs the oracle from the identical (device) state.  Returns (scaled error [N,18], pure
+    relative error [N,18] where |want| > 1e-3 else nan, oracle ok mask, failure codes, device done flags)."""
+    n = vec.num_envs
+    y0, wind, dry = parity.physics_state(vec)
+    gust = ph.dryden_output(spec, dry) if turb else np.zeros((n, 6))
+    cmd = parity.scaled_actions(vec, raw)
+    want, ok, fail, _, _ = ph.sim_step(spec, y0, cmd, wind, gust)
+    _, _, done, infos = vec.step(raw)
+    y1, _, _ = parity.physics_state(vec)
+    err = np.abs(y1 - want) / np.maximum(np.abs(want), parity.STATE_SCALE)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rel = np.where(np.abs(want) > 1e-3, np.abs(y1 - want) / np.abs(want), np.nan)
+    return err, rel, ok, fail, np.asarray(done).astype(bool), infos, y0
+
+
+G5_N = 4096
+
+
+def _g5_states(rng, n):
+    """states outside the reset distribution -- stall blend (|alpha| in [0.2, 0.5]), airspeed near zero
+    and near the Va constraint, large sideslip, fast body rates close to the constraints, actuators at their limits."""
+    st = {"roll": rng.uniform(-2.8, 2.8, n), "pitch": rng.uniform(-1.3, 1.3, n), "yaw": rng.uniform(-3.1, 3.1, n),
+          "omega_p": rng.uniform(-3, 3, n), "omega_q": rng.uniform(-3, 3, n), "omega_r": rng.uniform(-2, 2, n),
+          "position_n": rng.uniform(-500, 500, n), "position_e": rng.uniform(-500, 500, n), "position_d": rng.uniform(-300, -50, n),
+          "velocity_u": rng.uniform(12, 30, n), "velocity_v": rng.uniform(-3, 3, n), "velocity_w": rng.uniform(-2, 2, n),
+          "elevator": rng.uniform(-0.5, 0.5, n), "aileron": rng.uniform(-0.5, 0.5, n), "throttle": rng.uniform(0, 1, n),
+          "wind_n": rng.uniform(-6, 6, n), "wind_e": rng.uniform(-6, 6, n), "wind_d": rng.uniform(-2, 2, n)}
+    q = n // 8
+    alpha = rng.uniform(0.2, 0.5, q) * rng.choice([-1.0, 1.0], q)               # stall blend region
+    st["velocity_w"][:q] = st["velocity_u"][:q] * np.tan(alpha)
+    st["wind_n"][:q] = st["wind_e"][:q] = st["wind_d"][:q] = 0.0
+    st["velocity_u"][q:2 * q] = rng.uniform(0.3, 2.0, q)                          # airspeed near zero
+    st["velocity_u"][2 * q:3 * q] = rng.uniform(60.0, 69.0, q)                    # close to the Va <= 70 constraint
+    st["velocity_v"][3 * q:4 * q] = rng.uniform(8, 15, q) * rng.choice([-1.0, 1.0], q)   # large sideslip
+    st["omega_p"][4 * q:5 * q] = rng.uniform(11.5, 12.5, q) * rng.choice([-1.0, 1.0], q)  # +-720 deg/s = 12.57 rad/s
+    st["omega_q"][5 * q:6 * q] = rng.uniform(11.5, 12.5, q) * rng.choice([-1.0, 1.0], q)
+    st["elevator"][6 * q:7 * q] = rng.choice([-0.5236, 0.5236], q)                 # at the value limits
+    st["aileron"][6 * q:7 * q] = rng.choice([-0.5236, 0.5236], q)
+    st["pitch"][7 * q:] = rng.choice([-1.0, 1.0], n - 7 * q) * rng.uniform(1.45, 1.56, n - 7 * q)   # near +-90 deg
+    return {k: v.astype(np.float32) for k, v in st.items()}
+
+
+@pytest.mark.parametrize("substeps", [1, 2, 4])
+@pytest.mark.parametrize("turb", [False, True], ids=["calm", "dryden"])
+def test_single_step_parity_on_g5_states(turb, substeps):
+    """The 1e-5 bar on targeted states (stall, near-zero / near-limit airspeed, constraint trips, saturated and
+    rate-limited actuators, pitch near +-90 deg), 30 consecutive steps each so that the elevons run into their rate limit
+    (commands jump by up to the full travel every step), for RK4 sub-step counts 1, 2 and 4."""
+    cfg = configs.reference_like("cnn")
+    skw = {"integrator": {"method": "rk4", "substeps": substeps, "actuator_microsteps": 16}}
+    if turb:
+        skw.update({"turbulence": True, "turbulence_intensity": "severe"})
+    n = G5_N
+    vec = _vec(cfg, n, sim_config_kw=skw, seed=5, as_numpy=True, auto_reset=False, config_kw={"steps_max": 1000})
+    spec = parity.oracle_spec_from_env_config(vec.env_config)
+    assert spec.nsub == substeps
+    rng = np.random.default_rng(100 + substeps)
+    vec.reset(states=_g5_states(rng, n))
+    alive = np.ones(n, dtype=bool)
+    worst, worst_rel, trips, rate_limited, stalled = 0.0, 0.0, {}, 0, 0
+    for t in range(30):
+        raw = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
+        err, rel, ok, fail, done, infos, y0 = _one_step_errors(vec, spec, raw, turb)
+        a = alive
+        assert np.array_equal(done[a], ~ok[a]), "constraint trips differ at step {}".format(t)
+        for i in np.nonzero(a & ~ok)[0][:64]:
+            name = ph.VARS[int(fail[i])] if fail[i] < ph.N_VARS else "nan"
+            assert infos[int(i)]["termination"] == name, (t, i, infos[int(i)]["termination"], name)
+            trips[name] = trips.get(name, 0) + 1
+        live = a & ok
+        worst = max(worst, float(err[live].max()))
+        worst_rel = max(worst_rel, float(np.nanmax(rel[live])))
+        assert err[live].max() <= 1e-5, (t, np.unravel_index(np.argmax(np.where(live[:, None], err, 0)), err.shape), err[live].max())
+        rate_limited += int((np.abs(np.abs(y0[live][:, 16:18]) - spec.act["elevon_right"]["dot_max"]) < 1e-6).sum())
+        ua, wa = y0[live][:, 10], y0[live][:, 12]
+        stalled += int((np.abs(np.arctan2(wa, ua)) > 0.2).sum())
+        alive = alive & ok          # auto_reset is off: finished envs are outside the contract
+    print("substeps={} turb={}: worst scaled {:.2e}, worst pure-relative (|x| > 1e-3) {:.2e}; constraint trips {}; "
+          "rate-limited elevon samples {}, stalled samples {}".format(substeps, turb, worst, worst_rel, trips, rate_limited, stalled))
+    assert len(trips) >= 2 and rate_limited > 1000 and stalled > 1000
+    vec.close()
+
+
+def test_hundred_step_rollout_state_parity():
+    """100 consecutive steps, each compared from the device state (so the errors do not accumulate into the comparison but
+    the states visited are those of a long free flight with jumping commands), default config, 4 096 envs."""
+    cfg = configs.reference_like("default")
+    n = 4096
+    vec = _vec(cfg, n, seed=8, as_numpy=True, auto_reset=False)
+    spec = parity.oracle_spec_from_env_config(vec.env_config)
+    vec.reset()
+    acts = _actions(21, 100, n, scale=1.5)
+    alive = np.ones(n, dtype=bool)
+    worst = worst_rel = 0.0
+    for t in range(100):
+        err, rel, ok, fail, done, infos, _ = _one_step_errors(vec, spec, acts[t], False)
+        assert np.array_equal(done[alive], ~ok[alive])
+        live = alive & ok
+        worst, worst_rel = max(worst, float(err[live].max())), max(worst_rel, float(np.nanmax(rel[live])))
+        assert err[live].max() <= 1e-5, (t, err[live].max())
+        alive = live
+    print("100-step rollout: worst scaled error {:.2e}, worst pure-relative {:.2e}, {} of {} envs alive".format(worst, worst_rel, int(alive.sum()), n))
+    assert alive.sum() > n // 2
+    vec.close()

@@ -70,3 +70,19 @@ def test_pid_traces_of_the_reference_within_bands():
     assert report["p90_abs_dreward"] < 0.032             # round 1: 0.10
     assert report["len_err_mean"] < 0.14                 # round 1: 0.17
     assert report["len_err_p90"] < 0.30                  # round 1: 0.46
+
+
+def test_integration_scheme_convergence_claim():
+    """with the actuators advanced exactly in 16 micro-steps, ONE classical RK4 step per env step is as
+    accurate as four (the error is set by the actuator micro-stepping, i.e. by where the rate limit switches), and both
+    are at the level of the reference's own adaptive RK45 at rtol 1e-3 -- reproduced by tools/convergence.py
+    (profiles/r02_convergence.json holds the 2 000-env table)."""
+    import convergence as cv
+    res = cv.run(n=300, rk45_subset=12)
+    one, four = res["rk4x1_micro16"], res["rk4x4_micro16"]
+    assert one["after_100"] < 1.3 * four["after_100"]
+    assert one["after_100"] < 8e-3 and one["after_1"] < 4e-3
+    assert res["rk4x1_micro4"]["after_100"] > 3 * one["after_100"]          # too few micro-steps does show
+    assert res["rk4x4_micro64"]["after_100"] < 0.3 * one["after_100"]        # and the scheme converges when both are refined
+    rk45 = [v for k, v in res.items() if k.startswith("scipy_rk45")][0]
+    assert one["after_100"] < 3 * max(rk45["after_100"], 1e-3)
