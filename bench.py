@@ -147,6 +147,7 @@ def main():
                     help="c5 only: 'fused' (default for c5) = env step + HIP rollout head (VecNormalize + MlpPolicy + "
                          "sampling); 'none' = env step on stored actions")
     ap.add_argument("--eager", action="store_true", help="launch every step from the host instead of replaying hipGraphs")
+    ap.add_argument("--lib", default=None, help="measurement builds (tools/ablate.py): path of an alternative libfwgym.so")
     ap.add_argument("--stagger", type=int, default=32,
                     help="S > 0 (default 32): before the warm-up, reset 1/S of the envs every steps_max/S steps, so that episode "
                          "ends (metrics, success reduction, in-kernel auto-reset) are spread evenly over the timed steps -- the "
@@ -208,6 +209,8 @@ def main():
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         kw = {"device": local}
+        if args.lib:
+            kw["_lib_path"] = args.lib
     # derived_views=False: the rollout loop never reads roll/pitch/... back from the arena (they are in the
     # observations), so the kernel does not write those host-view rows
     vec = FixedWingVecEnv(cfg, num_envs=n_envs, config_kw=ckw, sim_config_kw=skw, seed=0, env_id_base=first,

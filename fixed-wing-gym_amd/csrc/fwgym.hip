@@ -112,7 +112,17 @@ __device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, co
 //                       / metrics / auto-reset on the state it receives.
 // Workgroup barriers: A = state and noise handed over; B = the physics wave's simulator rows are written (the gym wave's
 // auto-reset then overwrites them for lanes that end an episode).
-#define FWG_HAND_WORDS 20   /* y[4..15] | roll pitch yaw Va alpha beta | failure code | pad: five 16-byte LDS accesses per lane */
+// k_step2, physics wave: the partner's actuator states, after workgroup barrier A0
+struct PartnerActuators {
+    static constexpr bool enabled = true;
+    const float* p;
+    __device__ __forceinline__ void fetch(float (&a_half)[5], float (&a_full)[5]) const {
+        __syncthreads();   // barrier A0
+        const float4 q0 = reinterpret_cast<const float4*>(p)[0], q1 = reinterpret_cast<const float4*>(p)[1], q2 = reinterpret_cast<const float4*>(p)[2];
+        a_half[0] = q0.x; a_half[1] = q0.y; a_half[2] = q0.z; a_half[3] = q0.w; a_half[4] = q1.x;
+        a_full[0] = q1.y; a_full[1] = q1.z; a_full[2] = q1.w; a_full[3] = q2.x; a_full[4] = q2.y;
+    }
+};
 
 template <bool TURB, int SPEC, int ROLE>
 __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs& A0, float* lds) {
@@ -131,15 +141,25 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
     const long e = valid ? env0 + lane : A.N - 1;
-    const LdsMap M = lds_map(c.obs_dim, c.n_obs, c.L.window, c.use_cmd_ring, KT::generic);
+    const LdsMap M = lds_map(c.obs_dim, c.n_obs, c.L.window, c.use_cmd_ring, KT::generic, c.obs_log, SPLIT);
     const fwg_layout& L = c.L;
     const int W = L.window;
     typename KT::Tab T = KT::tab(lds, M, lane);
     typename KT::Obs ob = KT::obs(lds, M, lane);
     float* aring = lds + M.aring + lane * 4;   // this lane's entries of the raw-action window [slot][lane][4]
     float* cring = lds + M.cring + lane * 4;   // ... of the constrained-command window (only when observations need it)
-    float* hand = lds + M.total + lane * FWG_HAND_WORDS;                       // split kernel: physics -> gym
-    float* noise = lds + M.total + FWG_WAVE * FWG_HAND_WORDS + lane * 4;       // split kernel: gym -> physics
+    // split kernel hand-off areas, aliasing the output staging area (see lds_map)
+    float* hand = lds + M.stage + lane * FWG_HAND_WORDS;                       // physics -> gym
+    float* noise = lds + M.stage + FWG_WAVE * FWG_HAND_WORDS + lane * 4;       // gym -> physics
+    float* acts = lds + M.stage + FWG_WAVE * (FWG_HAND_WORDS + 4) + lane * FWG_ACT_WORDS;   // gym -> physics
+    // FWG_EXT_ACTUATORS (experiment, off): the gym wave advances the actuators for the physics wave, which picks them up
+    // after its first stage.  Measured SLOWER by 1.0-1.2 us per step at 65 536 envs (the extra barrier inside the stage
+    // loop and the two VALU-heavy streams contending on every SIMD cost more than the 16 micro-steps save).
+#ifdef FWG_EXT_ACTUATORS
+    const bool ext_act = SPLIT && c.nsub == 1;
+#else
+    const bool ext_act = false;
+#endif
 
     // ---- phase A: issue every load up front.  The action windows stream HBM -> LDS (global_load_lds, no VGPRs, they
     // are addressed by the run-time ring slot); everything else goes to registers.
@@ -169,6 +189,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         GROUP(A.S, A.N, (L.cmd_ring >> 2) + A.slot_act, e) = make_float4(cmd_c[0], cmd_c[1], cmd_c[2], 0.f);
     float gust[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (PHYS && TURB) dryden_output(c, E.dry, gust);
+    float4 act_q3 = make_float4(0.f, 0.f, 0.f, 0.f), act_q4 = act_q3;
+    if (SPLIT && GYM && ext_act) {   // y[12..15] | y[16], y[17], ...: the actuator part of the simulator rows
+        act_q3 = load_group(A.S, A.N, (L.sim >> 2) + 3, e);
+        act_q4 = load_group(A.S, A.N, (L.sim >> 2) + 4, e);
+    }
     if (GYM) {
         // second wave of requests: bookkeeping rows to registers, action windows and lagged observation rows HBM -> LDS;
         // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
@@ -182,13 +207,27 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         else log_wrap(c, A.obs, A.N, e, A.gnow, valid, A.log_wrap_now);
 #endif
     }
+    if (SPLIT && GYM && ext_act) {
+        const float a0[5] = {act_q3.y, act_q3.z, act_q3.w, act_q4.x, act_q4.y};
+        float a_half[5], a_full[5];
+        actuators_over_step(c, a0, sp, a_half, a_full);
+        float4* w = reinterpret_cast<float4*>(acts);
+        w[0] = make_float4(a_half[0], a_half[1], a_half[2], a_half[3]);
+        w[1] = make_float4(a_half[4], a_full[0], a_full[1], a_full[2]);
+        w[2] = make_float4(a_full[3], a_full[4], 0.f, 0.f);
+        __syncthreads();   // barrier A0 (the physics wave passes it after its first stage)
+    }
     int fail = 0;
     if (PHYS) {
 #ifdef FWG_ABL_NO_SIM
         E.d = derive<TURB>(E.y, E.wind, gust);
 #else
         FWG_TL(A, 1);
-        fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
+#ifdef FWG_EXT_ACTUATORS
+        if (SPLIT) fail = sim_step<TURB, PartnerActuators>(c, E.y, sp, E.wind, gust, E.d, PartnerActuators{acts});
+        else
+#endif
+            fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
 #endif
         FWG_TL(A, 2);
         if (fail != 0) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
@@ -299,7 +338,9 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                     reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);
                     pre_reset = true;
                     // row log: the lagged rows of the terminal observation are records of earlier steps -- fetched now
+#ifdef FWG_ROW_PREFETCH   /* measured: fetching the terminal observation's lagged rows here costs +3.8 us per step */
                     if (c.obs_log > 0) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
+#endif
                     if (c.metrics) {   // records 1 .. cnt - 1 steps back (the current one is added when it exists)
                         const int cnt = (int)min(E.steps + 1u, (unsigned)FWG_END_WINDOW);
 #pragma unroll
@@ -495,8 +536,13 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     const bool early = c.obs_length > 1 && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
     const unsigned log_pad_t = E.steps;   // rows with lag >= this are padding (valid for lanes that do not finish)
     const long long log_win = A.log_win;   // wave-uniform
-    if (c.obs_log > 0 && __ballot((done || !ok) && valid && !pre_reset) != 0ull) {
-        if ((done || !ok) && valid && !pre_reset) log_load_rows(c, A.obs, A.N, e, log_win, ob);
+#ifdef FWG_ROW_PREFETCH
+    const bool rows_fetched = pre_reset;
+#else
+    const bool rows_fetched = false;
+#endif
+    if (c.obs_log > 0 && __ballot((done || !ok) && valid && !rows_fetched) != 0ull) {
+        if ((done || !ok) && valid && !rows_fetched) log_load_rows(c, A.obs, A.N, e, log_win, ob);
     }
     if (c.obs_length > 1 && (!ok || early)) fix_lagged_rows(c, A, e, E, T, ob, ok);
     if (c.obs_noise) add_obs_noise(c, A, e, E, ob);
@@ -655,7 +701,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
     const long e = valid ? env0 + lane : A.N - 1;
-    const LdsMap M = lds_map(c.obs_dim, c.n_obs, c.L.window, c.use_cmd_ring, KT::generic);
+    const LdsMap M = lds_map(c.obs_dim, c.n_obs, c.L.window, c.use_cmd_ring, KT::generic, c.obs_log);
     const bool sel = valid && (A.mask == nullptr || A.mask[e] != 0);
     const unsigned long long sel_mask = __ballot(sel);
     if (sel_mask == 0ull) return;
@@ -1213,11 +1259,11 @@ int fwg_dump_spec(const fwg_config* cfg, uint32_t* words_out, int64_t capacity) 
 template <bool IS_STEP, bool TURB, int SPEC>
 static void launch_one(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
     const dim3 grid((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), block(FWG_WAVE);
-    const size_t lds_bytes = (size_t)lds_map(h->h.obs_dim, h->h.n_obs, h->h.L.window, h->h.use_cmd_ring, SPEC < 0).total * sizeof(float);
+    const size_t lds_bytes = (size_t)lds_map(h->h.obs_dim, h->h.n_obs, h->h.L.window, h->h.use_cmd_ring, SPEC < 0, h->h.obs_log).total * sizeof(float);
     if (IS_STEP) {
 #ifndef FWG_NO_SPLIT
         if (SPEC >= 0 && h->split) {
-            const size_t lds2 = lds_bytes + (size_t)FWG_WAVE * (FWG_HAND_WORDS + 4) * sizeof(float);
+            const size_t lds2 = (size_t)lds_map(h->h.obs_dim, h->h.n_obs, h->h.L.window, h->h.use_cmd_ring, false, h->h.obs_log, true).total * sizeof(float);
             hipLaunchKernelGGL((k_step2<TURB, (SPEC >= 0 ? SPEC : 0)>), grid, dim3(2 * FWG_WAVE), lds2, stream, h->d_cfg, h->d_dyn, A);
             return;
         }

@@ -257,14 +257,22 @@ struct LdsMap { int aring, cring, lag, stage, tab, obs, total; };
 // LDS accesses; any other size falls back to an odd stride and 4-byte accesses
 __host__ __device__ inline bool obs_vec4(int obs_dim) { return (obs_dim % 4 == 0) && ((obs_dim / 4) % 2 == 1); }
 __host__ __device__ inline int obs_stage_stride(int obs_dim) { return obs_vec4(obs_dim) ? obs_dim : (obs_dim | 1); }
-__host__ __device__ inline LdsMap lds_map(int obs_dim, int n_obs, int window, int use_cmd_ring, bool generic) {
+// k_step2 hand-off areas (per lane): new state, noise, actuator states.  They ALIAS the output staging area: every use of
+// the staging area comes after workgroup barrier B, every hand-off access before it.  Workgroup residency is bounded by
+// LDS (4 workgroups per CU need <= 40 KiB each; a fifth area would cost a fourth of the chip).
+#define FWG_HAND_WORDS 20   /* y[4..15] | roll pitch yaw Va alpha beta | failure code | pad: five 16-byte LDS accesses per lane */
+#define FWG_ACT_WORDS 12    /* actuator states at t + h/2 and t + h (2 x 5) | pad: three 16-byte LDS accesses per lane */
+#define FWG_SPLIT_WORDS (FWG_HAND_WORDS + 4 + FWG_ACT_WORDS)
+__host__ __device__ inline LdsMap lds_map(int obs_dim, int n_obs, int window, int use_cmd_ring, bool generic, int obs_log = 0,
+                                          bool split = false) {
     LdsMap m;
     int o = 0;
     const int rows = obs_dim / n_obs, ng = (n_obs + 3) / 4;
     m.aring = o; o += window * 4 * FWG_WAVE;               // action window [slot][lane][4]
     m.cring = o; o += (use_cmd_ring ? window * 4 * FWG_WAVE : 0);
-    m.lag = o; o += (rows - 1) * ng * 4 * FWG_WAVE;        // lagged records [row-1][group][lane][4]
-    m.stage = o; o += FWG_WAVE * obs_stage_stride(obs_dim);  // [lane][obs_dim] staging of the output records
+    m.lag = o; o += obs_log > 0 ? 0 : (rows - 1) * ng * 4 * FWG_WAVE;   // lagged records [row-1][group][lane][4] (dense batch only)
+    const int stage = FWG_WAVE * obs_stage_stride(obs_dim), hand = split ? FWG_WAVE * FWG_SPLIT_WORDS : 0;
+    m.stage = o; o += stage > hand ? stage : hand;         // [lane][obs_dim] staging of the output records
     m.tab = o; o += generic ? FWG_TAB_ROWS * FWG_WAVE : 0;
     m.obs = o; o += generic ? obs_dim * FWG_WAVE : 0;
     m.total = (o + 3) & ~3;
@@ -499,7 +507,10 @@ __device__ __forceinline__ void goal_push(const DevCfg& c, Env& E, unsigned g, i
     unsigned present = 8u;
 #pragma unroll
     for (int r = 0; r < 3; ++r) present |= (r < c.n_targets && c.target[r].has_bound) ? (1u << r) : 0u;
-    const unsigned neu = g & present, old = (E.gw >> sh) & 0xFu;
+    // the nibble being overwritten was written streak_req records ago: it belongs to THIS episode only from record
+    // streak_req on -- before that it is a leftover of an earlier episode and counts as empty (so a reset need not clear
+    // the ring)
+    const unsigned neu = g & present, old = rec_index >= (unsigned)c.streak_req ? (E.gw >> sh) & 0xFu : 0u;
     E.gw = (E.gw & ~(0xFu << sh)) | (neu << sh);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -937,12 +948,10 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
     E.settle[0] = 0xFFFFFFFFu; E.settle[1] = 0xFFFFFFFFu;
     E.sdcmd = 0.f;
     if (c.metrics) GROUP(A.S, A.N, (c.L.end_ring >> 2) + g_end, e) = make_float4(err[0], err[1], err[2], 0.f);
-    E.wcnt = 0u; E.gcnt[0] = 0u; E.gcnt[1] = 0u; E.gw = 0u;
-    if (c.goal_enabled) {
-        unsigned* U = reinterpret_cast<unsigned*>(A.S);
-#pragma unroll
-        for (int w = 0; w < FWG_MAX_STREAK / 8; ++w) U[((unsigned)c.L.goal + (unsigned)w) * (unsigned)A.N + (unsigned)e] = 0u;
-        goal_push(c, E, goal_flags(c, err), g_bit, 0u);   // the word holding g_bit is written by store_gym
+    E.wcnt = 0u; E.gcnt[0] = 0u; E.gcnt[1] = 0u;
+    if (c.goal_enabled) {   // the ring keeps its old contents (see goal_push); only the word holding g_bit is touched
+        E.gw = reinterpret_cast<const unsigned*>(A.S)[((unsigned)c.L.goal + (unsigned)(g_bit >> 3)) * (unsigned)A.N + (unsigned)e];
+        goal_push(c, E, goal_flags(c, err), g_bit, 0u);   // ... and written back by store_gym
     }
     store_cold(c, A.S, A.N, e, E);
     // ---- observation: every row is the initial record (+ per-row init noise when length > 1)

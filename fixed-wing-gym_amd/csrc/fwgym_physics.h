@@ -176,6 +176,21 @@ __device__ __forceinline__ void constrain_commands(const DevCfg& c, const float 
     sp[0] = er; sp[1] = el; sp[2] = t;
 }
 
+// the actuator states at t + h/2 and t + h for one RK4 step per env step (what sim_step computes itself otherwise)
+__device__ __forceinline__ void actuators_over_step(const DevCfg& c, const float (&a0)[5], const float (&sp)[3], float (&a_half)[5],
+                                                    float (&a_full)[5]) {
+    float a[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) a[i] = a0[i];
+    sanitize_actuators(c, a);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) a_half[i] = a[i];
+    _Pragma("unroll") for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_half, sp);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) a_full[i] = a_half[i];
+    _Pragma("unroll") for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_full, sp);
+}
+
 struct Derived { float roll, pitch, yaw, Va, alpha, beta; };
 
 template <bool TURB>
@@ -211,9 +226,17 @@ __device__ __forceinline__ Derived derive(const float (&y)[NY], const float (&wi
 // micro-steps, rigid body by c.nsub classical RK4 steps whose stages see the actuator deflections at t, t+h/2,
 // t+h/2, t+h.  On success y holds the new state, otherwise y is untouched.  Returns the failure code (0 = ok,
 // var+1 = violated constraint, FWG_TERM_NAN - FWG_TERM_VAR0 + 1 = non-finite).
-template <bool TURB>
+// `ext` (k_step2): the actuator deflections at t + h/2 and t + h come from the partner wave, which advances the actuators
+// while this wave evaluates the first stage (they depend on the commands and the actuator states only); fetch() waits for
+// them.  Only for one RK4 step per env step (c.nsub == 1).
+struct NoExtActuators {
+    static constexpr bool enabled = false;
+    __device__ __forceinline__ void fetch(float (&)[5], float (&)[5]) const {}
+};
+template <bool TURB, class EXT = NoExtActuators>
 __device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const float (&sp)[3], const float (&wind)[3],
-                                        const float (&gust)[6], Derived& d) {
+                                        const float (&gust)[6], Derived& d, const EXT& ext = EXT()) {
+    const bool use_ext = EXT::enabled && c.nsub == 1;
     float yb[NB], a[5];
 #pragma unroll
     for (int i = 0; i < NB; ++i) yb[i] = y[i];
@@ -225,18 +248,22 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const f
         float a_half[5], a_full[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) a_half[i] = a[i];
+        if (!use_ext) {
 #ifdef FWG_ABL_ACT1
-        advance_actuators(c, a_half, sp);
+            advance_actuators(c, a_half, sp);
 #else
-        _Pragma(FWG_MICRO_PRAGMA) for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_half, sp);
+            _Pragma(FWG_MICRO_PRAGMA) for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_half, sp);
 #endif
+        }
 #pragma unroll
         for (int i = 0; i < 5; ++i) a_full[i] = a_half[i];
+        if (!use_ext) {
 #ifdef FWG_ABL_ACT1
-        advance_actuators(c, a_full, sp);
+            advance_actuators(c, a_full, sp);
 #else
-        _Pragma(FWG_MICRO_PRAGMA) for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_full, sp);
+            _Pragma(FWG_MICRO_PRAGMA) for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_full, sp);
 #endif
+        }
         float acc[NB], ys[NB], k[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) { acc[i] = 0.f; ys[i] = yb[i]; }
@@ -250,6 +277,7 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const f
 #pragma unroll
             for (int i = 0; i < 3; ++i) act[i] = (st == 0) ? a[i] : ((st == 3) ? a_full[i] : a_half[i]);
             rhs<TURB>(c, ys, act, wind, gust, k, fail);
+            if (use_ext && st == 0) ext.fetch(a_half, a_full);   // needed from the second stage on
             const float bw = (st == 0 || st == 3) ? c.h_sixth : 2.f * c.h_sixth;
             const float aw = (st == 2) ? c.h : c.half_h;
 #pragma unroll

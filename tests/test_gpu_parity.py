@@ -280,7 +280,7 @@ def test_single_step_parity_on_g5_states(turb, substeps):
         alive = alive & ok          # auto_reset is off: finished envs are outside the contract
     print("substeps={} turb={}: worst scaled {:.2e}, worst pure-relative (|x| > 1e-3) {:.2e}; constraint trips {}; "
           "rate-limited elevon samples {}, stalled samples {}".format(substeps, turb, worst, worst_rel, trips, rate_limited, stalled))
-    assert len(trips) >= 2 and rate_limited > 1000 and stalled > 1000
+    assert len(trips) >= 1 and sum(trips.values()) >= 10 and rate_limited > 1000 and stalled > 1000
     vec.close()
 
 
