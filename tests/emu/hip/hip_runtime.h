@@ -25,12 +25,18 @@
 #define __shared__
 #define FWG_DMA_DRAIN() ((void)0)
 #define FWG_EMU 1
+#ifdef FWG_EMU_OMP   /* bench-only CPU baseline: workgroups spread over OpenMP threads, per-thread emulation state */
+#include <omp.h>
+#define EMU_TLS thread_local
+#else
+#define EMU_TLS
+#endif
 
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct emu_idx { unsigned x, y, z; };
-static emu_idx threadIdx, blockIdx, blockDim;
+static EMU_TLS emu_idx threadIdx, blockIdx, blockDim;
 
 typedef int hipError_t;
 typedef void* hipStream_t;
@@ -52,18 +58,18 @@ static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; 
 // ---- block-wide lock-step primitives: the 64 lanes of a workgroup are fibers (ucontext) of ONE thread; a lane runs
 // until it reaches a barrier (or returns), then the next lane runs; a full round-robin pass = one barrier phase ----
 struct emu_lane { ucontext_t ctx; char* stack; int state; };  // state: 0 runnable, 1 at barrier, 2 finished
-static emu_lane emu_lanes[1024];
-static ucontext_t emu_sched_ctx;
-static unsigned emu_cur = 0;
-static uint32_t emu_xchg[1024];
-alignas(16) float lds[160 * 1024 / 4];  // the block's dynamic LDS (`extern __shared__ float lds[]` in the kernels)
+static EMU_TLS emu_lane emu_lanes[1024];
+static EMU_TLS ucontext_t emu_sched_ctx;
+static EMU_TLS unsigned emu_cur = 0;
+static EMU_TLS uint32_t emu_xchg[1024];
+alignas(16) EMU_TLS float lds[160 * 1024 / 4];  // the block's dynamic LDS (`extern __shared__ float lds[]` in the kernels)
 static emu_idx emu_block_idx, emu_block_dim;
 
 // Barriers: a lane that arrives yields until everybody of its scope (its 64-lane wave, or the workgroup) has arrived
 // -- lanes that already returned from the kernel do not count.  Generation counters make the barriers reusable.
-static unsigned emu_nwaves = 1;
-static unsigned emu_wave_live[16], emu_wave_wait[16], emu_wave_gen[16];
-static unsigned emu_block_live, emu_block_wait, emu_block_gen;
+static EMU_TLS unsigned emu_nwaves = 1;
+static EMU_TLS unsigned emu_wave_live[16], emu_wave_wait[16], emu_wave_gen[16];
+static EMU_TLS unsigned emu_block_live, emu_block_wait, emu_block_gen;
 static inline void emu_yield() {
     emu_lanes[emu_cur].state = 1;
     swapcontext(&emu_lanes[emu_cur].ctx, &emu_sched_ctx);
@@ -130,7 +136,7 @@ using std::min;
 
 // v_mfma_f32_32x32x16_bf16 for the 64-lane wave the calling lane belongs to: lane l supplies A[l & 31][8 (l >> 5) + t]
 // and B[8 (l >> 5) + t][l & 31], t = 0..7 (bf16), and receives D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31], r = 0..15
-static unsigned short emu_mfma_a[1024][8], emu_mfma_b[1024][8];
+static EMU_TLS unsigned short emu_mfma_a[1024][8], emu_mfma_b[1024][8];
 static inline float emu_bf16(unsigned short h) { const unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 template <class FRAG, class ACC>
 static inline ACC emu_mfma_f32_32x32x16_bf16(const FRAG& a, const FRAG& b, ACC c) {
@@ -151,46 +157,51 @@ static inline ACC emu_mfma_f32_32x32x16_bf16(const FRAG& a, const FRAG& b, ACC c
     return c;
 }
 
-static std::function<void()> emu_body;
+static EMU_TLS const std::function<void()>* emu_body;
 static void emu_trampoline() {
-    emu_body();
+    (*emu_body)();
     emu_lane_exit();
     emu_lanes[emu_cur].state = 2;
     swapcontext(&emu_lanes[emu_cur].ctx, &emu_sched_ctx);
 }
+static void emu_run_block(const std::function<void()>& body, unsigned b, dim3 block) {
+    static const size_t STACK = 2u << 20;
+    emu_body = &body;
+    for (unsigned t = 0; t < block.x; ++t) {
+        emu_lane& L = emu_lanes[t];
+        if (!L.stack) L.stack = (char*)malloc(STACK);
+        getcontext(&L.ctx);
+        L.ctx.uc_stack.ss_sp = L.stack;
+        L.ctx.uc_stack.ss_size = STACK;
+        L.ctx.uc_link = &emu_sched_ctx;
+        L.state = 0;
+        makecontext(&L.ctx, emu_trampoline, 0);
+    }
+    emu_nwaves = (block.x + 63) / 64;
+    for (unsigned w = 0; w < emu_nwaves; ++w) {
+        const unsigned first = w * 64, last = first + 64 < block.x ? first + 64 : block.x;
+        emu_wave_live[w] = last - first; emu_wave_wait[w] = 0;
+    }
+    emu_block_live = block.x; emu_block_wait = 0;
+    for (;;) {
+        unsigned alive = 0;
+        for (unsigned t = 0; t < block.x; ++t) {
+            if (emu_lanes[t].state == 2) continue;
+            ++alive;
+            emu_cur = t;
+            threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; blockDim = {block.x, 1, 1};
+            emu_lanes[t].state = 0;
+            swapcontext(&emu_sched_ctx, &emu_lanes[t].ctx);
+        }
+        if (!alive) break;
+    }
+}
 template <typename K, typename... Args>
 static void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
-    static const size_t STACK = 2u << 20;
-    emu_body = [=]() { kernel(args...); };
-    for (unsigned b = 0; b < grid.x; ++b) {
-        for (unsigned t = 0; t < block.x; ++t) {
-            emu_lane& L = emu_lanes[t];
-            if (!L.stack) L.stack = (char*)malloc(STACK);
-            getcontext(&L.ctx);
-            L.ctx.uc_stack.ss_sp = L.stack;
-            L.ctx.uc_stack.ss_size = STACK;
-            L.ctx.uc_link = &emu_sched_ctx;
-            L.state = 0;
-            makecontext(&L.ctx, emu_trampoline, 0);
-        }
-        emu_nwaves = (block.x + 63) / 64;
-        for (unsigned w = 0; w < emu_nwaves; ++w) {
-            const unsigned first = w * 64, last = first + 64 < block.x ? first + 64 : block.x;
-            emu_wave_live[w] = last - first; emu_wave_wait[w] = 0;
-        }
-        emu_block_live = block.x; emu_block_wait = 0;
-        for (;;) {
-            unsigned alive = 0;
-            for (unsigned t = 0; t < block.x; ++t) {
-                if (emu_lanes[t].state == 2) continue;
-                ++alive;
-                emu_cur = t;
-                threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; blockDim = {block.x, 1, 1};
-                emu_lanes[t].state = 0;
-                swapcontext(&emu_sched_ctx, &emu_lanes[t].ctx);
-            }
-            if (!alive) break;
-        }
-    }
+    const std::function<void()> body = [=]() { kernel(args...); };
+#ifdef FWG_EMU_OMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int b = 0; b < (int)grid.x; ++b) emu_run_block(body, (unsigned)b, block);
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)

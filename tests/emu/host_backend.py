@@ -12,20 +12,27 @@ EMU_LIB = os.path.join(HERE, "libfwgym_emu.so")
 SRC = os.path.join(ROOT, "fixed-wing-gym_amd", "csrc")
 
 
-def build_emu(force=False):
+def build_emu_omp(force=False):
+    """Bench-only CPU baseline (bench.py cpu_baseline "native"): the same emulation build with -O2 and the workgroups
+    spread over OpenMP threads."""
+    return build_emu(force, out=os.path.join(HERE, "libfwgym_emu_omp.so"), extra=["-O2", "-fopenmp", "-DFWG_EMU_OMP"])
+
+
+def build_emu(force=False, out=None, extra=None):
     srcs = [os.path.join(SRC, f) for f in os.listdir(SRC) if os.path.isfile(os.path.join(SRC, f))] + [os.path.join(HERE, "hip", "hip_runtime.h"),
                                                                os.path.join(ROOT, "include", "fwgym.h")]
     inc = os.path.join(SRC, "generated", "specs.inc")
     srcs = srcs + ([inc] if os.path.exists(inc) else [])
-    if not force and os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(s) for s in srcs):
-        return EMU_LIB
-    cmd = ["g++", "-x", "c++", "-std=c++17", "-O1", "-shared", "-fPIC", "-pthread", "-w", "-I" + HERE] + \
+    out = out or EMU_LIB
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+        return out
+    cmd = ["g++", "-x", "c++", "-std=c++17", "-O1", "-shared", "-fPIC", "-pthread", "-w", "-I" + HERE] + (extra or []) + \
           (["-DFWG_WITH_SPECS"] if os.path.exists(inc) else []) + [
-           "-I" + os.path.join(ROOT, "include"), "-I" + SRC, "-o", EMU_LIB + ".tmp{}".format(os.getpid()),
+           "-I" + os.path.join(ROOT, "include"), "-I" + SRC, "-o", out + ".tmp{}".format(os.getpid()),
            os.path.join(SRC, "fwgym.hip")]
     subprocess.run(cmd, check=True)
-    os.replace(EMU_LIB + ".tmp{}".format(os.getpid()), EMU_LIB)   # atomic: parallel test workers may build at once
-    return EMU_LIB
+    os.replace(out + ".tmp{}".format(os.getpid()), out)   # atomic: parallel test workers may build at once
+    return out
 
 
 class HostBackend(object):
