@@ -343,13 +343,14 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #endif
                     if (c.metrics) {   // records 1 .. cnt - 1 steps back (the current one is added when it exists)
                         const int cnt = (int)min(E.steps + 1u, (unsigned)FWG_END_WINDOW);
+                        // every slot is requested unconditionally (all are valid memory) and masked in the sum: the 49
+                        // loads then issue back to back instead of one latency each
 #pragma unroll
                         for (int q = 1; q < FWG_END_WINDOW; ++q) {
-                            if (q < cnt) {
-                                int slot = A.slot_end - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
-                                const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
-                                end_prev[0] += r.x; end_prev[1] += r.y; end_prev[2] += r.z;
-                            }
+                            int slot = A.slot_end - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
+                            const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                            const bool in = q < cnt;
+                            end_prev[0] += in ? r.x : 0.f; end_prev[1] += in ? r.y : 0.f; end_prev[2] += in ? r.z : 0.f;
                         }
                     }
                 }
@@ -578,12 +579,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                     p += (p < 0) ? FWG_END_WINDOW : 0;
                     if (ok) { end_sum[0] = err[0]; end_sum[1] = err[1]; end_sum[2] = err[2]; }
 #pragma unroll
-                    for (int q = 0; q < FWG_END_WINDOW; ++q) {
-                        if (q >= first && q < end_cnt) {
-                            int slot = p - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
-                            const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
-                            end_sum[0] += r.x; end_sum[1] += r.y; end_sum[2] += r.z;
-                        }
+                    for (int q = 0; q < FWG_END_WINDOW; ++q) {   // unconditional loads, masked sums (see the prework)
+                        int slot = p - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
+                        const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                        const bool in = q >= first && q < end_cnt;
+                        end_sum[0] += in ? r.x : 0.f; end_sum[1] += in ? r.y : 0.f; end_sum[2] += in ? r.z : 0.f;
                     }
                 }
 #pragma unroll
@@ -638,7 +638,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #pragma unroll
             for (int i = 0; i < 32; ++i) v32[i] = i < FWG_N_REDUCE ? red[i] : 0.f;
             const float tot = wave_totals32(v32, lane);   // lane l holds the total of value l & 31
-            if (lane < FWG_N_REDUCE && tot != 0.f) atomicAdd(A.reduce + lane, tot);
+            if (lane < FWG_N_REDUCE && tot != 0.f)   // counts (0..4) as integers, the rest in 2^-20 fixed point: exact, order-free
+                atomicAdd(A.reduce + lane, (unsigned long long)(long long)rintf(lane < 5 ? tot : tot * FWG_ACC_SCALE));
         }
         if (c.auto_reset && done && valid) {
             if (!pre_reset) reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);   // not foreseen (failure, success): drawn now
@@ -737,6 +738,16 @@ __global__ void k_check_nan(const float* __restrict__ a, long n, int* flag) {
     if (i < n && a[i] != a[i]) atomicOr(flag, 1);
 }
 
+// fwg_reduce_success_device: fixed-point sums -> floats, accumulators cleared (one tiny launch, stream-ordered)
+__global__ void k_reduce_take(unsigned long long* __restrict__ acc, float* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < FWG_N_REDUCE) {
+        const long long q = (long long)acc[i];
+        out[i] = i < 5 ? (float)q : (float)((double)q / (double)FWG_ACC_SCALE);
+        acc[i] = 0ull;
+    }
+}
+
 // known-answer hook for the device Philox4x32-10 (fwg_selftest_philox): in[i] = counter[4] | key[2]
 __global__ void k_selftest_philox(const unsigned* __restrict__ in, unsigned* __restrict__ out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -775,7 +786,7 @@ struct fwg_handle {
     int spec;  // index of the frozen configuration the lowered DevCfg equals, or -1
     DevCfg* d_cfg;
     DynCfg* d_dyn;
-    float* d_reduce;
+    unsigned long long* d_reduce;
     int* d_flag;
     float* arena;
     int64_t n_envs;
@@ -1038,13 +1049,13 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     HIP_TRY(hipMalloc((void**)&h->d_cfg, sizeof(DevCfg)));
     HIP_TRY(hipMalloc((void**)&h->d_dyn, sizeof(DynCfg)));
     HIP_TRY(hipMemcpy(h->d_dyn, &h->hd, sizeof(DynCfg), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void**)&h->d_reduce, sizeof(float) * FWG_N_REDUCE));
+    HIP_TRY(hipMalloc((void**)&h->d_reduce, sizeof(unsigned long long) * FWG_N_REDUCE));
     HIP_TRY(hipMalloc((void**)&h->d_flag, sizeof(int)));
     HIP_TRY(hipMalloc((void**)&h->d_slots, 2 * sizeof(StepSlots)));
     HIP_TRY(hipMemset(h->d_slots, 0, 2 * sizeof(StepSlots)));
     h->graph_mode = 0;
     HIP_TRY(hipMemcpy(h->d_cfg, &h->h, sizeof(DevCfg), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(h->d_reduce, 0, sizeof(float) * FWG_N_REDUCE));
+    HIP_TRY(hipMemset(h->d_reduce, 0, sizeof(unsigned long long) * FWG_N_REDUCE));
     HIP_TRY(hipMemset(h->d_flag, 0, sizeof(int)));
     *out = h;
     return FWG_OK;
@@ -1178,18 +1189,23 @@ int fwg_check_actions(fwg_handle* h, const float* actions, void* stream) {
     return FWG_OK;
 }
 
+static inline float reduce_to_float(int i, unsigned long long q) {
+    return i < 5 ? (float)(long long)q : (float)((double)(long long)q / (double)FWG_ACC_SCALE);
+}
 int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream) {
     if (!h || !out_host) return fail_with(FWG_ERR_INVALID, "null argument");
-    HIP_TRY(hipMemcpyAsync(out_host, h->d_reduce, sizeof(float) * FWG_N_REDUCE, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIP_TRY(hipMemsetAsync(h->d_reduce, 0, sizeof(float) * FWG_N_REDUCE, (hipStream_t)stream));
+    unsigned long long q[FWG_N_REDUCE];
+    HIP_TRY(hipMemcpyAsync(q, h->d_reduce, sizeof(q), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(h->d_reduce, 0, sizeof(q), (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < FWG_N_REDUCE; ++i) out_host[i] = reduce_to_float(i, q[i]);
     return FWG_OK;
 }
 
 int fwg_reduce_success_device(fwg_handle* h, float* out_dev, void* stream) {
     if (!h || !out_dev) return fail_with(FWG_ERR_INVALID, "null argument");
-    HIP_TRY(hipMemcpyAsync(out_dev, h->d_reduce, sizeof(float) * FWG_N_REDUCE, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    HIP_TRY(hipMemsetAsync(h->d_reduce, 0, sizeof(float) * FWG_N_REDUCE, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_reduce_take, dim3(1), dim3(FWG_WAVE), 0, (hipStream_t)stream, h->d_reduce, out_dev);
+    HIP_TRY(hipGetLastError());
     return FWG_OK;
 }
 

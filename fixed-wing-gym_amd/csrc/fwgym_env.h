@@ -17,7 +17,8 @@ struct KArgs {
     float* term_obs;          // nullable [N][obs_dim]
     float* metrics;           // nullable [FWG_N_METRICS][N]
     float* tgt_out;           // nullable [N][n_targets]
-    float* reduce;            // [FWG_N_REDUCE]
+    unsigned long long* reduce;   // [FWG_N_REDUCE] fixed-point sums (2^-20; entries 0..4 are counts): integer atomics are
+                              // native and order-free, float atomicAdd compiles to a compare-and-swap loop
     const uint8_t* mask;      // reset: nullable [N]
     const float* init_state;  // reset: nullable [FWG_N_RESET_VARS][N]
     const float* init_target; // reset: nullable [n_targets][N]

@@ -49,6 +49,16 @@ def run():
         vec._lib.fwg_debug_set_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         vec._lib.fwg_debug_set_trace(vec._handle, ctypes.c_void_p(trace.data_ptr()))
         acts = [torch.rand((n, 3), device="cuda") * 2 - 1 for _ in range(16)]
+        stagger = int(os.environ.get("TL_STAGGER", "0"))
+        if stagger:   # spread the episode ages (and, with constant actions, provoke failures: TL_CONST=1)
+            const = os.environ.get("TL_CONST", "0") == "1"
+            per = int(vec.cfg["steps_max"]) // stagger
+            for k in range(stagger):
+                vec.reset(indices=np.arange(k, n, stagger))
+                for t in range(per):
+                    vec.step_device(acts[0] if const else acts[t % 16], want_obs=False)
+            if const:
+                acts = [acts[0]] * 16
         for t in range(300):
             vec.step_device(acts[t % 16])
         torch.cuda.synchronize()
@@ -80,6 +90,14 @@ def run():
             if np.all(np.isnan(med[w])):
                 continue
             print("   wave {}: ".format(w) + "  ".join("{}:{:.0f}".format(i, med[w][i]) for i in range(11) if not np.isnan(med[w][i])))
+        # the slowest block of the last launch: where did ITS time go?
+        last = rel[-1]
+        worst = int(np.nanargmax(np.nanmax(last, axis=(1, 2))))
+        print("   slowest block {} of the last launch (lifetime {:.0f}, done lanes in the wave: {}):".format(
+            worst, np.nanmax(last[worst]), int(vec._done[worst * 64:(worst + 1) * 64].sum().item())))
+        for w in range(2):
+            if not np.all(np.isnan(last[worst][w])):
+                print("      wave {}: ".format(w) + "  ".join("{}:{:.0f}".format(i, last[worst][w][i]) for i in range(11) if not np.isnan(last[worst][w][i])))
         vec.close()
     print(json.dumps(res))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
