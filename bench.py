@@ -148,11 +148,13 @@ def main():
                          "sampling); 'none' = env step on stored actions")
     ap.add_argument("--eager", action="store_true", help="launch every step from the host instead of replaying hipGraphs")
     ap.add_argument("--lib", default=None, help="measurement builds (tools/ablate.py): path of an alternative libfwgym.so")
-    ap.add_argument("--stagger", type=int, default=32,
-                    help="S > 0 (default 32): before the warm-up, reset 1/S of the envs every steps_max/S steps, so that episode "
-                         "ends (metrics, success reduction, in-kernel auto-reset) are spread evenly over the timed steps -- the "
-                         "steady state of a long run -- instead of all envs hitting steps_max at the same step; 0 = all envs "
-                         "start together (no episode ends inside a short timed region)")
+    ap.add_argument("--stagger", type=int, default=0,
+                    help="S > 0: before the warm-up, reset 1/S of the envs every steps_max/S steps, so that episode ends (metrics, "
+                         "success reduction, in-kernel auto-reset, early-episode observation padding) are spread evenly over the "
+                         "timed steps -- the steady state of a long run.  Default 0: all envs start together as a fresh VecEnv "
+                         "does (no episode ends inside a short timed region); the steady state is then measured as well and "
+                         "reported as `steady_state` next to `value` (1 GPU, env-step workloads)")
+    ap.add_argument("--no-steady-state", action="store_true", help="skip the `steady_state` side measurement")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: host-emulation build of the kernels + gloo, tiny batch (exercises the launcher, the "
                          "sharding and the collective on a machine without GPUs; the numbers are not measurements)")
@@ -216,17 +218,21 @@ def main():
     vec = FixedWingVecEnv(cfg, num_envs=n_envs, config_kw=ckw, sim_config_kw=skw, seed=0, env_id_base=first,
                           auto_reset=True, derived_views=False, obs_log_rows=log_rows, **kw)
     vec.reset()
-    if args.stagger and not args.emulate:
+    def stagger_ages(parts):
+        """Resets 1/parts of the envs every steps_max/parts steps (parts = steps_max: ages uniform over [0, steps_max))."""
         import numpy as _np
         gen0 = torch.Generator(device=dev)
         gen0.manual_seed(99 + rank)
-        a0 = torch.rand((n_envs, 3), device=dev, generator=gen0) * 2 - 1
-        per = max(1, int(vec.cfg["steps_max"]) // args.stagger)
-        for k in range(args.stagger):
-            vec.reset(indices=_np.arange(k, n_envs, args.stagger))
-            for _ in range(per):
-                vec.step_device(a0, want_obs=False)
+        acts0 = [torch.rand((n_envs, 3), device=dev, generator=gen0) * 2 - 1 for _ in range(4)]
+        per = max(1, int(vec.cfg["steps_max"]) // parts)
+        for k in range(parts):
+            vec.reset(indices=_np.arange(k, n_envs, parts))
+            for t in range(per):
+                vec.step_device(acts0[t % 4], want_obs=False)
         torch.cuda.synchronize(dev)
+
+    if args.stagger and not args.emulate:
+        stagger_ages(args.stagger)
     if args.emulate:
         import numpy as np
         rng = np.random.default_rng(1234 + rank)
@@ -250,7 +256,9 @@ def main():
             else:
                 seen["episodes"] += float(local_sums[0])
             return
-        vec.reduce_success_device(red_dev)         # local sums, device to device, stream-ordered (no host sync)
+        if fused or not graphs:
+            vec.reduce_success_device(red_dev)     # local sums, device to device, stream-ordered (no host sync)
+        # (graph mode: the local sums were taken by the last node of the replayed chunk)
         if use_dist:
             dist.all_gather_into_tensor(gathered, red_dev)   # RCCL over xGMI: 64 B per rank
 
@@ -285,6 +293,7 @@ def main():
             with torch.cuda.graph(g):
                 for t in range(n):
                     vec.step_device(pool[(offset + t) % len(pool)], want_obs=False)
+                vec.reduce_success_device(red_dev)   # the chunk's success sums: device to device, part of the graph
             vec.capture_end()
             step_graphs[key] = g
         return step_graphs[key]
@@ -348,6 +357,24 @@ def main():
         wall = float(tt.item())
     event_ms = ev0.elapsed_time(ev1) / args.steps if not args.emulate else None
 
+    steady = None
+    if (world == 1 and graphs and not fused and not args.stagger and not args.no_steady_state and chunk):
+        # the same launches with episode ages spread uniformly (every step then has waves that end episodes, reset envs in
+        # the kernel and pad early-episode observation rows): what a long run sees
+        stagger_ages(int(vec.cfg["steps_max"]))
+        run(chunk, 1, 0, 0)
+        torch.cuda.synchronize(dev)
+        reps = max(replays, (400 + chunk - 1) // chunk)
+        ts0 = time.perf_counter()
+        run(chunk, reps, 0, 0)
+        torch.cuda.synchronize(dev)
+        ts = (time.perf_counter() - ts0) / (reps * chunk)
+        steady = {"ms_per_step": ts * 1e3, "value": n_envs / ts, "unit": "env-steps/s",
+                  "roofline_frac": ALG_BYTES[args.workload] * n_envs / ts / 1e9 / HBM_PEAK_GBS, "steps": reps * chunk,
+                  "note": "episode ages uniform over [0, steps_max) (1/steps_max of the envs reset at every step of an untimed "
+                          "steps_max-step run): about {} episode ends per step, each in a different wave".format(
+                              round(n_envs / max(1, int(vec.cfg["steps_max"]))))}
+
     out = None
     if rank == 0:
         total_envs = args.total_envs if args.total_envs else n_envs * world
@@ -388,6 +415,8 @@ def main():
                          "clock": "wall clock of the timed region (the same interval as `value`)",
                          "algorithmic_bytes_per_env_step": ALG_BYTES[args.workload], "source_hash": source_hash()},
         }
+        if steady is not None:
+            out["steady_state"] = steady
         if args.emulate:
             out["emulated_episodes_seen"] = seen["episodes"]
     vec.close()

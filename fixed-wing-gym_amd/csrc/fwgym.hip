@@ -1212,6 +1212,7 @@ int fwg_reduce_success_device(fwg_handle* h, float* out_dev, void* stream) {
 int fwg_spec_index(const fwg_handle* h) { return h ? h->spec : -1; }
 #ifdef FWG_TIMELINE
 int fwg_debug_set_trace(fwg_handle* h, long long* trace_dev) { if (!h) return FWG_ERR_INVALID; h->trace = trace_dev; return FWG_OK; }
+int fwg_debug_set_actor_trace(struct fwg_actor* a, long long* trace_dev);
 #endif
 
 int fwg_set_graph_mode(fwg_handle* h, int enable, void* stream) {
@@ -1321,6 +1322,9 @@ struct fwg_actor {
     float* d_ret;
     size_t lds_act[2];     // dynamic LDS of k_actor_act<1>, <3>
     const fwg_handle* log_env;   // fwg_actor_set_obs_log: `obs` arguments are this env's row log
+#ifdef FWG_TIMELINE
+    long long* trace;
+#endif
 };
 
 static size_t actor_lds_bytes(int nk1, int parts) {
@@ -1337,6 +1341,9 @@ static ActorArgs actor_args(const fwg_actor* a) {
     A.D = a->D; A.nk1 = a->nk1; A.act_dim = a->act_dim; A.parity = a->parity; A.training = a->training;
     A.gamma = a->gamma; A.clip_obs = a->clip_obs; A.clip_rew = a->clip_rew; A.eps = a->eps;
     A.seed_lo = (unsigned)(a->seed & 0xFFFFFFFFull); A.seed_hi = (unsigned)(a->seed >> 32);
+#ifdef FWG_TIMELINE
+    A.trace = a->trace;
+#endif
     if (a->log_env != nullptr) {   // the window of the env's LAST completed step; read on the device in graph mode
         const fwg_handle* h = a->log_env;
         A.obs_n = h->h.n_obs;
@@ -1366,6 +1373,9 @@ int fwg_attach_observer(fwg_handle* h, fwg_actor* a) {
     return FWG_OK;
 }
 
+#ifdef FWG_TIMELINE
+int fwg_debug_set_actor_trace(fwg_actor* a, long long* trace_dev) { if (!a) return FWG_ERR_INVALID; a->trace = trace_dev; return FWG_OK; }
+#endif
 int fwg_actor_set_obs_log(fwg_actor* a, const fwg_handle* env) {
     if (!a) return fail_with(FWG_ERR_INVALID, "fwg_actor_set_obs_log: null actor");
     if (env != nullptr) {

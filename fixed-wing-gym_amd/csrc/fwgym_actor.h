@@ -39,6 +39,9 @@ struct ActorArgs {
     // obs_n > 0: `obs` is an env's observation ROW LOG (fwgym_env.h): feature f = r obs_n + j of env e sits at
     // obs[((win + r) N + e) obs_n + j], win = obs_slots->log_win (graph mode: read on the device) or obs_win (host value)
     const StepSlots* obs_slots; long long obs_win; int obs_n;
+#ifdef FWG_TIMELINE
+    long long* trace;   // measurement builds: [block][wave][8] s_memtime stamps
+#endif
     float* ret;
     ActorStats* stats;                  // [2], indexed by parity
     unsigned long long* acc; int acc_cols;   // [2][FWG_ACC_SHARDS][acc_cols]
@@ -86,6 +89,13 @@ __device__ __forceinline__ const float* actor_obs_at(const ActorArgs& A, long lo
     return A.obs + ((win + r) * A.N + e) * A.obs_n + j;
 }
 __device__ __forceinline__ long long actor_obs_win(const ActorArgs& A) { return A.obs_slots != nullptr ? A.obs_slots->log_win : A.obs_win; }
+
+#ifdef FWG_TIMELINE
+#define FWG_ATL(A, i) do { if ((A).trace != nullptr) { const long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); \
+        if ((threadIdx.x & 63) == 0) (A).trace[(blockIdx.x * FWG_ACT_WAVES + (threadIdx.x >> 6)) * 8 + (i)] = t_; } } while (0)
+#else
+#define FWG_ATL(A, i) do { } while (0)
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifdef FWG_EMU
@@ -248,6 +258,7 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, j = l & 31, half = l >> 5;
     constexpr int nf = 2 * (NK1 + 1) + 15;
     constexpr int PARTS = SPLIT > 1 ? 2 : 1;
+    FWG_ATL(A, 0);
     frag_t* F = reinterpret_cast<frag_t*>(lds);                     // [net][part][nf][64]
     float* mean_s = lds + 2 * PARTS * nf * 64 * 4;                  // [64]
     float* rstd_s = mean_s + FWG_ACT_MAX_OBS;                       // [64]
@@ -255,11 +266,23 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     // packed weights HBM/L2 -> LDS without a register round trip (global_load_lds, 1 KiB per wave instruction): in
     // flight while the statistics are folded and the observations normalised, waited for before the first MFMA
 #ifndef FWG_ABL_ACT_NO_STAGE
-    for (int net = 0; net < 2; ++net)
-        for (int part = 0; part < PARTS; ++part)
-            for (int fr = wv; fr < nf; fr += FWG_ACT_WAVES)
-                dma_group(reinterpret_cast<const float4*>(A.frags + ((net * 2 + part) * nf + fr) * 64 + l),
-                          reinterpret_cast<float*>(F + ((net * PARTS + part) * nf + fr) * 64));
+    if (PARTS == 2) {   // source and destination have the same layout: ONE linear copy of 2 * 2 * nf KiB, a wave moves 1 KiB
+        constexpr int total = 2 * 2 * nf;   // per instruction; the pieces are dealt to the 8 waves round-robin
+#pragma unroll
+        for (int i = 0; i < (total + FWG_ACT_WAVES - 1) / FWG_ACT_WAVES; ++i) {
+            const int fr = wv + i * FWG_ACT_WAVES;
+            if (fr < total) dma_group(reinterpret_cast<const float4*>(A.frags + fr * 64 + l), reinterpret_cast<float*>(F + fr * 64));
+        }
+    } else {            // single products: only the hi parts are staged
+#pragma unroll
+        for (int i = 0; i < (2 * nf + FWG_ACT_WAVES - 1) / FWG_ACT_WAVES; ++i) {
+            const int q = wv + i * FWG_ACT_WAVES;
+            if (q < 2 * nf) {
+                const int net = q / nf, fr = q - net * nf;
+                dma_group(reinterpret_cast<const float4*>(A.frags + ((net * 2) * nf + fr) * 64 + l), reinterpret_cast<float*>(F + (net * nf + fr) * 64));
+            }
+        }
+    }
 #endif
     // raw observation entries of this lane (k-slots of the first layer), requested before the statistics are folded
     const long e = (long)blockIdx.x * FWG_ACT_ENVS + wv * 32 + j;
@@ -286,6 +309,7 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
             for (int i = 0; i < 4; ++i) raw_x[kk][4 * q + i] = v[i];
         }
     }
+    FWG_ATL(A, 1);
     {   // add the accumulator shards (integers: exact, order-free) and fold the batch into the running statistics (the
         // parallel-variance update of VecNormalize's RunningMeanStd).  Every block computes the same values; block 0
         // publishes them and clears the other parity's accumulators for the launches that follow
@@ -343,6 +367,7 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
         }
     }
     __syncthreads();
+    FWG_ATL(A, 2);
 
     frag_t bx_hi[NK1], bx_lo[NK1];
 #pragma unroll
@@ -367,8 +392,10 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
         }
         split8(x, bx_hi[kk], bx_lo[kk]);
     }
+    FWG_ATL(A, 3);
     dma_wait();
     __syncthreads();
+    FWG_ATL(A, 4);
     // both networks in one instruction stream: their MFMA chains and tanh phases are independent and interleave
 #ifdef FWG_ABL_ACT_NO_MLP   // measurement only (tools/ablate.py)
     f32x16 o_pi = {0.f}, o_vf = {0.f};
@@ -377,6 +404,7 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     const f32x16 o_pi = mlp_forward<SPLIT, NK1>(F, l, bx_hi, bx_lo);
     const f32x16 o_vf = mlp_forward<SPLIT, NK1>(F + PARTS * nf * 64, l, bx_hi, bx_lo);
 #endif
+    FWG_ATL(A, 5);
     const float res[2][FWG_ACT_MAX_ACT] = {{o_pi[0], o_pi[1], o_pi[2], o_pi[3]}, {o_vf[0], o_vf[1], o_vf[2], o_vf[3]}};
     if (half == 0 && valid) {
         float n[4] = {0.f, 0.f, 0.f, 0.f};
@@ -400,6 +428,7 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
             A.norm_rew[e] = fminf(fmaxf(A.rew[e] * misc[0], -A.clip_rew), A.clip_rew);
         if (A.done_out != nullptr && A.done != nullptr) A.done_out[e] = A.done[e];
     }
+    FWG_ATL(A, 6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
