@@ -253,11 +253,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     float fval_action[FWG_MAX_FACTORS];   // values of the reward factors of class "action" (fixed_wing.py:686-700)
     float obs_action[FWG_MAX_OBS];        // "action" entries of the newest observation row (fixed_wing.py:813-828)
     float tgt_next[3] = {0.f, 0.f, 0.f};  // targets propagated by one step, valid unless the target is resampled
-    // episodes that end at steps_max are known before the integration: their reset draw (the Philox-heavy half of reset)
-    // and the sum of the previous end-error records are prepared here too, off the step's critical path
-    bool pre_reset = false;
-    ResetDraw RD;
-    float end_prev[3] = {0.f, 0.f, 0.f};
+    // (the next episode's reset draw is prepared here too, piece by piece, in the steps after each reset)
     auto gym_prework = [&]() {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {   // the own action enters the LDS copy of the windows
@@ -331,28 +327,25 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #pragma unroll
             for (int k = 0; k < 3; ++k) { tgt_next[k] = E.tgt[k]; E.tgt[k] = keep[k]; }
         }
-        if (c.auto_reset && c.steps_max > 0) {
-            const bool will_end = valid && done;   // E.steps reached steps_max
-            if (__ballot(will_end) != 0ull) {
-                if (will_end) {
-                    reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);
-                    pre_reset = true;
-                    // row log: the lagged rows of the terminal observation are records of earlier steps -- fetched now
-#ifdef FWG_ROW_PREFETCH   /* measured: fetching the terminal observation's lagged rows here costs +3.8 us per step */
-                    if (c.obs_log > 0) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
-#endif
-                    if (c.metrics) {   // records 1 .. cnt - 1 steps back (the current one is added when it exists)
-                        const int cnt = (int)min(E.steps + 1u, (unsigned)FWG_END_WINDOW);
-                        // every slot is requested unconditionally (all are valid memory) and masked in the sum: the 49
-                        // loads then issue back to back instead of one latency each
+        if (c.auto_reset) {   // one piece of the NEXT episode's reset draw, for lanes that do not have it yet.  At most ONE
+            // kind of piece per wave and step (the least advanced lanes first): a wave whose lanes sit at different stages
+            // would otherwise run all the pieces back to back and outlast the integration it hides behind
+            const unsigned stage = draw_stage_of(E.flags);
+            const bool work = valid && stage < FWG_DRAW_READY;
+            unsigned long long m = 0ull;
+            unsigned pick = FWG_DRAW_READY;
 #pragma unroll
-                        for (int q = 1; q < FWG_END_WINDOW; ++q) {
-                            int slot = A.slot_end - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
-                            const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
-                            const bool in = q < cnt;
-                            end_prev[0] += in ? r.x : 0.f; end_prev[1] += in ? r.y : 0.f; end_prev[2] += in ? r.z : 0.f;
-                        }
-                    }
+            for (unsigned sidx = 0; sidx < FWG_DRAW_READY; ++sidx) {
+                const unsigned long long ms = __ballot(work && stage == sidx);
+                if (pick == FWG_DRAW_READY && ms != 0ull) { pick = sidx; m = ms; }
+            }
+#ifdef FWG_ABL_NO_STAGED_DRAW
+            m = 0ull;
+#endif
+            if (m != 0ull) {
+                if (work && stage == pick) {
+                    const unsigned ns = draw_stage_step(c, dc, A, e, E.episode, stage, T);
+                    E.flags = (E.flags & ~FWG_DRAW_STAGE_MASK) | (ns << FWG_DRAW_STAGE_SHIFT);
                 }
             }
         }
@@ -494,7 +487,9 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 E.emin[k] = fminf(E.emin[k], err[k]); E.emax[k] = fmaxf(E.emax[k], err[k]);
                 E.perr[k] = err[k];
             }
-            if (valid) store_group_once(A.S, A.N, (L.end_ring >> 2) + A.slot_end, e, make_float4(err[0], err[1], err[2], 0.f));
+            // the ring holds the episode's CUMULATIVE error sums: the sum over the last 50 records is then the difference
+            // of two entries (one load at the episode end instead of the whole window)
+            if (valid) store_group_once(A.S, A.N, (L.end_ring >> 2) + A.slot_end, e, make_float4(E.esum[0], E.esum[1], E.esum[2], 0.f));
         }
     } else {
         done = true;
@@ -537,13 +532,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     const bool early = c.obs_length > 1 && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
     const unsigned log_pad_t = E.steps;   // rows with lag >= this are padding (valid for lanes that do not finish)
     const long long log_win = A.log_win;   // wave-uniform
-#ifdef FWG_ROW_PREFETCH
-    const bool rows_fetched = pre_reset;
-#else
-    const bool rows_fetched = false;
-#endif
-    if (c.obs_log > 0 && __ballot((done || !ok) && valid && !rows_fetched) != 0ull) {
-        if ((done || !ok) && valid && !rows_fetched) log_load_rows(c, A.obs, A.N, e, log_win, ob);
+    if (c.obs_log > 0 && __ballot((done || !ok) && valid) != 0ull) {
+        if ((done || !ok) && valid) log_load_rows(c, A.obs, A.N, e, log_win, ob);
     }
     if (c.obs_length > 1 && (!ok || early)) fix_lagged_rows(c, A, e, E, T, ob, ok);
     if (c.obs_noise) add_obs_noise(c, A, e, E, ob);
@@ -565,26 +555,16 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #pragma unroll
             for (int i = 0; i < FWG_N_METRICS; ++i) mt[i] = NAN;
             if (c.metrics) {
-                // end_error: |mean of the last <= 50 errors|.  Foreseen ends: the older records were summed before the
-                // barrier; otherwise the whole ring is requested at once (one 16-byte record per slot, 49 independent
-                // loads) -- the newest record is this step's error, still in registers
+                // end_error: |mean of the last <= 50 errors| = (S_last - S_(last-50)) / count over the cumulative sums; S_last
+                // is E.esum (this step's record when the step was valid, the previous one otherwise) and the record 50
+                // before it sits in the slot after the last written one of the 51-slot ring
                 const int end_cnt = (int)min(n_rec, (unsigned)FWG_END_WINDOW);
-                float end_sum[3] = {0.f, 0.f, 0.f};
-                if (pre_reset && ok) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) end_sum[k] = end_prev[k] + err[k];
-                } else {
-                    const int first = ok ? 1 : 0;   // ok: ages 1.. + the register copy; failed step: nothing was stored for it
-                    int p = ok ? A.slot_end : A.slot_end - 1;
-                    p += (p < 0) ? FWG_END_WINDOW : 0;
-                    if (ok) { end_sum[0] = err[0]; end_sum[1] = err[1]; end_sum[2] = err[2]; }
-#pragma unroll
-                    for (int q = 0; q < FWG_END_WINDOW; ++q) {   // unconditional loads, masked sums (see the prework)
-                        int slot = p - q; slot += (slot < 0) ? FWG_END_WINDOW : 0;
-                        const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
-                        const bool in = q >= first && q < end_cnt;
-                        end_sum[0] += in ? r.x : 0.f; end_sum[1] += in ? r.y : 0.f; end_sum[2] += in ? r.z : 0.f;
-                    }
+                float end_sum[3] = {E.esum[0], E.esum[1], E.esum[2]};
+                if (n_rec > (unsigned)FWG_END_WINDOW) {
+                    int slot = ok ? A.slot_end + 1 : A.slot_end;
+                    slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
+                    const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                    end_sum[0] -= r.x; end_sum[1] -= r.y; end_sum[2] -= r.z;
                 }
 #pragma unroll
                 for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
@@ -642,7 +622,15 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 atomicAdd(A.reduce + lane, (unsigned long long)(long long)rintf(lane < 5 ? tot : tot * FWG_ACC_SCALE));
         }
         if (c.auto_reset && done && valid) {
-            if (!pre_reset) reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);   // not foreseen (failure, success): drawn now
+            ResetDraw RD;
+            bool ready = draw_stage_of(E.flags) == FWG_DRAW_READY;
+            if (ready) {   // prepared in the steps after the previous reset; valid for this configuration generation / episode?
+                const float4 tag = draw_tag(A.S, A.N, e, c);
+                ready = f2u(tag.x) == dc.generation && f2u(tag.y) == E.episode + 1u;
+                RD.flags = f2u(tag.z); RD.episode = E.episode + 1u;
+            }
+            if (ready) draw_load_final(c, A.S, A.N, e, RD);
+            else reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);   // episode ended before its successor's draw was complete
             reset_finish<TURB>(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal, RD);
             store_sim<TURB>(c, A.S, A.N, e, E);
             store_gym(c, A.S, A.N, e, E, A.bit_goal, true, true);
@@ -836,7 +824,7 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
     L->goal = o; o += FWG_MAX_STREAK / 8; // goal-window ring: plain word rows, 8 positions x 4 flags per word
     L->act_ring = o; o += window * 4;    // raw actions, one group per slot, slot = global_step % window
     L->cmd_ring = o; o += use_cmd ? window * 4 : 0;
-    L->end_ring = o; o += FWG_END_WINDOW * 4;
+    L->end_ring = o; o += FWG_END_RING * 4;
     if (c.obs_log_rows != 0) {
         if (c.obs_length < 2) { *why = "obs_log_rows needs a lagged (matrix) observation"; return -1; }
         if (c.obs_noise) { *why = "obs_log_rows: observation noise re-draws every row each step, use the dense batch"; return -1; }
@@ -846,6 +834,11 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
     L->lag_depth = c.obs_length > 1 ? (c.obs_log_rows != 0 ? 1 : (c.obs_length - 1) * c.obs_step + 1) : 0;
     L->lag_groups = (c.n_obs + 3) / 4;
     L->lag_ring = o; o += L->lag_depth * L->lag_groups * 4;
+    {   // the next episode's reset draw (fwgym_env.h "draw_stage_step"): 11 groups, + 3 with dynamic target classes
+        bool dynamic = false;
+        for (int k = 0; k < c.n_targets; ++k) dynamic = dynamic || c.target[k].cls >= FWG_TGT_LINEAR;
+        L->draw = o; o += dynamic ? 56 : 44;
+    }
     L->window = window;
     L->rows = o;
     return use_cmd;
@@ -1079,6 +1072,7 @@ int fwg_update_config(fwg_handle* h, const fwg_config* cfg) {
     if (lower_config(*cfg, &d, &dy, &why) != 0) return fail_with(FWG_ERR_INVALID, why);
     if (memcmp(&d.L, &h->h.L, sizeof(fwg_layout)) != 0 || d.obs_dim != h->h.obs_dim)
         return fail_with(FWG_ERR_INVALID, "fwg_update_config must not change the state layout");
+    dy.generation = h->hd.generation + 1u;   // ranges may have changed: prepared reset draws are stale
     h->cfg = *cfg; h->h = d; h->hd = dy;
     h->spec = match_spec(h->h);
     HIP_TRY(hipSetDevice(h->device));
@@ -1089,6 +1083,11 @@ int fwg_update_config(fwg_handle* h, const fwg_config* cfg) {
 
 int fwg_seed(fwg_handle* h, uint64_t seed) {
     if (!h) return fail_with(FWG_ERR_INVALID, "null handle");
+    if (seed != h->seed) {   // prepared reset draws belong to the old streams
+        h->hd.generation += 1u;
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpy(h->d_dyn, &h->hd, sizeof(DynCfg), hipMemcpyHostToDevice));
+    }
     h->seed = seed;
     return FWG_OK;
 }

@@ -26,6 +26,7 @@ struct DynTarget { float low, high, delta, slope_low, slope_high, amp_low, amp_h
 struct DynCfg {
     float init_min[FWG_N_VARS], init_max[FWG_N_VARS];
     DynTarget target[FWG_MAX_TARGETS];
+    unsigned generation;   // bumped whenever what a reset draw depends on changes (ranges, seed): prepared draws are then discarded
 };
 struct DevFactor { int cls, type, src, fclass, shaping, window, has_max, value_is_timesteps; float sign, inv_scaling, max, value; };
 

@@ -158,7 +158,7 @@ __host__ __device__ inline StepSlots make_slots(int obs_step, int obs_log, int o
         s.log_wrap_now = s.qmod_p == 0;
     }
     s.slot_act = slots_pmod(g, window);
-    s.slot_end = slots_pmod(g, FWG_END_WINDOW);
+    s.slot_end = slots_pmod(g, FWG_END_RING);
     s.slot_lag = slots_pmod(g, lag_depth);
     s.bit_goal = slots_pmod(g, streak_req);
     for (int r = 0; r < FWG_MAX_ROWS; ++r) s.lag_slots[r] = slots_pmod(g - (long long)r * obs_step, lag_depth);
@@ -178,7 +178,7 @@ __host__ __device__ inline StepSlots next_slots(int obs_step, int obs_log, int o
         s.log_wrap_now = s.qmod_p == 0;
     }
     s.slot_act = slots_inc(c.slot_act, window);
-    s.slot_end = slots_inc(c.slot_end, FWG_END_WINDOW);
+    s.slot_end = slots_inc(c.slot_end, FWG_END_RING);
     s.slot_lag = slots_inc(c.slot_lag, lag_depth);
     s.bit_goal = slots_inc(c.bit_goal, streak_req);
     for (int r = 0; r < FWG_MAX_ROWS; ++r) s.lag_slots[r] = slots_inc(c.lag_slots[r], lag_depth);
@@ -834,19 +834,16 @@ struct ResetDraw {
     float row_noise[FWG_MAX_ROWS];
 };
 
-template <class TAB>
-__device__ __forceinline__ void reset_sample(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_old,
-                                             unsigned flags_old, TAB& T, ResetDraw& D) {
+// ---- the draw in pieces, so that it can be computed in one go (reset kernel, unforeseen situations) or one piece per env
+// step, off the critical path (draw_stage_step below).  Identical arithmetic either way.
+// (1) sampled initial values of the variables [4 BLK0, 4 (BLK0 + NBLK)): given values or U(init_min, init_max)
+template <int BLK0, int NBLK>
+__device__ __forceinline__ void draw_state_values(const DynCfg& dc, const KArgs& A, long e, unsigned episode_new,
+                                                  float (&v0)[FWG_N_RESET_VARS + 3]) {
     const unsigned env_id = (unsigned)(A.env_base + e);
-    Env R;   // scratch: only the fields sample_targets / fill_vars touch
-    R.episode = episode_old + 1u;
-    R.steps = 0u;
-    R.flags = flags_old & FWG_FLAG_GOAL_ACHIEVED;  // prev_shaping := None, resample counter := 0; goal_achieved is sticky
-    // ---- initial simulator state: given values or U(init_min, init_max)
-    float v0[FWG_N_RESET_VARS];
 #pragma unroll
-    for (int blk = 0; blk < 6; ++blk) {
-        const u4 b = philox4x32(env_id, R.episode, (unsigned)blk, FWG_STREAM_RESET_STATE, A.seed_lo, A.seed_hi);
+    for (int blk = BLK0; blk < BLK0 + NBLK; ++blk) {
+        const u4 b = philox4x32(env_id, episode_new, (unsigned)blk, FWG_STREAM_RESET_STATE, A.seed_lo, A.seed_hi);
         const unsigned bits[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -861,6 +858,15 @@ __device__ __forceinline__ void reset_sample(const DevCfg& c, const DynCfg& dc, 
             }
         }
     }
+}
+// (2) state vector, derived angles and the sampled targets from the initial values
+template <class TAB>
+__device__ __forceinline__ void draw_state_and_targets(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_new,
+                                                       const float (&v0)[FWG_N_RESET_VARS + 3], TAB& T, ResetDraw& D) {
+    Env R;   // scratch: only the fields sample_targets / fill_vars touch
+    R.episode = episode_new;
+    R.steps = 0u;
+    R.flags = 0u;   // prev_shaping := None, resample counter := 0 (the sticky goal bit is merged by reset_finish)
     {
         float sr, cr, sp, cp, sy, cy;
         sincosf(0.5f * v0[FWG_V_ROLL], &sr, &cr);
@@ -883,7 +889,6 @@ __device__ __forceinline__ void reset_sample(const DevCfg& c, const DynCfg& dc, 
     const float gust0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     R.d = derive<false>(R.y, R.wind, gust0);
     fill_vars(R, T);
-    // ---- targets
     sample_targets(c, dc, A, e, R, T, A.init_target);
 #pragma unroll
     for (int i = 0; i < NY; ++i) D.y[i] = R.y[i];
@@ -897,16 +902,125 @@ __device__ __forceinline__ void reset_sample(const DevCfg& c, const DynCfg& dc, 
         for (int i = 0; i < 4; ++i) D.tprop[k][i] = c.any_dynamic_target ? R.tprop[k][i] : 0.f;
     }
     D.flags = R.flags; D.episode = R.episode;
-    // per-row initial noise of the lagged rows (fixed_wing.py:792-795,831-832)
+}
+// (3) per-row initial noise of the lagged rows (fixed_wing.py:792-795,831-832)
+__device__ __forceinline__ void draw_row_noise(const DevCfg& c, const KArgs& A, long e, unsigned episode_new, ResetDraw& D) {
+    const unsigned env_id = (unsigned)(A.env_base + e);
 #pragma unroll
     for (int r = 0; r < FWG_MAX_ROWS; ++r) {
         D.row_noise[r] = 0.f;
         if (c.obs_length > 1 && r < c.obs_length) {
-            const u4 b = philox4x32(env_id, 0u, R.episode, FWG_STREAM_INIT_NOISE + 256u * (r >> 2), A.seed_lo, A.seed_hi);
+            const u4 b = philox4x32(env_id, 0u, episode_new, FWG_STREAM_INIT_NOISE + 256u * (r >> 2), A.seed_lo, A.seed_hi);
             const unsigned bits = (r & 3) == 0 ? b.x : ((r & 3) == 1 ? b.y : ((r & 3) == 2 ? b.z : b.w));
             D.row_noise[r] = (2.f * u01(bits) - 1.f) * c.dt;
         }
     }
+}
+
+template <class TAB>
+__device__ __forceinline__ void reset_sample(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_old,
+                                             unsigned flags_old, TAB& T, ResetDraw& D) {
+    (void)flags_old;
+    float v0[FWG_N_RESET_VARS + 3];
+    draw_state_values<0, 6>(dc, A, e, episode_old + 1u, v0);
+    draw_state_and_targets(c, dc, A, e, episode_old + 1u, v0, T, D);
+    draw_row_noise(c, A, e, episode_old + 1u, D);
+}
+
+// ---- The NEXT episode's draw, prepared ahead of time.  After every reset the step kernel computes the draw of the episode
+// that will follow, one piece per env step in the gym wave's idle time before the barrier (4 steps), into a cold arena
+// section (L.draw, 11 groups + 3 with dynamic targets); when the episode ends -- time limit, failure or success alike --
+// reset_finish only has to load it.  Stage (flags bits 4..6): 0 nothing yet | 1 values 0..11 | 2 values 0..20 | 3 state,
+// angles, targets | 4 complete.  Every piece carries the configuration generation (DynCfg::generation, bumped by
+// fwg_update_config / fwg_seed): a draw sampled from other ranges or another seed is discarded.
+// Final layout (groups): 0-3 y[0..15] | 4 wind, - | 5 roll pitch yaw Va | 6 alpha beta tgt0 tgt1 | 7 tgt2 - - - |
+// 8-9 row noise | 10 generation, episode, flags, - | 11-13 target properties.  Stages 1-2 keep the raw values in groups 0-5.
+#define FWG_DRAW_STAGE_SHIFT 4
+#define FWG_DRAW_STAGE_MASK (7u << FWG_DRAW_STAGE_SHIFT)
+#define FWG_DRAW_READY 4u
+__device__ __forceinline__ unsigned draw_stage_of(unsigned flags) { return (flags & FWG_DRAW_STAGE_MASK) >> FWG_DRAW_STAGE_SHIFT; }
+__device__ __forceinline__ void draw_store_final(const DevCfg& c, float* __restrict__ S, long N, long e, const ResetDraw& D, bool with_noise) {
+    const int g0 = c.L.draw >> 2;
+    if (!with_noise) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) GROUP(S, N, g0 + g, e) = make_float4(D.y[4 * g], D.y[4 * g + 1], D.y[4 * g + 2], D.y[4 * g + 3]);
+        GROUP(S, N, g0 + 4, e) = make_float4(D.wind[0], D.wind[1], D.wind[2], 0.f);
+        GROUP(S, N, g0 + 5, e) = make_float4(D.d.roll, D.d.pitch, D.d.yaw, D.d.Va);
+        GROUP(S, N, g0 + 6, e) = make_float4(D.d.alpha, D.d.beta, D.tgt[0], D.tgt[1]);
+        GROUP(S, N, g0 + 7, e) = make_float4(D.tgt[2], 0.f, 0.f, 0.f);
+        if (c.any_dynamic_target) {
+#pragma unroll
+            for (int k = 0; k < FWG_MAX_TARGETS; ++k)
+                GROUP(S, N, g0 + 11 + k, e) = make_float4(D.tprop[k][0], D.tprop[k][1], D.tprop[k][2], D.tprop[k][3]);
+        }
+    } else {
+        GROUP(S, N, g0 + 8, e) = make_float4(D.row_noise[0], D.row_noise[1], D.row_noise[2], D.row_noise[3]);
+        GROUP(S, N, g0 + 9, e) = make_float4(D.row_noise[4], D.row_noise[5], D.row_noise[6], D.row_noise[7]);
+    }
+}
+__device__ __forceinline__ void draw_load_final(const DevCfg& c, const float* __restrict__ S, long N, long e, ResetDraw& D) {
+    const int g0 = c.L.draw >> 2;
+    float4 q[10];
+#pragma unroll
+    for (int g = 0; g < 10; ++g) q[g] = CGROUP(S, N, g0 + g, e);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { D.y[4 * g] = q[g].x; D.y[4 * g + 1] = q[g].y; D.y[4 * g + 2] = q[g].z; D.y[4 * g + 3] = q[g].w; }
+    D.y[16] = 0.f; D.y[17] = 0.f;
+    D.wind[0] = q[4].x; D.wind[1] = q[4].y; D.wind[2] = q[4].z;
+    D.d.roll = q[5].x; D.d.pitch = q[5].y; D.d.yaw = q[5].z; D.d.Va = q[5].w;
+    D.d.alpha = q[6].x; D.d.beta = q[6].y; D.tgt[0] = q[6].z; D.tgt[1] = q[6].w; D.tgt[2] = q[7].x;
+    D.row_noise[0] = q[8].x; D.row_noise[1] = q[8].y; D.row_noise[2] = q[8].z; D.row_noise[3] = q[8].w;
+    D.row_noise[4] = q[9].x; D.row_noise[5] = q[9].y; D.row_noise[6] = q[9].z; D.row_noise[7] = q[9].w;
+#pragma unroll
+    for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c.any_dynamic_target) t = CGROUP(S, N, g0 + 11 + k, e);
+        D.tprop[k][0] = t.x; D.tprop[k][1] = t.y; D.tprop[k][2] = t.z; D.tprop[k][3] = t.w;
+    }
+}
+// generation | episode the draw is for | flags after sample_targets
+__device__ __forceinline__ float4 draw_tag(const float* __restrict__ S, long N, long e, const DevCfg& c) { return CGROUP(S, N, (c.L.draw >> 2) + 10, e); }
+// one piece of the next episode's draw (called for lanes whose stage is below FWG_DRAW_READY); returns the new stage
+template <class TAB>
+__device__ __forceinline__ unsigned draw_stage_step(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_now,
+                                                    unsigned stage, TAB& T) {
+    const int g0 = c.L.draw >> 2;
+    const unsigned episode_new = episode_now + 1u;
+    if (stage != 0u) {   // pieces of another configuration generation / seed / episode are discarded
+        const float4 tag = draw_tag(A.S, A.N, e, c);
+        if (f2u(tag.x) != dc.generation || f2u(tag.y) != episode_new) stage = 0u;
+    }
+    float v0[FWG_N_RESET_VARS + 3];
+    if (stage == 0u) {
+        draw_state_values<0, 3>(dc, A, e, episode_new, v0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) GROUP(A.S, A.N, g0 + g, e) = make_float4(v0[4 * g], v0[4 * g + 1], v0[4 * g + 2], v0[4 * g + 3]);
+        GROUP(A.S, A.N, g0 + 10, e) = make_float4(u2f(dc.generation), u2f(episode_new), 0.f, 0.f);
+        return 1u;
+    }
+    if (stage == 1u) {
+        draw_state_values<3, 3>(dc, A, e, episode_new, v0);
+        GROUP(A.S, A.N, g0 + 3, e) = make_float4(v0[12], v0[13], v0[14], v0[15]);
+        GROUP(A.S, A.N, g0 + 4, e) = make_float4(v0[16], v0[17], v0[18], v0[19]);
+        GROUP(A.S, A.N, g0 + 5, e) = make_float4(v0[20], 0.f, 0.f, 0.f);
+        return 2u;
+    }
+    ResetDraw D;
+    if (stage == 2u) {
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const float4 q = CGROUP(A.S, A.N, g0 + g, e);
+            v0[4 * g] = q.x;
+            if (4 * g + 1 < FWG_N_RESET_VARS + 3) { v0[4 * g + 1] = q.y; v0[4 * g + 2] = q.z; v0[4 * g + 3] = q.w; }
+        }
+        draw_state_and_targets(c, dc, A, e, episode_new, v0, T, D);
+        draw_store_final(c, A.S, A.N, e, D, false);
+        GROUP(A.S, A.N, g0 + 10, e) = make_float4(u2f(dc.generation), u2f(episode_new), u2f(D.flags), 0.f);
+        return 3u;
+    }
+    draw_row_noise(c, A, e, episode_new, D);
+    draw_store_final(c, A.S, A.N, e, D, true);
+    return FWG_DRAW_READY;
 }
 
 template <bool TURB, class TAB, class OB>

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 13
+#define FWG_ABI_VERSION 14
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -38,6 +38,7 @@ extern "C" {
 #define FWG_MAX_WINDOW 8     /* action window_size (fixed_wing.py:689,822) */
 #define FWG_MAX_STREAK 128   /* target.success_streak_req (fixed_wing.py:377) */
 #define FWG_END_WINDOW 50    /* end_error window (fixed_wing.py:1107) */
+#define FWG_END_RING (FWG_END_WINDOW + 1)   /* slots of the cumulative-error ring: the window and the record just before it */
 #define FWG_N_DRYDEN 8       /* Dryden filter states (joint realisation u | v,r | w,q | p) */
 #define FWG_N_METRICS 28     /* rows of the metrics block written by fwg_step, see fwg_metric_row */
 #define FWG_N_REDUCE 16      /* floats accumulated for fwg_reduce_success */
@@ -197,11 +198,12 @@ typedef struct fwg_layout {
     int32_t goal;        /* 16 plain word rows [word][N] (NOT grouped): goal-window ring, 8 positions x 4 flags per word */
     int32_t act_ring;    /* window*4: raw actions (a0 a1 a2 pad) per slot, slot = global_step % window */
     int32_t cmd_ring;    /* window*4: constrained commands (only when observations need them) */
-    int32_t end_ring;    /* 50*4: errors (e0 e1 e2 pad) per slot, slot = global_step % 50 */
+    int32_t end_ring;    /* 51*4: cumulative error sums of the episode (S0 S1 S2 pad) per slot, slot = global_step % 51 */
     int32_t lag_ring;    /* lag_depth*lag_groups*4: normalised observation records, slot = global_step % lag_depth */
     int32_t window;      /* action window depth */
     int32_t lag_depth;   /* (length-1)*step+1 */
     int32_t lag_groups;  /* ceil(n_obs/4) */
+    int32_t draw;        /* 44 (+12 with linear/sinusoidal targets): the NEXT episode's reset draw, prepared ahead of time (cold) */
 } fwg_layout;
 
 /* rows of the metrics block (float32 [FWG_N_METRICS][N], valid where done) -- get_metric, fixed_wing.py:1095-1162 */

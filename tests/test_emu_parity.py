@@ -60,3 +60,51 @@ def test_tail_block_and_masked_reset(emu_lib):
     np.testing.assert_allclose(obs2[69, 6:9], [0.3, 0.0, 23.0], atol=1e-6)
     assert not np.array_equal(obs0[3], obs2[3])
     vec.close()
+
+
+@pytest.mark.parametrize("kind,ckw", [("default", {"steps_max": 3}), ("cnn", {"steps_max": 2, "observation": {"step": 2}}),
+                                      ("default", {"steps_max": 6})])
+def test_episode_ends_before_the_next_draw_is_prepared(emu_lib, kind, ckw):
+    """The next episode's reset draw is prepared one piece per step over the 4 steps after a reset; an episode shorter
+    than that falls back to drawing on the spot.  Both routes must give the oracle's sampled states and targets."""
+    cfg = configs.reference_like(kind)
+    n, steps = 5, 40
+    vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, seed=7, as_numpy=True, _backend=HostBackend(), _lib_path=emu_lib)
+    orc = parity.make_oracles(cfg, n, 7, config_kw=ckw)
+    acts = _actions(3, steps, n)
+    res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3)
+    assert res["episodes"] >= n * (steps // ckw["steps_max"] - 1)
+    vec.close()
+
+
+def test_prepared_draw_is_discarded_when_ranges_or_seed_change(emu_lib):
+    """set_curriculum_level (new init/target ranges) and seed() between two resets: the draw prepared under the old
+    configuration must not be used -- the reference samples at reset time with the ranges of that moment."""
+    cfg = configs.default()
+    ckw = {"steps_max": 12}
+    n = 6
+    vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, seed=3, as_numpy=True, _backend=HostBackend(), _lib_path=emu_lib)
+    orc = parity.make_oracles(cfg, n, 3, config_kw=ckw)
+    obs = vec.reset()
+    want = np.stack([o.reset() for o in orc])
+    np.testing.assert_allclose(obs, want, atol=2e-5)
+    acts = _actions(9, 60, n)
+    for t in range(60):
+        if t == 8:     # draw for the next episode is complete (4 steps after the reset): now change the ranges
+            vec.set_curriculum_level(0.3)
+            for o in orc:
+                o.set_curriculum_level(0.3)
+        if t == 30:    # ... and later the seed
+            vec.seed(99)
+            for i, o in enumerate(orc):
+                o.seed(99)
+                o.rng = parity.PhiloxStream(99, i)
+                o.rng.begin_episode(o.simulator.episode)
+        obs, rew, done, infos = vec.step(acts[t])
+        for i, o in enumerate(orc):
+            ob, r, d, info = o.step(acts[t][i].astype(np.float64))
+            assert bool(done[i]) == d
+            if d:
+                ob = o.reset()
+            np.testing.assert_allclose(obs[i], ob, rtol=4e-3, atol=4e-3, err_msg="step {} env {}".format(t, i))
+    vec.close()

@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "fixed-wing-gym_amd")
 OUT = os.path.join(PKG, "gym_fixed_wing", "_abl")
-LIB = os.path.join(OUT, "libfwgym_timeline.so")
+LIB = os.path.join(OUT, os.environ.get("TL_LIB", "libfwgym_timeline.so"))
 # (table of phase names kept for reference; the run prints the stamps of each wave relative to the block's start)
 NAMES = ["entry->loads issued", "integration (incl. wait for state)", "store sim rows", "wait streamed windows (vmcnt0)",
          "gym logic", "store gym rows", "observation build", "episode-end branch", "outputs issued", "stores acknowledged"]
