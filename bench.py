@@ -219,14 +219,16 @@ def main():
                           auto_reset=True, derived_views=False, obs_log_rows=log_rows, **kw)
     vec.reset()
     def stagger_ages(parts):
-        """Resets 1/parts of the envs every steps_max/parts steps (parts = steps_max: ages uniform over [0, steps_max))."""
+        """Resets 1/parts of the envs (a random subset: episode ends of a training run are not aligned with the env index)
+        every steps_max/parts steps (parts = steps_max: ages uniform over [0, steps_max))."""
         import numpy as _np
         gen0 = torch.Generator(device=dev)
         gen0.manual_seed(99 + rank)
         acts0 = [torch.rand((n_envs, 3), device=dev, generator=gen0) * 2 - 1 for _ in range(4)]
         per = max(1, int(vec.cfg["steps_max"]) // parts)
+        perm = _np.random.RandomState(4321 + rank).permutation(n_envs)
         for k in range(parts):
-            vec.reset(indices=_np.arange(k, n_envs, parts))
+            vec.reset(indices=_np.sort(perm[k::parts]))
             for t in range(per):
                 vec.step_device(acts0[t % 4], want_obs=False)
         torch.cuda.synchronize(dev)
@@ -371,8 +373,8 @@ def main():
         ts = (time.perf_counter() - ts0) / (reps * chunk)
         steady = {"ms_per_step": ts * 1e3, "value": n_envs / ts, "unit": "env-steps/s",
                   "roofline_frac": ALG_BYTES[args.workload] * n_envs / ts / 1e9 / HBM_PEAK_GBS, "steps": reps * chunk,
-                  "note": "episode ages uniform over [0, steps_max) (1/steps_max of the envs reset at every step of an untimed "
-                          "steps_max-step run): about {} episode ends per step, each in a different wave".format(
+                  "note": "episode ages uniform over [0, steps_max) (a random 1/steps_max of the envs reset at every step of an "
+                          "untimed steps_max-step run): about {} episode ends per step, scattered over the waves".format(
                               round(n_envs / max(1, int(vec.cfg["steps_max"]))))}
 
     out = None

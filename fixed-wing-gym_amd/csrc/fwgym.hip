@@ -253,7 +253,16 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     float fval_action[FWG_MAX_FACTORS];   // values of the reward factors of class "action" (fixed_wing.py:686-700)
     float obs_action[FWG_MAX_OBS];        // "action" entries of the newest observation row (fixed_wing.py:813-828)
     float tgt_next[3] = {0.f, 0.f, 0.f};  // targets propagated by one step, valid unless the target is resampled
-    // (the next episode's reset draw is prepared here too, piece by piece, in the steps after each reset)
+    // (the next episode's reset draw is prepared here too, piece by piece, in the steps after each reset).  An episode that
+    // ends at steps_max is known before the integration: everything its episode-end branch reads from memory -- the
+    // prepared draw, the end-error record, the lagged rows of the terminal observation -- is requested here, so that the
+    // round trips run while the physics wave integrates
+    bool pre_end = false, pre_draw = false;
+    float4 pre_tag = make_float4(0.f, 0.f, 0.f, 0.f), pre_old = make_float4(0.f, 0.f, 0.f, 0.f);
+    ResetDraw RD;
+    // lanes in the first steps of an episode: the padding rows of their observation, up to the "action" entries
+    bool pre_early = false;
+    float early_noise[FWG_MAX_ROWS] = {};
     auto gym_prework = [&]() {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {   // the own action enters the LDS copy of the windows
@@ -282,6 +291,13 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
         }
         E.steps += 1u;
+        // lanes in the first steps of an episode (row-log mode): their record 0 is requested now, the padding rows follow at
+        // the end of this block
+        const bool early_now = c.obs_log > 0 && c.obs_length > 1 && valid && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
+        float rec0[FWG_MAX_OBS];
+        if (__ballot(early_now) != 0ull) {
+            if (early_now) early_rows_request(c, A, e, rec0);
+        }
         E.sft += 1u;
         if (c.steps_max > 0 && E.steps >= (unsigned)c.steps_max) { done = true; term = FWG_TERM_STEPS; }
 #pragma unroll
@@ -331,7 +347,23 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             // kind of piece per wave and step (the least advanced lanes first): a wave whose lanes sit at different stages
             // would otherwise run all the pieces back to back and outlast the integration it hides behind
             const unsigned stage = draw_stage_of(E.flags);
-            const bool work = valid && stage < FWG_DRAW_READY;
+            if (c.steps_max > 0 && __ballot(valid && done) != 0ull) {   // done: E.steps reached steps_max
+                if (valid && done) {
+                    pre_end = true;
+                    if (stage == FWG_DRAW_READY) {
+                        pre_draw = true;
+                        pre_tag = draw_tag(A.S, A.N, e, c);
+                        draw_load_final(c, A.S, A.N, e, RD);   // used only if the tag checks out
+                    }
+                    if (c.metrics) {
+                        int slot = A.slot_end + 1; slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
+                        pre_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                    }
+                    if (c.obs_log > 0) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
+                }
+            }
+            // (not in the first steps of an episode, whose lanes have their padding rows to compute in this same interval)
+            const bool work = valid && stage < FWG_DRAW_READY && !early_now;
             unsigned long long m = 0ull;
             unsigned pick = FWG_DRAW_READY;
 #pragma unroll
@@ -349,13 +381,17 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 }
             }
         }
+        if (__ballot(early_now) != 0ull) {
+            if (early_now) { pre_early = true; early_rows_pre(c, A, e, E, ob, rec0, early_noise); }
+        }
     };
     if (SPLIT && GYM) {
         FWG_DMA_DRAIN();   // this wave's own streamed windows have landed (no other wave reads them)
         FWG_WAVE_SYNC();
         gym_prework();
+        FWG_TL(A, 2);
     }
-    if (SPLIT) __syncthreads();          // barrier A
+    if (SPLIT) FWG_BLOCK_SYNC_LDS();     // barrier A
     if (SPLIT && PHYS && TURB) {
         const float4 q = *reinterpret_cast<const float4*>(noise);
         n[0] = q.x; n[1] = q.y; n[2] = q.z; n[3] = q.w;
@@ -378,7 +414,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     }
     if (SPLIT && PHYS) {   // barrier B: the simulator rows are written before the gym wave may overwrite them (auto-reset)
         FWG_DMA_DRAIN();   // s_waitcnt vmcnt(0): covers stores as well
-        __syncthreads();
+        FWG_BLOCK_SYNC_LDS();
         return;
     }
     // everything streamed HBM -> LDS at kernel start is needed from here on; the integration above hid its latency
@@ -527,15 +563,18 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     if (c.obs_log == 0) load_lag_rows(c, lds + M.lag + lane * 4, ob);
 #endif
     build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid && c.obs_log == 0, A.slot_act, obs_action);
+    FWG_TL(A, 14);
     // row-log mode: the lagged rows stay where they are; only lanes that need the COMPLETE record in registers (episode
     // end: terminal observation) read them back, and only early-episode / failed lanes compute rows of their own
     const bool early = c.obs_length > 1 && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
     const unsigned log_pad_t = E.steps;   // rows with lag >= this are padding (valid for lanes that do not finish)
     const long long log_win = A.log_win;   // wave-uniform
-    if (c.obs_log > 0 && __ballot((done || !ok) && valid) != 0ull) {
-        if ((done || !ok) && valid) log_load_rows(c, A.obs, A.N, e, log_win, ob);
+    const bool reload = c.obs_log > 0 && (done || !ok) && valid && !pre_end;   // (overwrites what early_rows_pre prepared)
+    if (__ballot(reload) != 0ull) {
+        if (reload) log_load_rows(c, A.obs, A.N, e, log_win, ob);
     }
-    if (c.obs_length > 1 && (!ok || early)) fix_lagged_rows(c, A, e, E, T, ob, ok);
+    if (c.obs_length > 1 && (!ok || early)) fix_lagged_rows(c, A, e, E, T, ob, ok, pre_early && !reload, early_noise);
+    FWG_TL(A, 15);
     if (c.obs_noise) add_obs_noise(c, A, e, E, ob);
 
     FWG_TL(A, 7);
@@ -544,7 +583,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // waves in which no episode ends have their final observation records here: the moments for an attached rollout head
     // go out before the remaining stores, whose issue then hides the round trip of the atomics
     if (A.acc != nullptr && done_mask == 0ull) step_moments(c, A, ob, reward, done, valid, lane, e);
-    if (SPLIT) __syncthreads();   // barrier B (the physics wave arrived long ago: its rows are in memory)
+    if (SPLIT) FWG_BLOCK_SYNC_LDS();   // barrier B (the physics wave arrived long ago: its rows are in memory)
     if (done_mask != 0ull) {
         float red[FWG_N_REDUCE];
 #pragma unroll
@@ -561,9 +600,12 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 const int end_cnt = (int)min(n_rec, (unsigned)FWG_END_WINDOW);
                 float end_sum[3] = {E.esum[0], E.esum[1], E.esum[2]};
                 if (n_rec > (unsigned)FWG_END_WINDOW) {
-                    int slot = ok ? A.slot_end + 1 : A.slot_end;
-                    slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
-                    const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                    float4 r = pre_old;   // requested before the integration for foreseen ends
+                    if (!(pre_end && ok)) {
+                        int slot = ok ? A.slot_end + 1 : A.slot_end;
+                        slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
+                        r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                    }
                     end_sum[0] -= r.x; end_sum[1] -= r.y; end_sum[2] -= r.z;
                 }
 #pragma unroll
@@ -572,12 +614,12 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                     const unsigned lo = E.rise[k] & 0xFFFFu, hi = E.rise[k] >> 16;
                     mt[FWG_M_RISE_TIME + k] = (lo == 0xFFFFu || hi == 0xFFFFu) ? NAN : (float)lo - (float)hi;
                     const float ext = E.e0[k] > 0.f ? E.emin[k] : E.emax[k];
-                    mt[FWG_M_OVERSHOOT + k] = (fsignf(ext) == fsignf(E.e0[k])) ? NAN : fabsf(ext / E.e0[k]);
+                    mt[FWG_M_OVERSHOOT + k] = (fsignf(ext) == fsignf(E.e0[k])) ? NAN : fabsf(fast_div(ext, E.e0[k]));
                     mt[FWG_M_TOTAL_ERROR + k] = E.eabs[k];
-                    mt[FWG_M_AVG_ERROR + k] = fabsf(E.e0[k]) >= 0.01f ? fabsf((E.esum[k] / (float)n_rec) / E.e0[k]) : NAN;
-                    mt[FWG_M_END_ERROR + k] = fabsf(end_sum[k] / (float)end_cnt);
+                    mt[FWG_M_AVG_ERROR + k] = fabsf(E.e0[k]) >= 0.01f ? fabsf(fast_div(E.esum[k], (float)n_rec * E.e0[k])) : NAN;
+                    mt[FWG_M_END_ERROR + k] = fabsf(fast_div(end_sum[k], (float)end_cnt));
                 }
-                mt[FWG_M_CONTROL_VARIATION] = E.sdcmd / (3.f * c.dt * (float)(E.steps - 1u));
+                mt[FWG_M_CONTROL_VARIATION] = fast_div(E.sdcmd, 3.f * c.dt * (float)(E.steps - 1u));
                 if (c.goal_enabled) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -586,7 +628,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                             const unsigned st = pack16_get(E.settle, r);
                             mt[FWG_M_SETTLING_TIME + r] = st == 0xFFFFu ? NAN : (float)st;
                             mt[FWG_M_SUCCESS + r] = st == 0xFFFFu ? 0.f : 1.f;
-                            mt[FWG_M_SUCCESS_TIME_FRAC + r] = (float)pack16_get(E.gcnt, r) / (float)n_rec;
+                            mt[FWG_M_SUCCESS_TIME_FRAC + r] = fast_div((float)pack16_get(E.gcnt, r), (float)n_rec);
                         }
                     }
                 }
@@ -610,7 +652,20 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 red[0] = 1.f;
             }
         }
-        if (A.term_obs != nullptr) write_obs<ROLE>(c, A.term_obs, env0, A.N, ob, lds + M.stage, lane, done_mask);
+        FWG_TL(A, 11);
+        if (A.term_obs != nullptr) {   // a few ending lanes: each stores its own record; many (synchronised episodes): staged, coalesced
+            if ((c.obs_dim & 3) == 0 && __popcll(done_mask) <= 8) {
+                if (done && valid) {
+                    float4* o4 = reinterpret_cast<float4*>(A.term_obs + e * c.obs_dim);
+#pragma unroll
+                    for (int q = 0; q < (FWG_MAX_OBS * FWG_MAX_ROWS) / 4; ++q)
+                        if (q * 4 < c.obs_dim) o4[q] = make_float4(ob.get(4 * q), ob.get(4 * q + 1), ob.get(4 * q + 2), ob.get(4 * q + 3));
+                }
+            } else {
+                write_obs<ROLE>(c, A.term_obs, env0, A.N, ob, lds + M.stage, lane, done_mask);
+            }
+        }
+        FWG_TL(A, 12);
         // per-wave reduction by shuffles, one atomic per value per wave (the per-GPU part of the success reduction of
         // examples/train_rl_controller.py:51-66,80-85)
         {
@@ -621,17 +676,17 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             if (lane < FWG_N_REDUCE && tot != 0.f)   // counts (0..4) as integers, the rest in 2^-20 fixed point: exact, order-free
                 atomicAdd(A.reduce + lane, (unsigned long long)(long long)rintf(lane < 5 ? tot : tot * FWG_ACC_SCALE));
         }
+        FWG_TL(A, 13);
         if (c.auto_reset && done && valid) {
-            ResetDraw RD;
             bool ready = draw_stage_of(E.flags) == FWG_DRAW_READY;
             if (ready) {   // prepared in the steps after the previous reset; valid for this configuration generation / episode?
-                const float4 tag = draw_tag(A.S, A.N, e, c);
+                const float4 tag = pre_draw ? pre_tag : draw_tag(A.S, A.N, e, c);
                 ready = f2u(tag.x) == dc.generation && f2u(tag.y) == E.episode + 1u;
                 RD.flags = f2u(tag.z); RD.episode = E.episode + 1u;
             }
-            if (ready) draw_load_final(c, A.S, A.N, e, RD);
+            if (ready) { if (!pre_draw) draw_load_final(c, A.S, A.N, e, RD); }
             else reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);   // episode ended before its successor's draw was complete
-            reset_finish<TURB>(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal, RD);
+            reset_finish<TURB>(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal, RD, true);
             store_sim<TURB>(c, A.S, A.N, e, E);
             store_gym(c, A.S, A.N, e, E, A.bit_goal, true, true);
         }

@@ -82,6 +82,23 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 __device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fclampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 __device__ __forceinline__ float fsignf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+// keeps a product from being fused into a later addition (-ffp-contract=fast works across statements): values that two
+// code paths must reproduce bit for bit are rounded here
+__device__ __forceinline__ float rounded(float x) {
+#ifndef FWG_EMU
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+// a / b by v_rcp_f32 (1 ulp) for the episodic metrics: the IEEE division sequence is ~10x the instructions, in a branch whose
+// length is the step time of the whole launch whenever any episode ends
+__device__ __forceinline__ float fast_div(float a, float b) {
+#ifdef FWG_EMU
+    return a / b;
+#else
+    return a * __builtin_amdgcn_rcpf(b);
+#endif
+}
 
 // atan2 for the kinematics (angle of attack, sideslip, Euler angles): odd minimax polynomial of degree 17 on [0,1]
 // (max abs error 1.1e-7 in fp32, fitted offline) + octant folding; ~20 VALU instructions instead of the library's ~45.
@@ -170,6 +187,15 @@ __device__ __forceinline__ void dma_group_once(const float4* src_lane_ptr, float
 // the compiler does not order LDS reads behind an in-flight global_load_lds: drain the vector-memory counter by hand
 #ifndef FWG_DMA_DRAIN
 #define FWG_DMA_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+// workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release + acquire around the
+// s_barrier, which on gfx950 drains every global load and store in flight (s_waitcnt vmcnt(0)); the two waves of k_step2
+// exchange data through LDS alone, and requests issued before the barrier (prefetches for the episode-end branch, the
+// bookkeeping stores) are meant to stay in flight across it
+#ifdef FWG_EMU
+#define FWG_BLOCK_SYNC_LDS() __syncthreads()
+#else
+#define FWG_BLOCK_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 // ordering of LDS traffic between the lanes of ONE wave (k_step2: the other wave of the workgroup is not involved)
 #ifdef FWG_EMU

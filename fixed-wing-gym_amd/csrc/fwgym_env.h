@@ -707,20 +707,72 @@ __device__ __forceinline__ float lag_entry(const DevCfg& c, const KArgs& A, long
 //    a fresh U(-1,1)*dt per row, with "action" entries replaced by the CURRENT actuator value;
 //  * after a failed simulator step the state/target histories are one record shorter than the action history, so
 //    the non-action entries come from one slot further back.
+// The step kernel splits the first case (row-log mode): early_rows_pre computes everything that does not need this step's
+// state -- the initial record, the per-row noise -- before the integration has finished; fix_lagged_rows(pre = true) then
+// only fills in the "action" entries.
+// the per-row uniform bits of the "initial record" noise: one Philox block per four rows (stream FWG_STREAM_INIT_NOISE + 256 q,
+// component r & 3), each block computed once
+__device__ __forceinline__ void init_noise_bits(const DevCfg& c, unsigned env_id, unsigned c1, unsigned c2, unsigned seed_lo,
+                                                unsigned seed_hi, unsigned (&bits)[FWG_MAX_ROWS]) {
+#pragma unroll
+    for (int q = 0; q < (FWG_MAX_ROWS + 3) / 4; ++q) {
+        u4 b = u4{0u, 0u, 0u, 0u};
+        if (q * 4 < c.obs_length) b = philox4x32(env_id, c1, c2, FWG_STREAM_INIT_NOISE + 256u * q, seed_lo, seed_hi);
+        if (4 * q < FWG_MAX_ROWS) bits[4 * q] = b.x;
+        if (4 * q + 1 < FWG_MAX_ROWS) bits[4 * q + 1] = b.y;
+        if (4 * q + 2 < FWG_MAX_ROWS) bits[4 * q + 2] = b.z;
+        if (4 * q + 3 < FWG_MAX_ROWS) bits[4 * q + 3] = b.w;
+    }
+}
+__device__ __forceinline__ void early_rows_request(const DevCfg& c, const KArgs& A, long e, float (&rec)[FWG_MAX_OBS]) {
+#pragma unroll
+    for (int g = 0; g < FWG_MAX_OBS / 4; ++g) {   // the episode's record 0: slot 0 of the one-slot ring
+        if (g < c.L.lag_groups) {
+            const float4 q = CGROUP(A.S, A.N, (c.L.lag_ring >> 2) + g, e);
+            rec[4 * g] = q.x; rec[4 * g + 1] = q.y; rec[4 * g + 2] = q.z; rec[4 * g + 3] = q.w;
+        }
+    }
+}
+template <class OB>
+__device__ __forceinline__ void early_rows_pre(const DevCfg& c, const KArgs& A, long e, const Env& E, OB& ob, const float (&rec)[FWG_MAX_OBS],
+                                               float (&row_noise)[FWG_MAX_ROWS]) {
+    const int t = (int)E.steps;
+    unsigned bits[FWG_MAX_ROWS];
+    init_noise_bits(c, (unsigned)(A.env_base + e), E.steps, E.episode, A.seed_lo, A.seed_hi, bits);
+#pragma unroll
+    for (int r = 1; r < FWG_MAX_ROWS; ++r) {
+        row_noise[r] = 0.f;
+        if (r >= c.obs_length || r * c.obs_step < t) continue;
+        const float noise = rounded((2.f * u01(bits[r]) - 1.f) * c.dt);
+        row_noise[r] = noise;
+#pragma unroll
+        for (int j = 0; j < FWG_MAX_OBS; ++j)
+            if (j < c.n_obs && c.obs[j].type != FWG_OBS_ACTION)
+                ob.put(r * c.n_obs + j, rec[j] + noise * (c.obs[j].norm ? c.obs[j].inv_var : 1.f));
+    }
+}
 template <class TAB, class OB>
 __device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A, long e, const Env& E, const TAB& T, OB& ob,
-                                                bool ok) {
+                                                bool ok, bool pre, const float (&pre_noise)[FWG_MAX_ROWS]) {
     const int depth = c.L.lag_depth;
     const int t = (int)E.steps;
-    const unsigned env_id = (unsigned)(A.env_base + e);
+    unsigned bits[FWG_MAX_ROWS] = {};
+    if (!pre && t <= (c.obs_length - 1) * c.obs_step) init_noise_bits(c, (unsigned)(A.env_base + e), E.steps, E.episode, A.seed_lo, A.seed_hi, bits);
 #pragma unroll
     for (int r = 1; r < FWG_MAX_ROWS; ++r) {
         if (r >= c.obs_length) continue;
         const int lag = r * c.obs_step;
-        if (lag >= t) {
-            const u4 b = philox4x32(env_id, E.steps, E.episode, FWG_STREAM_INIT_NOISE + 256u * (r >> 2), A.seed_lo, A.seed_hi);
-            const unsigned bits = (r & 3) == 0 ? b.x : ((r & 3) == 1 ? b.y : ((r & 3) == 2 ? b.z : b.w));
-            const float noise = (2.f * u01(bits) - 1.f) * c.dt;
+        if (lag >= t && pre) {
+#pragma unroll
+            for (int j = 0; j < FWG_MAX_OBS; ++j) {
+                if (j >= c.n_obs || c.obs[j].type != FWG_OBS_ACTION) continue;
+                const DevObs& o = c.obs[j];
+                float v = backscale_action(c, o.src, T.get(FWG_V_ELEVATOR + o.src)) + pre_noise[r];
+                if (o.norm) v = (v - o.mean) * o.inv_var;
+                ob.put(r * c.n_obs + j, v);
+            }
+        } else if (lag >= t) {
+            const float noise = rounded((2.f * u01(bits[r]) - 1.f) * c.dt);
             int slot0 = A.slot_lag - t; slot0 += (slot0 < 0) ? depth : 0;  // ring slot of the episode's record 0
             if (c.obs_log > 0) slot0 = 0;   // row-log mode: the ring has one slot and holds exactly that record
 #pragma unroll
@@ -905,15 +957,12 @@ __device__ __forceinline__ void draw_state_and_targets(const DevCfg& c, const Dy
 }
 // (3) per-row initial noise of the lagged rows (fixed_wing.py:792-795,831-832)
 __device__ __forceinline__ void draw_row_noise(const DevCfg& c, const KArgs& A, long e, unsigned episode_new, ResetDraw& D) {
-    const unsigned env_id = (unsigned)(A.env_base + e);
+    unsigned bits[FWG_MAX_ROWS] = {};
+    if (c.obs_length > 1) init_noise_bits(c, (unsigned)(A.env_base + e), 0u, episode_new, A.seed_lo, A.seed_hi, bits);
 #pragma unroll
     for (int r = 0; r < FWG_MAX_ROWS; ++r) {
         D.row_noise[r] = 0.f;
-        if (c.obs_length > 1 && r < c.obs_length) {
-            const u4 b = philox4x32(env_id, 0u, episode_new, FWG_STREAM_INIT_NOISE + 256u * (r >> 2), A.seed_lo, A.seed_hi);
-            const unsigned bits = (r & 3) == 0 ? b.x : ((r & 3) == 1 ? b.y : ((r & 3) == 2 ? b.z : b.w));
-            D.row_noise[r] = (2.f * u01(bits) - 1.f) * c.dt;
-        }
+        if (c.obs_length > 1 && r < c.obs_length) D.row_noise[r] = (2.f * u01(bits[r]) - 1.f) * c.dt;
     }
 }
 
@@ -1025,7 +1074,7 @@ __device__ __forceinline__ unsigned draw_stage_step(const DevCfg& c, const DynCf
 
 template <bool TURB, class TAB, class OB>
 __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, long e, Env& E, TAB& T, OB& ob, const float* ring,
-                                             int g_end, int g_lag, int g_bit, const ResetDraw& D) {
+                                             int g_end, int g_lag, int g_bit, const ResetDraw& D, bool have_gw = false) {
     E.episode = D.episode;
     E.steps = 0u;
     E.sft = 0u;
@@ -1065,7 +1114,8 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
     if (c.metrics) GROUP(A.S, A.N, (c.L.end_ring >> 2) + g_end, e) = make_float4(err[0], err[1], err[2], 0.f);
     E.wcnt = 0u; E.gcnt[0] = 0u; E.gcnt[1] = 0u;
     if (c.goal_enabled) {   // the ring keeps its old contents (see goal_push); only the word holding g_bit is touched
-        E.gw = reinterpret_cast<const unsigned*>(A.S)[((unsigned)c.L.goal + (unsigned)(g_bit >> 3)) * (unsigned)A.N + (unsigned)e];
+        // (have_gw: the step kernel holds that very word in E.gw already -- it is the one this step's record went into)
+        if (!have_gw) E.gw = reinterpret_cast<const unsigned*>(A.S)[((unsigned)c.L.goal + (unsigned)(g_bit >> 3)) * (unsigned)A.N + (unsigned)e];
         goal_push(c, E, goal_flags(c, err), g_bit, 0u);   // ... and written back by store_gym
     }
     store_cold(c, A.S, A.N, e, E);

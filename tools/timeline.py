@@ -38,7 +38,7 @@ def run():
     from gym_fixed_wing import presets
     from gym_fixed_wing.vec_env import FixedWingVecEnv
     res = {}
-    for wl, log_rows in (("c3", 0), ("c3", presets.OBS_LOG_ROWS), ("c2", 0), ("c5", 0)):
+    for wl, log_rows in (("c3", presets.OBS_LOG_ROWS), ("c5", 0)):
         cfg, ckw, skw, n, desc = presets.workload(wl)
         n = 65536
         vec = FixedWingVecEnv(cfg, num_envs=n, device=0, config_kw=ckw, sim_config_kw=skw, seed=1, derived_views=False,
@@ -53,8 +53,9 @@ def run():
         if stagger:   # spread the episode ages (and, with constant actions, provoke failures: TL_CONST=1)
             const = os.environ.get("TL_CONST", "0") == "1"
             per = int(vec.cfg["steps_max"]) // stagger
+            perm = np.random.RandomState(5).permutation(n) if os.environ.get("TL_PERM", "0") == "1" else np.arange(n)
             for k in range(stagger):
-                vec.reset(indices=np.arange(k, n, stagger))
+                vec.reset(indices=np.sort(perm[k::stagger]))
                 for t in range(per):
                     vec.step_device(acts[0] if const else acts[t % 16], want_obs=False)
             if const:
@@ -93,11 +94,15 @@ def run():
         # the slowest block of the last launch: where did ITS time go?
         last = rel[-1]
         worst = int(np.nanargmax(np.nanmax(last, axis=(1, 2))))
-        print("   slowest block {} of the last launch (lifetime {:.0f}, done lanes in the wave: {}):".format(
-            worst, np.nanmax(last[worst]), int(vec._done[worst * 64:(worst + 1) * 64].sum().item())))
-        for w in range(2):
-            if not np.all(np.isnan(last[worst][w])):
-                print("      wave {}: ".format(w) + "  ".join("{}:{:.0f}".format(i, last[worst][w][i]) for i in range(11) if not np.isnan(last[worst][w][i])))
+        order = np.argsort(-np.nanmax(last, axis=(1, 2)))
+        steps_now = vec.field("steps_count").cpu().numpy()
+        for worst in [int(order[0]), int(order[8]), int(order[40]), int(order[200])]:
+            print("   block {} of the last launch (lifetime {:.0f}, done lanes in the wave: {}{}):".format(
+                worst, np.nanmax(last[worst]), int(vec._done[worst * 64:(worst + 1) * 64].sum().item()),
+                "" if steps_now is None else ", lanes in their first 8 steps: {}".format(int((steps_now[worst * 64:(worst + 1) * 64] <= 8).sum()))))
+            for w in range(2):
+                if not np.all(np.isnan(last[worst][w])):
+                    print("      wave {}: ".format(w) + "  ".join("{}:{:.0f}".format(i, last[worst][w][i]) for i in (0, 1, 2, 3, 4, 5, 6, 14, 15, 7, 11, 12, 13, 8, 9, 10) if not np.isnan(last[worst][w][i])))
         vec.close()
     print(json.dumps(res))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
