@@ -20,8 +20,8 @@ def parse(path, kernel):
 
 
 out = {}
-for key, fn, kernel in (("c3_log", "r02_c3_rocprofv3_summary_v9.txt", "k_step2<true, 6>"),
-                        ("c3", "r02_c3_dense_rocprofv3_summary_v9.txt", "k_step2<true, 4>")):
+for key, fn, kernel in (("c3_log", "r02_c3_rocprofv3_summary_v10.txt", "k_step2<true, 6>"),
+                        ("c3", "r02_c3_dense_rocprofv3_summary_v10.txt", "k_step2<true, 4>")):
     p = os.path.join(ROOT, "profiles", fn)
     v = parse(p, kernel)
     b = int(v["FETCH_SIZE"] * 1024 * 2 + v["WRITE_SIZE"] * 1024)
