@@ -224,10 +224,16 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #else
         FWG_TL(A, 1);
 #ifdef FWG_EXT_ACTUATORS
-        if (SPLIT) fail = sim_step<TURB, PartnerActuators>(c, E.y, sp, E.wind, gust, E.d, PartnerActuators{acts});
+        if (SPLIT) fail = sim_step<TURB, PartnerActuators>(c, c, E.y, sp, E.wind, gust, E.d, PartnerActuators{acts});
         else
 #endif
-            fail = sim_step<TURB>(c, E.y, sp, E.wind, gust, E.d);
+        if (KT::generic || c.model_n > 0) {   // per-lane force / moment constants (the generic kernel keeps ONE code path)
+            Aero la;
+            if (c.model_n > 0) load_aero(c, A.S, A.N, e, la); else aero_from_cfg(c, la);
+            fail = sim_step<TURB, NoExtActuators, Aero>(c, la, E.y, sp, E.wind, gust, E.d);
+        } else {
+            fail = sim_step<TURB>(c, c, E.y, sp, E.wind, gust, E.d);
+        }
 #endif
         FWG_TL(A, 2);
         if (fail != 0) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
@@ -776,6 +782,54 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     }
 }
 
+// simulator.model (fixed_wing.py:532-559): the aircraft parameter table of the NEXT episode of every env whose prepared set
+// is stale -- listed parameters drawn around their nominal values (Philox: counter = env id, episode, index in the list),
+// the force / moment constants derived from the table by the formulas of lower_config -- into L.aero_next, tagged with
+// the episode it is for and the configuration generation.  Launched before every kernel that may reset an env (fwg_step,
+// fwg_reset); lanes whose set is current leave at once.  Rare path: loops, the table in a lane-private LDS column.
+struct LaneColumn {
+    const float* base;
+    __device__ __forceinline__ float operator[](int i) const { return base[i * FWG_WAVE]; }
+};
+__global__ __launch_bounds__(FWG_WAVE) void k_model_draw(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [FWG_N_PARAMS][64]
+    float* tab = lds;
+    const DevCfg& c = *cp;
+    const ModelCfg& m = dp->model;
+    const int lane = threadIdx.x;
+    const long e = (long)blockIdx.x * FWG_WAVE + lane;
+    if (e >= A.N) return;
+    const unsigned episode_new = f2u(CGROUP(A.S, A.N, (c.L.cold >> 2), e).w) + 1u;
+    const float4 tag = CGROUP(A.S, A.N, (c.L.aero_next >> 2) + FWG_AERO_GROUPS - 1, e);
+    if (f2u(tag.y) == episode_new && f2u(tag.z) == dp->generation) return;
+    float* P = tab + lane;
+    for (int i = 0; i < FWG_N_PARAMS; ++i) P[i * FWG_WAVE] = m.nominal[i];
+    const unsigned env_id = (unsigned)(A.env_base + e);
+    for (int i = 0; i < m.n; ++i) {
+        const u4 b = philox4x32(env_id, episode_new, (unsigned)i, FWG_STREAM_MODEL, A.seed_lo, A.seed_hi);
+        const float nominal = m.nominal[m.idx[i]];
+        float x;
+        if (m.dist == 0) {   // np_random.normal(loc, scale) then np.clip (numpy's order: max with the lower end first)
+            const float z = sqrtf(-2.f * logf(u01(b.x))) * cosf(6.2831853071795865f * u01(b.y));
+            x = fminf(fmaxf(nominal + m.var[i] * z, m.lo[i]), m.hi[i]);
+        } else {
+            x = (nominal - m.var[i]) + 2.f * m.var[i] * u01(b.x);
+        }
+        P[m.idx[i] * FWG_WAVE] = x;
+    }
+    Aero a;
+    derive_aero<float>(LaneColumn{P}, m.rho, m.g, a);
+    float v[4 * FWG_AERO_GROUPS];
+    int k = 0;
+#define FWG_AERO_PUT(n) v[k++] = a.n;
+    FWG_AERO_LIST(FWG_AERO_PUT)
+#undef FWG_AERO_PUT
+    v[FWG_N_AERO] = u2f(episode_new); v[FWG_N_AERO + 1] = u2f(dp->generation); v[FWG_N_AERO + 2] = 0.f;
+#pragma unroll
+    for (int g = 0; g < FWG_AERO_GROUPS; ++g)
+        GROUP(A.S, A.N, (c.L.aero_next >> 2) + g, e) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+
 __global__ void k_check_nan(const float* __restrict__ a, long n, int* flag) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && a[i] != a[i]) atomicOr(flag, 1);
@@ -894,6 +948,9 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
         for (int k = 0; k < c.n_targets; ++k) dynamic = dynamic || c.target[k].cls >= FWG_TGT_LINEAR;
         L->draw = o; o += dynamic ? 56 : 44;
     }
+    if (c.model_n < 0 || c.model_n > FWG_N_PARAMS) { *why = "model_n out of range"; return -1; }
+    L->aero = o; o += c.model_n > 0 ? FWG_AERO_GROUPS * 4 : 0;        // per-env force/moment constants: this episode's ...
+    L->aero_next = o; o += c.model_n > 0 ? FWG_AERO_GROUPS * 4 : 0;   // ... and the next one's (k_model_draw)
     L->window = window;
     L->rows = o;
     return use_cmd;
@@ -938,35 +995,25 @@ static int lower_config(const fwg_config& c, DevCfg* d, DynCfg* dy, std::string*
     const double h = c.dt / c.n_substeps;
     d->h = f32(h); d->half_h = f32(0.5 * h); d->h_sixth = f32(h / 6.0);
     d->turbulence = c.turbulence;
-    d->half_rho_S = f32(0.5 * c.rho * P[FWG_P_S_WING]);
-    d->mg = f32(P[FWG_P_MASS] * c.g);
-    d->inv_mass = f32(1.0 / P[FWG_P_MASS]);
-    d->inv_Jy = f32(1.0 / P[FWG_P_JY]);
-    {
-        const double Jx = P[FWG_P_JX], Jy = P[FWG_P_JY], Jz = P[FWG_P_JZ], Jxz = P[FWG_P_JXZ];
-        const double G = Jx * Jz - Jxz * Jxz;
-        d->G1 = f32(Jxz * (Jx - Jy + Jz) / G); d->G2 = f32((Jz * (Jz - Jy) + Jxz * Jxz) / G);
-        d->G3 = f32(Jz / G); d->G4 = f32(Jxz / G); d->G5 = f32((Jz - Jx) / Jy); d->G6 = f32(Jxz / Jy);
-        d->G7 = f32(((Jx - Jy) * Jx + Jxz * Jxz) / G); d->G8 = f32(Jx / G);
+    {   // force / moment constants from the parameter table (derive_aero: the device runs the same formulas per env when
+        // simulator.model re-samples the table)
+        AeroT<double> ad;
+        derive_aero<double>(P, c.rho, c.g, ad);
+#define FWG_AERO_LOWER(n) d->n = f32(ad.n);
+        FWG_AERO_LIST(FWG_AERO_LOWER)
+#undef FWG_AERO_LOWER
     }
-    d->M = f32(P[FWG_P_M]); d->Ma0 = f32(P[FWG_P_M] * P[FWG_P_A_0]);
-    d->CL0 = f32(P[FWG_P_C_LIFT_0]); d->CLa = f32(P[FWG_P_C_LIFT_ALPHA]);
-    d->cLq = f32(P[FWG_P_C_LIFT_Q] * P[FWG_P_C]); d->CLde = f32(P[FWG_P_C_LIFT_DELTA_E]);
-    d->CDp = f32(P[FWG_P_C_D_P]); d->kInd = f32(1.0 / (M_PI * P[FWG_P_E] * P[FWG_P_AR]));
-    d->CDb1 = f32(P[FWG_P_C_D_BETA1]); d->CDb2 = f32(P[FWG_P_C_D_BETA2]);
-    d->cDq = f32(P[FWG_P_C_D_Q] * P[FWG_P_C]); d->CDde = f32(P[FWG_P_C_D_DELTA_E]);
-    d->Cm0 = f32(P[FWG_P_C_M_0]); d->Cma = f32(P[FWG_P_C_M_ALPHA]);
-    d->cmq = f32(P[FWG_P_C_M_Q] * P[FWG_P_B]); d->Cmde = f32(P[FWG_P_C_M_DELTA_E]); d->Cmfp = f32(P[FWG_P_C_M_FP]);
-    d->chord = f32(P[FWG_P_C]); d->span = f32(P[FWG_P_B]);
-    d->CY0 = f32(P[FWG_P_C_Y_0]); d->CYb = f32(P[FWG_P_C_Y_BETA]);
-    d->cYp = f32(P[FWG_P_C_Y_P] * P[FWG_P_B]); d->cYr = f32(P[FWG_P_C_Y_R] * P[FWG_P_B]); d->CYda = f32(P[FWG_P_C_Y_DELTA_A]);
-    d->Cl0 = f32(P[FWG_P_C_ROLL_0]); d->Clb = f32(P[FWG_P_C_ROLL_BETA]);
-    d->clp = f32(P[FWG_P_C_ROLL_P] * P[FWG_P_B]); d->clr = f32(P[FWG_P_C_ROLL_R] * P[FWG_P_B]); d->Clda = f32(P[FWG_P_C_ROLL_DELTA_A]);
-    d->Cn0 = f32(P[FWG_P_C_N_0]); d->Cnb = f32(P[FWG_P_C_N_BETA]);
-    d->cnp = f32(P[FWG_P_C_N_P] * P[FWG_P_B]); d->cnr = f32(P[FWG_P_C_N_R] * P[FWG_P_B]); d->Cnda = f32(P[FWG_P_C_N_DELTA_A]);
-    d->kprop = f32(0.5 * c.rho * P[FWG_P_S_PROP] * P[FWG_P_C_PROP]);
-    d->kmotor = f32(P[FWG_P_K_MOTOR]);
-    d->ktp = f32(P[FWG_P_K_T_P] * P[FWG_P_K_OMEGA] * P[FWG_P_K_OMEGA]);
+    d->model_n = c.model_n;
+    dy->model.n = c.model_n; dy->model.dist = c.model_dist;
+    dy->model.rho = f32(c.rho); dy->model.g = f32(c.g);
+    for (int i = 0; i < FWG_N_PARAMS; ++i) dy->model.nominal[i] = f32(P[i]);
+    for (int i = 0; i < c.model_n; ++i) {
+        if (c.model_idx[i] < 0 || c.model_idx[i] >= FWG_N_PARAMS) { *why = "model_idx out of range"; return -1; }
+        if (c.model_dist != 0 && c.model_dist != 1) { *why = "model_dist must be 0 (gaussian) or 1 (uniform)"; return -1; }
+        dy->model.idx[i] = c.model_idx[i];
+        dy->model.var[i] = f32(c.model_var[i]);
+        dy->model.lo[i] = lim32(c.model_clip_lo[i], true); dy->model.hi[i] = lim32(c.model_clip_hi[i], false);
+    }
     d->con_mask = 0;
     for (int v = 0; v < FWG_N_VARS; ++v) {
         d->con_min[v] = lim32(c.con_min[v], true); d->con_max[v] = lim32(c.con_max[v], false);
@@ -1167,6 +1214,11 @@ static void base_args(const fwg_handle* h, KArgs* A) {
 }
 
 static void observer_args(fwg_handle* h, KArgs* A);   // defined with the rollout head below
+// simulator.model: before any launch that may reset an env, every env has the parameter set of its next episode prepared
+static void launch_model_draw(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
+    if (h->h.model_n <= 0) return;
+    hipLaunchKernelGGL(k_model_draw, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), FWG_N_PARAMS * FWG_WAVE * sizeof(float), stream, h->d_cfg, h->d_dyn, A);
+}
 
 int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const float* init_target, float* obs_out, void* stream) {
     if (!h || !obs_out) return fail_with(FWG_ERR_INVALID, "null argument");
@@ -1175,6 +1227,7 @@ int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const
     A.mask = mask; A.init_state = init_state; A.init_target = init_target; A.obs = obs_out;
     fill_slots(h, h->gstep - 1, &A);  // initial records take the ring position of the last completed step
     if (h->graph_mode) { A.slots_in = h->d_slots + (h->gstep & 1); A.reset_launch = 1; }
+    launch_model_draw(h, A, (hipStream_t)stream);
     launch<false>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return FWG_OK;
@@ -1193,6 +1246,7 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
 #ifdef FWG_TIMELINE
     A.trace = h->trace;
 #endif
+    launch_model_draw(h, A, (hipStream_t)stream);
     launch<true>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     h->gstep += 1;

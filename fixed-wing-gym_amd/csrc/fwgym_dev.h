@@ -18,16 +18,74 @@
 #define FWG_STREAM_RESET_TARGET 3u
 #define FWG_STREAM_OBS_NOISE 4u
 #define FWG_STREAM_INIT_NOISE 5u
+#define FWG_STREAM_MODEL 7u              // simulator.model draws (6 = the rollout head's policy noise)
 
 struct DevObs { int type, src, window, norm; float mean, inv_var; };
 struct DevTarget { int var, cls, wrap, has_delta, has_bound; float bound; };
 // ranges that set_curriculum_level rescales (fixed_wing.py:224-285): kept OUT of the compile-time-specialisable block
 struct DynTarget { float low, high, delta, slope_low, slope_high, amp_low, amp_high, period_low, period_high; };
+// simulator.model (fixed_wing.py:532-559): the parameters re-sampled at every reset and how
+struct ModelCfg {
+    int n, dist;                       // listed parameters; 0 gaussian (+ clip), 1 uniform
+    int idx[FWG_N_PARAMS];             // fwg_param id of listed parameter i
+    float var[FWG_N_PARAMS], lo[FWG_N_PARAMS], hi[FWG_N_PARAMS];   // per listed parameter: std / half-width, clip interval
+    float nominal[FWG_N_PARAMS];       // the parameter table (by fwg_param id)
+    float rho, g;
+};
 struct DynCfg {
     float init_min[FWG_N_VARS], init_max[FWG_N_VARS];
     DynTarget target[FWG_MAX_TARGETS];
     unsigned generation;   // bumped whenever what a reset draw depends on changes (ranges, seed): prepared draws are then discarded
+    ModelCfg model;
 };
+// The constants of the force / moment model, pre-combined from the parameter table (same names and order as the block at
+// the head of DevCfg).  One set for all envs (DevCfg) unless simulator.model re-samples the table per env and episode: then
+// every lane carries its own (arena section L.aero), derived on the device by the same formulas (derive_aero).
+#define FWG_AERO_LIST(X)                                                                                          \
+    X(half_rho_S) X(mg) X(inv_mass) X(inv_Jy) X(G1) X(G2) X(G3) X(G4) X(G5) X(G6) X(G7) X(G8) X(M) X(Ma0)          \
+    X(CL0) X(CLa) X(cLq) X(CLde) X(CDp) X(kInd) X(CDb1) X(CDb2) X(cDq) X(CDde)                                    \
+    X(Cm0) X(Cma) X(cmq) X(Cmde) X(Cmfp) X(chord) X(span) X(CY0) X(CYb) X(cYp) X(cYr) X(CYda)                     \
+    X(Cl0) X(Clb) X(clp) X(clr) X(Clda) X(Cn0) X(Cnb) X(cnp) X(cnr) X(Cnda) X(kprop) X(kmotor) X(ktp)
+#define FWG_N_AERO 49
+#define FWG_AERO_GROUPS 13   // 52 words: the 49 constants | tag: episode the set is for, configuration generation, -
+template <class T> struct AeroT {
+#define FWG_AERO_MEMBER(n) T n;
+    FWG_AERO_LIST(FWG_AERO_MEMBER)
+#undef FWG_AERO_MEMBER
+};
+typedef AeroT<float> Aero;
+// P = parameter table by fwg_param id; the formulas of lower_config (host, double) and k_model_draw (device, float)
+template <class T, class PA>
+__host__ __device__ inline void derive_aero(const PA& P, T rho, T g, AeroT<T>& d) {
+    const T pi = (T)3.14159265358979323846;
+    d.half_rho_S = (T)0.5 * rho * P[FWG_P_S_WING];
+    d.mg = P[FWG_P_MASS] * g;
+    d.inv_mass = (T)1 / P[FWG_P_MASS];
+    d.inv_Jy = (T)1 / P[FWG_P_JY];
+    const T Jx = P[FWG_P_JX], Jy = P[FWG_P_JY], Jz = P[FWG_P_JZ], Jxz = P[FWG_P_JXZ];
+    const T G = Jx * Jz - Jxz * Jxz;
+    d.G1 = Jxz * (Jx - Jy + Jz) / G; d.G2 = (Jz * (Jz - Jy) + Jxz * Jxz) / G;
+    d.G3 = Jz / G; d.G4 = Jxz / G; d.G5 = (Jz - Jx) / Jy; d.G6 = Jxz / Jy;
+    d.G7 = ((Jx - Jy) * Jx + Jxz * Jxz) / G; d.G8 = Jx / G;
+    d.M = P[FWG_P_M]; d.Ma0 = P[FWG_P_M] * P[FWG_P_A_0];
+    d.CL0 = P[FWG_P_C_LIFT_0]; d.CLa = P[FWG_P_C_LIFT_ALPHA];
+    d.cLq = P[FWG_P_C_LIFT_Q] * P[FWG_P_C]; d.CLde = P[FWG_P_C_LIFT_DELTA_E];
+    d.CDp = P[FWG_P_C_D_P]; d.kInd = (T)1 / (pi * P[FWG_P_E] * P[FWG_P_AR]);
+    d.CDb1 = P[FWG_P_C_D_BETA1]; d.CDb2 = P[FWG_P_C_D_BETA2];
+    d.cDq = P[FWG_P_C_D_Q] * P[FWG_P_C]; d.CDde = P[FWG_P_C_D_DELTA_E];
+    d.Cm0 = P[FWG_P_C_M_0]; d.Cma = P[FWG_P_C_M_ALPHA];
+    d.cmq = P[FWG_P_C_M_Q] * P[FWG_P_B]; d.Cmde = P[FWG_P_C_M_DELTA_E]; d.Cmfp = P[FWG_P_C_M_FP];
+    d.chord = P[FWG_P_C]; d.span = P[FWG_P_B];
+    d.CY0 = P[FWG_P_C_Y_0]; d.CYb = P[FWG_P_C_Y_BETA];
+    d.cYp = P[FWG_P_C_Y_P] * P[FWG_P_B]; d.cYr = P[FWG_P_C_Y_R] * P[FWG_P_B]; d.CYda = P[FWG_P_C_Y_DELTA_A];
+    d.Cl0 = P[FWG_P_C_ROLL_0]; d.Clb = P[FWG_P_C_ROLL_BETA];
+    d.clp = P[FWG_P_C_ROLL_P] * P[FWG_P_B]; d.clr = P[FWG_P_C_ROLL_R] * P[FWG_P_B]; d.Clda = P[FWG_P_C_ROLL_DELTA_A];
+    d.Cn0 = P[FWG_P_C_N_0]; d.Cnb = P[FWG_P_C_N_BETA];
+    d.cnp = P[FWG_P_C_N_P] * P[FWG_P_B]; d.cnr = P[FWG_P_C_N_R] * P[FWG_P_B]; d.Cnda = P[FWG_P_C_N_DELTA_A];
+    d.kprop = (T)0.5 * rho * P[FWG_P_S_PROP] * P[FWG_P_C_PROP];
+    d.kmotor = P[FWG_P_K_MOTOR];
+    d.ktp = P[FWG_P_K_T_P] * P[FWG_P_K_OMEGA] * P[FWG_P_K_OMEGA];
+}
 struct DevFactor { int cls, type, src, fclass, shaping, window, has_max, value_is_timesteps; float sign, inv_scaling, max, value; };
 
 // Static configuration.  Every member is a 32-bit int/float (no padding), so that a lowered instance can be frozen into
@@ -72,6 +130,7 @@ struct DevCfg {
     int metrics, auto_reset, use_cmd_ring, store_derived;
     int obs_log;   // rows per parity of the observation row log (0 = dense observation batch)
     float rise_low, rise_high;
+    int model_n;   // > 0: simulator.model -- per-env force/moment constants (L.aero), re-sampled at every reset
     fwg_layout L;
 };
 

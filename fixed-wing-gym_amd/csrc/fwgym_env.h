@@ -366,6 +366,25 @@ __device__ __forceinline__ void load_cold(const DevCfg& c, const float* __restri
     E.wind[0] = w.x; E.wind[1] = w.y; E.wind[2] = w.z; E.episode = f2u(w.w);
 }
 
+// simulator.model: this lane's force / moment constants (arena section L.aero) / the shared set of the configuration
+__device__ __forceinline__ void load_aero(const DevCfg& c, const float* __restrict__ S, long N, long e, Aero& a) {
+    float v[4 * FWG_AERO_GROUPS];
+#pragma unroll
+    for (int g = 0; g < FWG_AERO_GROUPS; ++g) {
+        const float4 q = CGROUP(S, N, (c.L.aero >> 2) + g, e);
+        v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+    }
+    int i = 0;
+#define FWG_AERO_TAKE(n) a.n = v[i++];
+    FWG_AERO_LIST(FWG_AERO_TAKE)
+#undef FWG_AERO_TAKE
+}
+__device__ __forceinline__ void aero_from_cfg(const DevCfg& c, Aero& a) {
+#define FWG_AERO_TAKE(n) a.n = c.n;
+    FWG_AERO_LIST(FWG_AERO_TAKE)
+#undef FWG_AERO_TAKE
+}
+
 // The write-back is split so that each part is issued as soon as its values are final: the simulator block right after
 // the integration, the bookkeeping after the gym logic -- the store traffic then overlaps the remaining computation
 // instead of forming one burst at the end of the kernel.
@@ -1075,6 +1094,11 @@ __device__ __forceinline__ unsigned draw_stage_step(const DevCfg& c, const DynCf
 template <bool TURB, class TAB, class OB>
 __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, long e, Env& E, TAB& T, OB& ob, const float* ring,
                                              int g_end, int g_lag, int g_bit, const ResetDraw& D, bool have_gw = false) {
+    if (c.model_n > 0) {   // simulator.model: the set prepared for this episode by k_model_draw becomes the current one
+#pragma unroll
+        for (int g = 0; g < FWG_AERO_GROUPS; ++g)
+            GROUP(A.S, A.N, (c.L.aero >> 2) + g, e) = CGROUP(A.S, A.N, (c.L.aero_next >> 2) + g, e);
+    }
     E.episode = D.episode;
     E.steps = 0u;
     E.sft = 0u;

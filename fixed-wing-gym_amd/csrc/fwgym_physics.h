@@ -45,8 +45,10 @@ __device__ __forceinline__ void check_var(const DevCfg& c, int& fail, int var, f
 
 // d/dt of the 13 rigid-body states for the actuator deflections act = (elevon_right, elevon_left, throttle) at the
 // stage time (oracle/physics.py rhs)
-template <bool TURB>
-__device__ __forceinline__ void rhs(const DevCfg& c, const float (&y)[NB], const float (&act)[3], const float (&wind)[3],
+// `a` = the force / moment constants: the DevCfg itself (one aircraft for all envs; compile-time constants in the specialised
+// kernels) or this lane's own set (Aero, simulator.model)
+template <bool TURB, class AP>
+__device__ __forceinline__ void rhs(const DevCfg& c, const AP& a_, const float (&y)[NB], const float (&act)[3], const float (&wind)[3],
                                     const float (&gust)[6], float (&dy)[NB], int& fail) {
     const float e0 = y[0], e1 = y[1], e2 = y[2], e3 = y[3];
     const float p = y[4], q = y[5], r = y[6];
@@ -75,50 +77,50 @@ __device__ __forceinline__ void rhs(const DevCfg& c, const float (&y)[NB], const
     const float rv = frsq(v2), rxz = frsq(xz2);
     const float ca = a.ua * rxz, sa = a.wa * rxz, sb = a.va * rv, cb = xz2 * rxz * rv;
 
-    const float pre = c.half_rho_S * Va * Va;
+    const float pre = a_.half_rho_S * Va * Va;
     const float i2v = 0.5f * frcp(Va);
     // stall blend: 1 - sigma = 1/((1+exp(M(a-a0)))(1+exp(-M(a+a0))))  (overflow-safe form of the published sigma)
-    const float ex1 = __expf(c.M * a.alpha - c.Ma0), ex2 = __expf(-c.M * a.alpha - c.Ma0);
+    const float ex1 = __expf(a_.M * a.alpha - a_.Ma0), ex2 = __expf(-a_.M * a.alpha - a_.Ma0);
     const float oms = frcp((1.f + ex1) * (1.f + ex2));
     const float sig = 1.f - oms;
     const float sgn = fsignf(a.alpha);
     const float sa2 = sa * sa;
-    const float CLlin = c.CL0 + c.CLa * a.alpha;
+    const float CLlin = a_.CL0 + a_.CLa * a.alpha;
     const float CL = oms * CLlin + sig * (2.f * sgn * sa2 * ca);
-    const float lift = pre * (CL + c.cLq * i2v * qa + c.CLde * elev);
-    const float CD = c.CDp + oms * CLlin * CLlin * c.kInd + sig * (2.f * sgn * sa2 * sa);
-    const float CDb = (c.CDb1 + c.CDb2 * a.beta) * a.beta;
-    const float drag = pre * (CD + CDb + c.cDq * i2v * qa + c.CDde * elev * elev);
-    const float Cm = oms * (c.Cm0 + c.Cma * a.alpha) + sig * (c.Cmfp * sgn * sa2);
-    const float m_ = pre * c.chord * (Cm + c.cmq * i2v * qa + c.Cmde * elev);
-    const float fy_s = pre * (c.CY0 + c.CYb * a.beta + i2v * (c.cYp * pa + c.cYr * ra) + c.CYda * ail);
-    const float l_ = pre * c.span * (c.Cl0 + c.Clb * a.beta + i2v * (c.clp * pa + c.clr * ra) + c.Clda * ail)
-                     - c.ktp * th * th;
-    const float n_ = pre * c.span * (c.Cn0 + c.Cnb * a.beta + i2v * (c.cnp * pa + c.cnr * ra) + c.Cnda * ail);
+    const float lift = pre * (CL + a_.cLq * i2v * qa + a_.CLde * elev);
+    const float CD = a_.CDp + oms * CLlin * CLlin * a_.kInd + sig * (2.f * sgn * sa2 * sa);
+    const float CDb = (a_.CDb1 + a_.CDb2 * a.beta) * a.beta;
+    const float drag = pre * (CD + CDb + a_.cDq * i2v * qa + a_.CDde * elev * elev);
+    const float Cm = oms * (a_.Cm0 + a_.Cma * a.alpha) + sig * (a_.Cmfp * sgn * sa2);
+    const float m_ = pre * a_.chord * (Cm + a_.cmq * i2v * qa + a_.Cmde * elev);
+    const float fy_s = pre * (a_.CY0 + a_.CYb * a.beta + i2v * (a_.cYp * pa + a_.cYr * ra) + a_.CYda * ail);
+    const float l_ = pre * a_.span * (a_.Cl0 + a_.Clb * a.beta + i2v * (a_.clp * pa + a_.clr * ra) + a_.Clda * ail)
+                     - a_.ktp * th * th;
+    const float n_ = pre * a_.span * (a_.Cn0 + a_.Cnb * a.beta + i2v * (a_.cnp * pa + a_.cnr * ra) + a_.Cnda * ail);
 
     // wind axes -> body axes
     const float fxa = -ca * cb * drag - ca * sb * fy_s + sa * lift;
     const float fya = -sb * drag + cb * fy_s;
     const float fza = -sa * cb * drag - sa * sb * fy_s - ca * lift;
-    const float Vd = Va + th * (c.kmotor - Va);
-    const float fprop = c.kprop * Vd * (Vd - Va);
-    const float fx = fprop + c.mg * 2.f * (e1 * e3 - e2 * e0) + fxa;
-    const float fy = c.mg * 2.f * (e2 * e3 + e1 * e0) + fya;
-    const float fz = c.mg * (e3 * e3 + e0 * e0 - e1 * e1 - e2 * e2) + fza;
+    const float Vd = Va + th * (a_.kmotor - Va);
+    const float fprop = a_.kprop * Vd * (Vd - Va);
+    const float fx = fprop + a_.mg * 2.f * (e1 * e3 - e2 * e0) + fxa;
+    const float fy = a_.mg * 2.f * (e2 * e3 + e1 * e0) + fya;
+    const float fz = a_.mg * (e3 * e3 + e0 * e0 - e1 * e1 - e2 * e2) + fza;
 
     dy[0] = 0.5f * (-p * e1 - q * e2 - r * e3);
     dy[1] = 0.5f * (p * e0 + r * e2 - q * e3);
     dy[2] = 0.5f * (q * e0 - r * e1 + p * e3);
     dy[3] = 0.5f * (r * e0 + q * e1 - p * e2);
-    dy[4] = c.G1 * p * q - c.G2 * q * r + c.G3 * l_ + c.G4 * n_;
-    dy[5] = c.G5 * p * r - c.G6 * (p * p - r * r) + m_ * c.inv_Jy;
-    dy[6] = c.G7 * p * q - c.G1 * q * r + c.G4 * l_ + c.G8 * n_;
+    dy[4] = a_.G1 * p * q - a_.G2 * q * r + a_.G3 * l_ + a_.G4 * n_;
+    dy[5] = a_.G5 * p * r - a_.G6 * (p * p - r * r) + m_ * a_.inv_Jy;
+    dy[6] = a_.G7 * p * q - a_.G1 * q * r + a_.G4 * l_ + a_.G8 * n_;
     dy[7] = R.r00 * u + R.r01 * v + R.r02 * w;
     dy[8] = R.r10 * u + R.r11 * v + R.r12 * w;
     dy[9] = R.r20 * u + R.r21 * v + R.r22 * w;
-    dy[10] = r * v - q * w + fx * c.inv_mass;
-    dy[11] = p * w - r * u + fy * c.inv_mass;
-    dy[12] = q * u - p * v + fz * c.inv_mass;
+    dy[10] = r * v - q * w + fx * a_.inv_mass;
+    dy[11] = p * w - r * u + fy * a_.inv_mass;
+    dy[12] = q * u - p * v + fz * a_.inv_mass;
 }
 
 // one actuator micro-step with the command held: exact linear response (2x2 transition per elevon, exponential for
@@ -233,8 +235,8 @@ struct NoExtActuators {
     static constexpr bool enabled = false;
     __device__ __forceinline__ void fetch(float (&)[5], float (&)[5]) const {}
 };
-template <bool TURB, class EXT = NoExtActuators>
-__device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const float (&sp)[3], const float (&wind)[3],
+template <bool TURB, class EXT = NoExtActuators, class AP = DevCfg>
+__device__ __forceinline__ int sim_step(const DevCfg& c, const AP& aero, float (&y)[NY], const float (&sp)[3], const float (&wind)[3],
                                         const float (&gust)[6], Derived& d, const EXT& ext = EXT()) {
     const bool use_ext = EXT::enabled && c.nsub == 1;
     float yb[NB], a[5];
@@ -276,7 +278,7 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, float (&y)[NY], const f
             float act[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) act[i] = (st == 0) ? a[i] : ((st == 3) ? a_full[i] : a_half[i]);
-            rhs<TURB>(c, ys, act, wind, gust, k, fail);
+            rhs<TURB>(c, aero, ys, act, wind, gust, k, fail);
             if (use_ext && st == 0) ext.fetch(a_half, a_full);   // needed from the second stage on
             const float bw = (st == 0 || st == 3) ? c.h_sixth : 2.f * c.h_sixth;
             const float aw = (st == 2) ? c.h : c.half_h;

@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 14
+FWG_ABI_VERSION = 15
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -109,13 +109,15 @@ class Config(C.Structure):
         ("factor", FactorDesc * MAX_FACTORS),
         ("metrics", C.c_int32), ("auto_reset", C.c_int32), ("store_derived", C.c_int32), ("obs_log_rows", C.c_int32),
         ("rise_low", C.c_double), ("rise_high", C.c_double),
+        ("model_n", C.c_int32), ("model_dist", C.c_int32), ("model_idx", C.c_int32 * N_PARAMS), ("pad_model_", C.c_int32),
+        ("model_var", C.c_double * N_PARAMS), ("model_clip_lo", C.c_double * N_PARAMS), ("model_clip_hi", C.c_double * N_PARAMS),
     ]
 
 
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ["rows", "sim", "cold", "derived", "gym", "tprop", "goal", "act_ring", "cmd_ring", "end_ring", "lag_ring",
-                 "window", "lag_depth", "lag_groups", "draw"]]
+                 "window", "lag_depth", "lag_groups", "draw", "aero", "aero_next"]]
 
 
 class ActorWeights(C.Structure):

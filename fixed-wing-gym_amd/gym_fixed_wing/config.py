@@ -258,8 +258,15 @@ class EnvConfig(object):
         if cfg["reward"].get("randomize_scaling", False):
             raise NotImplementedError("reward.randomize_scaling")
         for key in cfg["simulator"]:
-            if key != "states":
+            if key not in ("states", "model"):
                 raise NotImplementedError("simulator.{} sampling".format(key))
+        if "model" in cfg["simulator"]:
+            m = cfg["simulator"]["model"]
+            if m.get("distribution", "gaussian") not in ("gaussian", "uniform"):
+                raise ValueError("Unexpected distribution type {}".format(m.get("distribution")))   # fixed_wing.py:557
+            for pa in m["parameters"]:
+                if pa["name"] not in nat.PARAMS:
+                    raise NotImplementedError("simulator.model parameter {} is not part of the force/moment model".format(pa["name"]))
         if "goals" in cfg["observation"]:
             raise NotImplementedError("FixedWingAircraftGoal observations")
         for t in cfg["target"]["states"]:
@@ -481,4 +488,38 @@ class EnvConfig(object):
         c.auto_reset = int(bool(auto_reset))
         c.store_derived = int(bool(store_derived))
         c.obs_log_rows = int(obs_log_rows)
+        self._compile_model(c)
         return c
+
+    def _compile_model(self, c):
+        """simulator["model"] (sample_simulator_parameters, fixed_wing.py:532-559) -> absolute spreads and clip intervals per
+        listed parameter.  `original` is the value of the parameter file (fixed_wing.py:540-543); parameters whose original
+        is 0 are never sampled (fixed_wing.py:544-545)."""
+        c.model_n = 0
+        model = self.cfg["simulator"].get("model", None)
+        if model is None:
+            return
+        relative = model["var_type"] == "relative"
+        c.model_dist = {"gaussian": 0, "uniform": 1}[model.get("distribution", "gaussian")]
+        n = 0
+        for pa in model["parameters"]:
+            orig = pa.get("original", None)
+            if orig is None:
+                orig = self.params[pa["name"]]
+            orig = float(orig)
+            if orig == 0:
+                continue
+            if abs(orig - float(self.params[pa["name"]])) > 1e-12 * max(1.0, abs(orig)):
+                raise NotImplementedError("simulator.model: `original` of {} differs from the parameter file".format(pa["name"]))
+            var = float(pa.get("var", model["var"]))
+            if relative:
+                var *= abs(orig)
+            clip = pa.get("clip", model.get("clip", None))
+            lo, hi = -math.inf, math.inf
+            if clip is not None and c.model_dist == 0:
+                clip = float(clip) * (orig if relative else 1.0)   # signed, as the reference computes it
+                lo, hi = orig - clip, orig + clip
+            c.model_idx[n] = nat.PARAMS.index(pa["name"])
+            c.model_var[n], c.model_clip_lo[n], c.model_clip_hi[n] = var, lo, hi
+            n += 1
+        c.model_n = n

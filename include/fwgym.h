@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 14
+#define FWG_ABI_VERSION 15
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -184,6 +184,17 @@ typedef struct fwg_config {
     int32_t obs_log_rows;   /* 0: fwg_step writes the dense [N][obs_dim] batch.  L > 0 (matrix observations without
                              * observation noise): observation history kept once, as a row log -- see fwg_obs_window */
     double rise_low, rise_high;         /* metrics[rise_time].low/high (fixed_wing.py:1131) */
+
+    /* ---- simulator["model"]: aircraft parameters re-sampled for every env at every reset (sample_simulator_parameters,
+     * fixed_wing.py:532-559).  Listed parameter i has id model_idx[i]; its nominal value is param[id].  Gaussian:
+     * N(nominal, model_var[i]) then min(max(x, model_clip_lo[i]), model_clip_hi[i]) (-/+INFINITY = no clip; numpy's clip
+     * order, so an interval given upside down -- relative clip of a negative nominal -- collapses to its upper end).
+     * Uniform: U(nominal - model_var[i], nominal + model_var[i]).  Entries with nominal == 0 are skipped by the caller. */
+    int32_t model_n;                    /* 0 = off */
+    int32_t model_dist;                 /* 0 gaussian, 1 uniform */
+    int32_t model_idx[FWG_N_PARAMS];
+    int32_t pad_model_;
+    double model_var[FWG_N_PARAMS], model_clip_lo[FWG_N_PARAMS], model_clip_hi[FWG_N_PARAMS];
 } fwg_config;
 
 /* The caller-owned state arena is an array of 16-byte GROUPS [rows/4][N] of 32-bit words: word w of env e lives at
@@ -204,6 +215,8 @@ typedef struct fwg_layout {
     int32_t lag_depth;   /* (length-1)*step+1 */
     int32_t lag_groups;  /* ceil(n_obs/4) */
     int32_t draw;        /* 44 (+12 with linear/sinusoidal targets): the NEXT episode's reset draw, prepared ahead of time (cold) */
+    int32_t aero;        /* 52 (model randomisation only): this episode's 49 force/moment constants of the env | - - - */
+    int32_t aero_next;   /* 52: the next episode's | episode it is for, configuration generation, - */
 } fwg_layout;
 
 /* rows of the metrics block (float32 [FWG_N_METRICS][N], valid where done) -- get_metric, fixed_wing.py:1095-1162 */

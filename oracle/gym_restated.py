@@ -54,6 +54,12 @@ class MTStream:
     def obs_normal(self, idx, mean, std):
         return self.rs.normal(loc=mean, scale=std)
 
+    def model_normal(self, i, loc, scale):
+        return self.rs.normal(loc=loc, scale=scale)
+
+    def model_uniform(self, i, low, high):
+        return self.rs.uniform(low=low, high=high)
+
     def begin_obs(self, steps_count):
         pass
 
@@ -102,6 +108,16 @@ class PhiloxStream:
     def begin_obs(self, steps_count):
         self.steps = int(steps_count)
 
+    # simulator.model (csrc/fwgym.hip k_model_draw): listed parameter i of the episode, ctr = (env, episode, i, STREAM_MODEL)
+    def model_normal(self, i, loc, scale):
+        b = self._bits(self.episode, i, self.ph.STREAM_MODEL)
+        z = np.sqrt(-2.0 * np.log(self.ph.u01(b[0]))) * np.cos(2.0 * np.pi * self.ph.u01(b[1]))
+        return loc + scale * z
+
+    def model_uniform(self, i, low, high):
+        b = self._bits(self.episode, i, self.ph.STREAM_MODEL)
+        return low + (high - low) * self.ph.u01(b[0])
+
     def init_noise(self, row):
         b = self._bits(self.steps, self.episode, self.ph.STREAM_INIT_NOISE, block=row // 4)
         return 2.0 * self.ph.u01(b[row % 4]) - 1.0
@@ -140,8 +156,6 @@ class FixedWingOracle:
             raise NotImplementedError("integration_window > 0")
         if cfg["reward"].get("randomize_scaling", False):
             raise NotImplementedError("reward.randomize_scaling")
-        if "model" in cfg["simulator"]:
-            raise NotImplementedError("simulator.model randomisation")
         self.goal_achieved = False           # sticky for the env's lifetime (fixed_wing.py:51,381-382)
         self.steps_count = None
         self.steps_for_target = None
@@ -325,9 +339,36 @@ class FixedWingOracle:
             self.tprops[name] = vp
 
     def _sample_sim_attrs(self):
-        # fixed_wing.py:523-570, non-"states"/"model" keys: sampled and set on the simulator each reset
+        # fixed_wing.py:523-570: keys other than "states" are sampled and set on the simulator at each reset
         for key, value in self.cfg["simulator"].items():
-            if key in ("states", "model"):
+            if key == "states":
+                continue
+            if key == "model":   # fixed_wing.py:532-559: the aircraft parameter table, one draw per listed parameter
+                dist_type = value.get("distribution", "gaussian")
+                n_drawn = 0
+                for pa in value["parameters"]:
+                    orig = pa.get("original", None)
+                    if orig is None:
+                        orig = self.simulator.params[pa["name"]]
+                        pa["original"] = orig
+                    if orig == 0:
+                        continue
+                    var = pa.get("var", value["var"])
+                    if value["var_type"] == "relative":
+                        var *= np.abs(orig)
+                    if dist_type == "gaussian":
+                        x = self.rng.model_normal(n_drawn, orig, var)
+                        clip = pa.get("clip", value.get("clip", None))
+                        if clip is not None:
+                            if value["var_type"] == "relative":
+                                clip *= orig
+                            x = min(max(x, orig - clip), orig + clip)   # np.clip's order of operations
+                    elif dist_type == "uniform":
+                        x = self.rng.model_uniform(n_drawn, orig - var, orig + var)
+                    else:
+                        raise ValueError("Unexpected distribution type {}".format(dist_type))
+                    n_drawn += 1
+                    self.simulator.params[pa["name"]] = x
                 continue
             if "values" in value:
                 probs = value.get("probabilities", None)

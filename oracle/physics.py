@@ -43,7 +43,10 @@ AERO_KEYS = ["mass", "Jx", "Jy", "Jz", "Jxz", "S_wing", "b", "c", "S_prop", "C_p
 class SimSpec:
     """Constants of one simulator instance (float64)."""
 
-    def __init__(self, sim_cfg, params):
+    def __init__(self, sim_cfg, params, dryden_span=None):
+        # dryden_span: wingspan the turbulence filters are built with (the parameter FILE's value when simulator.model
+        # re-samples the table: the filters are set up once, csrc lower_config / config.dryden_matrices)
+        self.dryden_span = None if dryden_span is None else float(dryden_span)
         self.dt = float(sim_cfg["dt"])
         self.rho = float(sim_cfg["rho"])
         self.g = float(sim_cfg["g"])
@@ -98,7 +101,7 @@ class SimSpec:
 
     def dryden(self):
         if self._dryden is None:
-            self._dryden = dryden_discretise(self.params["b"], self.dt, self.turb_h, self.turb_va,
+            self._dryden = dryden_discretise(self.params["b"] if self.dryden_span is None else self.dryden_span, self.dt, self.turb_h, self.turb_va,
                                              self.turbulence_intensity)
         return self._dryden
 
@@ -552,6 +555,7 @@ def box_muller(bits):
 
 # stream ids (ctr[3]) shared with the kernels
 STREAM_TURB, STREAM_RESET_STATE, STREAM_RESET_TARGET, STREAM_OBS_NOISE, STREAM_INIT_NOISE = 1, 2, 3, 4, 5
+STREAM_MODEL = 7   # simulator.model draws (6: the rollout head's policy noise)
 
 
 def rng_bits(seed, env_ids, counter, stream, sub=0):

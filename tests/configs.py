@@ -41,6 +41,19 @@ def reference_like(kind):
         for t, b in zip(cfg["target"]["states"], (77, 41, 10)):
             t["bound"] = b
         return cfg
+    if kind in ("model_gaussian", "model_uniform"):   # simulator["model"]: the aircraft re-sampled at every reset
+        names = ["mass", "Jx", "Jz", "C_L_alpha", "C_L_0", "C_D_p", "C_m_alpha", "C_m_q", "C_m_delta_e", "C_Y_0", "C_Y_beta",
+                 "C_l_p", "C_l_delta_a", "C_n_beta", "C_n_r", "k_motor", "S_prop", "C_D_q"]   # C_Y_0, C_D_q: 0 -> never sampled
+        pars = [{"name": n} for n in names]
+        if kind == "model_gaussian":
+            pars[0]["clip"] = 0.05          # mass: tight relative clip
+            pars[7]["var"] = 0.3            # C_m_q: own spread; negative original -> the relative clip interval is upside down
+            cfg["simulator"]["model"] = {"var_type": "relative", "var": 0.1, "clip": 0.2, "distribution": "gaussian",
+                                         "parameters": pars}
+        else:
+            pars[3]["var"] = 0.5
+            cfg["simulator"]["model"] = {"var_type": "absolute", "var": 0.002, "distribution": "uniform", "parameters": pars}
+        return cfg
     raise KeyError(kind)
 
 
@@ -71,4 +84,6 @@ CASES = [
     ("dynamic_targets", "dynamic_targets", {"steps_max": 80}, None),
     ("reward_mix", "reward_mix", {"steps_max": 60}, None),
     ("reward_mix_potential", "reward_mix", {"steps_max": 60, "reward": {"form": "potential"}}, None),
+    ("model_gaussian", "model_gaussian", {"steps_max": 45}, None),
+    ("model_uniform", "model_uniform", {"steps_max": 45}, {"turbulence": True, "turbulence_intensity": "light"}),
 ]

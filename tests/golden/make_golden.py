@@ -106,6 +106,8 @@ def run_case(ref, case, steps=140, episodes=3):
         explicit_target = None if name in ("dynamic_targets", "resample_normalize", "potential_new") else dict(SCENARIO_TARGET)
         obs = env.reset(state=st, target=explicit_target)
         e = {"state": st, "target": explicit_target, "reset_obs": obs, "reset_target": dict(env.target), "steps": []}
+        if "model" in cfg["simulator"]:   # the aircraft this episode flies (sample_simulator_parameters, fixed_wing.py:532-559)
+            e["sim_params"] = {k: float(v) for k, v in env.simulator.params.items() if not isinstance(v, str)}
         while t < steps:
             a = acts[t]
             t += 1

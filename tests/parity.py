@@ -164,3 +164,64 @@ def scaled_actions(vec, raw):
         return raw
     lo, hi = ec.cfg["action"]["scale_low"], ec.cfg["action"]["scale_high"]
     return (ec.action_scale_to_high - ec.action_scale_to_low) * (np.clip(raw, lo, hi) - lo) / (hi - lo) + ec.action_scale_to_low
+
+
+# ---- simulator["model"]: per-env force / moment constants in the arena (section L.aero, order of FWG_AERO_LIST in
+# csrc/fwgym_dev.h) against the constants derived from an oracle env's sampled parameter table
+AERO_NAMES = ("half_rho_S mg inv_mass inv_Jy G1 G2 G3 G4 G5 G6 G7 G8 M Ma0 CL0 CLa cLq CLde CDp kInd CDb1 CDb2 cDq CDde "
+              "Cm0 Cma cmq Cmde Cmfp chord span CY0 CYb cYp cYr CYda Cl0 Clb clp clr Clda Cn0 Cnb cnp cnr Cnda kprop kmotor ktp").split()
+
+
+def aero_from_params(P, rho, g):
+    Jx, Jy, Jz, Jxz = P["Jx"], P["Jy"], P["Jz"], P["Jxz"]
+    G = Jx * Jz - Jxz * Jxz
+    b, c = P["b"], P["c"]
+    v = {"half_rho_S": 0.5 * rho * P["S_wing"], "mg": P["mass"] * g, "inv_mass": 1 / P["mass"], "inv_Jy": 1 / Jy,
+         "G1": Jxz * (Jx - Jy + Jz) / G, "G2": (Jz * (Jz - Jy) + Jxz * Jxz) / G, "G3": Jz / G, "G4": Jxz / G,
+         "G5": (Jz - Jx) / Jy, "G6": Jxz / Jy, "G7": ((Jx - Jy) * Jx + Jxz * Jxz) / G, "G8": Jx / G,
+         "M": P["M"], "Ma0": P["M"] * P["a_0"], "CL0": P["C_L_0"], "CLa": P["C_L_alpha"], "cLq": P["C_L_q"] * c,
+         "CLde": P["C_L_delta_e"], "CDp": P["C_D_p"], "kInd": 1 / (np.pi * P["e"] * P["ar"]), "CDb1": P["C_D_beta1"],
+         "CDb2": P["C_D_beta2"], "cDq": P["C_D_q"] * c, "CDde": P["C_D_delta_e"], "Cm0": P["C_m_0"], "Cma": P["C_m_alpha"],
+         "cmq": P["C_m_q"] * b, "Cmde": P["C_m_delta_e"], "Cmfp": P["C_m_fp"], "chord": c, "span": b, "CY0": P["C_Y_0"],
+         "CYb": P["C_Y_beta"], "cYp": P["C_Y_p"] * b, "cYr": P["C_Y_r"] * b, "CYda": P["C_Y_delta_a"], "Cl0": P["C_l_0"],
+         "Clb": P["C_l_beta"], "clp": P["C_l_p"] * b, "clr": P["C_l_r"] * b, "Clda": P["C_l_delta_a"], "Cn0": P["C_n_0"],
+         "Cnb": P["C_n_beta"], "cnp": P["C_n_p"] * b, "cnr": P["C_n_r"] * b, "Cnda": P["C_n_delta_a"],
+         "kprop": 0.5 * rho * P["S_prop"] * P["C_prop"], "kmotor": P["k_motor"], "ktp": P["k_T_P"] * P["k_Omega"] ** 2}
+    return np.array([v[n] for n in AERO_NAMES], dtype=np.float64)
+
+
+def device_aero(vec):
+    """[N, 49] host copy of the envs' current force / moment constants."""
+    L = vec.layout
+    return np.stack([_np(vec.word(L.aero + i)) for i in range(len(AERO_NAMES))], axis=1).astype(np.float64)
+
+
+def check_model_randomisation(vec, oracles, steps, action_fn):
+    """Resets, then steps through at least one auto-reset: after every (re)start the constants in the arena equal those of
+    the oracle env's sampled table (1e-5: float32 sampling and derivation vs float64), and they change between episodes."""
+    vec.reset()
+    for o in oracles:
+        o.reset()
+    rho, g = oracles[0].simulator.rho, oracles[0].simulator.g
+    first = device_aero(vec)
+    want = np.stack([aero_from_params(o.simulator.params, rho, g) for o in oracles])
+    close(first, want, 1e-5, 1e-7, "per-env constants after reset")
+    assert np.abs(first[0] - first[1]).max() > 0, "two envs drew the same aircraft"
+    changed = 0
+    for t in range(steps):
+        a = action_fn(t)
+        out = vec.step(a)
+        done = _np(out[2]).astype(bool)
+        for i, o in enumerate(oracles):
+            _, _, d, _ = o.step(np.asarray(a[i], dtype=np.float64))
+            assert bool(d) == bool(done[i]), (t, i)
+            if d:
+                o.reset()
+        if done.any():
+            now = device_aero(vec)
+            want = np.stack([aero_from_params(o.simulator.params, rho, g) for o in oracles])
+            close(now, want, 1e-5, 1e-7, "per-env constants after the auto-reset at step {}".format(t))
+            changed += int((np.abs(now - first).max(axis=1) > 0)[done].sum())
+            first = now
+    assert changed > 0
+    return changed

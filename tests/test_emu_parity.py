@@ -108,3 +108,17 @@ def test_prepared_draw_is_discarded_when_ranges_or_seed_change(emu_lib):
                 ob = o.reset()
             np.testing.assert_allclose(obs[i], ob, rtol=4e-3, atol=4e-3, err_msg="step {} env {}".format(t, i))
     vec.close()
+
+
+@pytest.mark.parametrize("kind", ["model_gaussian", "model_uniform"])
+def test_model_randomisation_constants_follow_the_oracle(emu_lib, kind):
+    """simulator["model"] (fixed_wing.py:532-559): every env flies its own aircraft, re-sampled at every reset."""
+    cfg = configs.reference_like(kind)
+    n = 6
+    ckw = {"steps_max": 12}
+    vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, seed=3, as_numpy=True, _backend=HostBackend(), _lib_path=emu_lib)
+    assert vec.layout.aero_next > vec.layout.aero > 0
+    orc = parity.make_oracles(cfg, n, 3, config_kw=ckw)
+    acts = _actions(9, 30, n, scale=1.0)
+    assert parity.check_model_randomisation(vec, orc, 30, lambda t: acts[t]) >= n
+    vec.close()

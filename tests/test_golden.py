@@ -68,6 +68,8 @@ def test_oracle_reproduces_reference_vectors(path):
         parity.close(obs, _arr(ep["reset_obs"]), 1e-11, 1e-11, "reset obs")
         for k, v in ep["reset_target"].items():
             parity.close(env.target[k], v, 1e-12, 1e-12, "reset target")
+        for k, v in ep.get("sim_params", {}).items():   # simulator["model"]: the aircraft sampled for this episode
+            parity.close(float(env.simulator.params[k]), v, 1e-13, 1e-13, "sampled parameter " + k)
         for t, st in enumerate(ep["steps"]):
             obs, rew, done, info = env.step(np.array(st["action"]))
             what = "{} step {}".format(os.path.basename(path), t)

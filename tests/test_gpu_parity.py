@@ -305,3 +305,39 @@ def test_hundred_step_rollout_state_parity():
     print("100-step rollout: worst scaled error {:.2e}, worst pure-relative {:.2e}, {} of {} envs alive".format(worst, worst_rel, int(alive.sum()), n))
     assert alive.sum() > n // 2
     vec.close()
+
+
+@pytest.mark.parametrize("kind", ["model_gaussian", "model_uniform"])
+def test_model_randomisation_on_gpu(kind):
+    """simulator["model"] (sample_simulator_parameters, fixed_wing.py:532-559): per-env aircraft re-sampled at every reset
+    (k_model_draw + the per-lane constants of the physics), generic AND run-time specialised kernels; the sampled constants
+    equal the oracle's (1e-5), respect the clip interval and have the configured spread over 4 096 envs."""
+    cfg = configs.reference_like(kind)
+    ckw = {"steps_max": 12}
+    n = 6
+    acts = np.random.default_rng(9).uniform(-1, 1, size=(30, n, 3)).astype(np.float32)
+    for spec in (False, True):
+        vec = _vec(cfg, n, config_kw=ckw, seed=3, as_numpy=True, specialize=spec)
+        assert (vec.spec_index >= 0) == spec
+        orc = parity.make_oracles(cfg, n, 3, config_kw=ckw)
+        assert parity.check_model_randomisation(vec, orc, 30, lambda t: acts[t]) >= n
+        vec.close()
+    # distribution over many envs
+    big = _vec(cfg, 4096, config_kw=ckw, seed=5, as_numpy=True)
+    big.reset()
+    A = parity.device_aero(big)
+    col = {nme: A[:, i] for i, nme in enumerate(parity.AERO_NAMES)}
+    mass = 1.0 / col["inv_mass"]
+    cla = col["CLa"]
+    if kind == "model_gaussian":
+        assert np.all(np.abs(mass / 3.364 - 1) <= 0.05 + 1e-5)                  # relative clip 0.05 on the mass
+        assert np.all(np.abs(cla / 4.02 - 1) <= 0.2 + 1e-5)                     # model-wide relative clip 0.2
+        assert abs(cla.mean() / 4.02 - 1) < 0.01 and 0.075 < cla.std() / 4.02 < 0.1   # N(., 0.1) truncated at 2 sigma: 0.088
+        # negative original with a relative clip: the interval is upside down and numpy's clip order pins the value to its
+        # upper end, original * (1 + clip), for every env (fixed_wing.py:551-554)
+        np.testing.assert_allclose(col["cmq"] / 2.1, -1.3047 * 1.2, rtol=1e-5)
+    else:
+        assert np.all(np.abs(cla - 4.02) <= 0.5 + 1e-4) and 0.27 < cla.std() < 0.31   # U(-0.5, 0.5): std 0.289
+        assert np.all(np.abs(col["CDp"] - 0.0115) <= 0.002 + 1e-6)
+    assert np.all(col["CY0"] == 0) and np.all(col["cDq"] == 0)                  # original 0: never sampled
+    big.close()
