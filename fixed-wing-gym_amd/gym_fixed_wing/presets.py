@@ -72,6 +72,11 @@ def preset(kind):
         for st in cfg["simulator"]["states"]:
             if st["name"].startswith("omega"):
                 st["constraint_min"], st["constraint_max"] = None, None
+        # the shipped dev file lists the body velocities a second time; entries are applied in order, the later ones win
+        cfg["simulator"]["states"] += [{"name": "velocity_u", "init_min": 11, "init_max": 28},
+                                       {"name": "velocity_v", "init_min": -5, "init_max": 5},
+                                       {"name": "velocity_w", "init_min": -5, "init_max": 5}]
+        cfg["render"]["plot_action"] = False
         return cfg
     raise KeyError(kind)
 
