@@ -57,6 +57,29 @@ def test_gym_rollout_matches_oracle(case):
     vec.close()
 
 
+SPLIT_END_CASES = ["cnn_step2_turb", "default_short", "fail_prone", "success_done", "dynamic_targets", "model_gaussian"]
+
+
+@pytest.mark.parametrize("case", [c for c in configs.CASES if c[0] in SPLIT_END_CASES], ids=SPLIT_END_CASES)
+def test_two_wave_kernel_matches_oracle_through_episode_ends(case):
+    """The specialised two-wave kernel (k_step2) with its episode-end machinery -- prepared draws, requests issued before the
+    barrier for foreseen ends, padding rows built before the barrier, failure / success ends -- against the oracle.  The
+    build-time presets run 2 000-step episodes; here the same kernel source is specialised at run time (jit.py) for
+    short-episode configurations so that every env ends several episodes inside the comparison."""
+    name, kind, ckw, skw = case
+    cfg = configs.reference_like(kind)
+    n, steps = 70, 130                      # two workgroups, the second one partially filled
+    vec = _vec(cfg, n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True, specialize=True)
+    assert vec.spec_index >= 0
+    orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
+    acts = _actions(5, steps, n, scale=1.8 if name == "fail_prone" else 1.3)
+    res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3)
+    if ckw and "steps_max" in ckw:
+        assert res["episodes"] >= n
+    print(name, res)
+    vec.close()
+
+
 @pytest.mark.parametrize("case", [c for c in configs.CASES if c[1] == "cnn"], ids=[c[0] + "_dense" for c in configs.CASES if c[1] == "cnn"])
 def test_gym_rollout_matches_oracle_dense_batch(case):
     """Lagged matrix observations default to the row log (zero-copy window); the dense [N][5][12] batch written by the
