@@ -472,11 +472,12 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                     val = (g & 8u) ? F.value : 0.f;
                 }
             }
+            const float inv_scaling = c.randomize_scaling ? E.fscale[f] : F.inv_scaling;   // per env and episode / fixed
             if (F.fclass == FWG_FC_LINEAR) {
-                val = fabsf(val) * F.inv_scaling;
+                val = fabsf(val) * inv_scaling;
                 if (F.has_max) val = fminf(val, F.max);
             } else {
-                val = val * val * F.inv_scaling;
+                val = val * val * inv_scaling;
             }
             val *= F.sign;
             const int fc = F.fclass;
@@ -800,11 +801,30 @@ __global__ __launch_bounds__(FWG_WAVE) void k_model_draw(const DevCfg* __restric
     const long e = (long)blockIdx.x * FWG_WAVE + lane;
     if (e >= A.N) return;
     const unsigned episode_new = f2u(CGROUP(A.S, A.N, (c.L.cold >> 2), e).w) + 1u;
+    const unsigned env_id = (unsigned)(A.env_base + e);
+    if (c.randomize_scaling) {   // reward.randomize_scaling (fixed_wing.py:330-334): 1 / U(low, high) per listed factor
+        const float4 tag = CGROUP(A.S, A.N, (c.L.fscale_next >> 2) + FWG_MAX_FACTORS / 4, e);
+        if (!(f2u(tag.x) == episode_new && f2u(tag.y) == dp->generation)) {
+            for (int g = 0; g < FWG_MAX_FACTORS / 4; ++g) {
+                float v[4];
+                for (int i = 0; i < 4; ++i) {
+                    const int f = 4 * g + i;
+                    v[i] = f < c.n_factors ? c.factor[f].inv_scaling : 1.f;
+                    if (f < c.n_factors && dp->fs_hi[f] > dp->fs_lo[f]) {
+                        const u4 b = philox4x32(env_id, episode_new, (unsigned)f, FWG_STREAM_REWARD_SCALE, A.seed_lo, A.seed_hi);
+                        v[i] = 1.f / (dp->fs_lo[f] + (dp->fs_hi[f] - dp->fs_lo[f]) * u01(b.x));
+                    }
+                }
+                GROUP(A.S, A.N, (c.L.fscale_next >> 2) + g, e) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            GROUP(A.S, A.N, (c.L.fscale_next >> 2) + FWG_MAX_FACTORS / 4, e) = make_float4(u2f(episode_new), u2f(dp->generation), 0.f, 0.f);
+        }
+    }
+    if (c.model_n <= 0) return;
     const float4 tag = CGROUP(A.S, A.N, (c.L.aero_next >> 2) + FWG_AERO_GROUPS - 1, e);
     if (f2u(tag.y) == episode_new && f2u(tag.z) == dp->generation) return;
     float* P = tab + lane;
     for (int i = 0; i < FWG_N_PARAMS; ++i) P[i * FWG_WAVE] = m.nominal[i];
-    const unsigned env_id = (unsigned)(A.env_base + e);
     for (int i = 0; i < m.n; ++i) {
         const u4 b = philox4x32(env_id, episode_new, (unsigned)i, FWG_STREAM_MODEL, A.seed_lo, A.seed_hi);
         const float nominal = m.nominal[m.idx[i]];
@@ -951,6 +971,8 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
     if (c.model_n < 0 || c.model_n > FWG_N_PARAMS) { *why = "model_n out of range"; return -1; }
     L->aero = o; o += c.model_n > 0 ? FWG_AERO_GROUPS * 4 : 0;        // per-env force/moment constants: this episode's ...
     L->aero_next = o; o += c.model_n > 0 ? FWG_AERO_GROUPS * 4 : 0;   // ... and the next one's (k_model_draw)
+    L->fscale = o; o += c.randomize_scaling ? FWG_MAX_FACTORS : 0;             // per-env 1 / scaling of the reward factors ...
+    L->fscale_next = o; o += c.randomize_scaling ? FWG_MAX_FACTORS + 4 : 0;    // ... and the next episode's, + tag group
     L->window = window;
     L->rows = o;
     return use_cmd;
@@ -1013,6 +1035,14 @@ static int lower_config(const fwg_config& c, DevCfg* d, DynCfg* dy, std::string*
         dy->model.idx[i] = c.model_idx[i];
         dy->model.var[i] = f32(c.model_var[i]);
         dy->model.lo[i] = lim32(c.model_clip_lo[i], true); dy->model.hi[i] = lim32(c.model_clip_hi[i], false);
+    }
+    d->randomize_scaling = c.randomize_scaling ? 1 : 0;
+    for (int f = 0; f < FWG_MAX_FACTORS; ++f) {
+        const bool listed = c.randomize_scaling && f < c.n_factors;
+        dy->fs_lo[f] = f32(listed ? c.factor_scaling_low[f] : 1.0); dy->fs_hi[f] = f32(listed ? c.factor_scaling_high[f] : 1.0);
+        if (listed && !(c.factor_scaling_low[f] > 0.0 && c.factor_scaling_high[f] >= c.factor_scaling_low[f])) {
+            *why = "factor_scaling_low/high must satisfy 0 < low <= high"; return -1;
+        }
     }
     d->con_mask = 0;
     for (int v = 0; v < FWG_N_VARS; ++v) {
@@ -1216,7 +1246,7 @@ static void base_args(const fwg_handle* h, KArgs* A) {
 static void observer_args(fwg_handle* h, KArgs* A);   // defined with the rollout head below
 // simulator.model: before any launch that may reset an env, every env has the parameter set of its next episode prepared
 static void launch_model_draw(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
-    if (h->h.model_n <= 0) return;
+    if (h->h.model_n <= 0 && !h->h.randomize_scaling) return;
     hipLaunchKernelGGL(k_model_draw, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), FWG_N_PARAMS * FWG_WAVE * sizeof(float), stream, h->d_cfg, h->d_dyn, A);
 }
 

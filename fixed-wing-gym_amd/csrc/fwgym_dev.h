@@ -19,6 +19,7 @@
 #define FWG_STREAM_OBS_NOISE 4u
 #define FWG_STREAM_INIT_NOISE 5u
 #define FWG_STREAM_MODEL 7u              // simulator.model draws (6 = the rollout head's policy noise)
+#define FWG_STREAM_REWARD_SCALE 8u       // reward.randomize_scaling draws
 
 struct DevObs { int type, src, window, norm; float mean, inv_var; };
 struct DevTarget { int var, cls, wrap, has_delta, has_bound; float bound; };
@@ -37,6 +38,7 @@ struct DynCfg {
     DynTarget target[FWG_MAX_TARGETS];
     unsigned generation;   // bumped whenever what a reset draw depends on changes (ranges, seed): prepared draws are then discarded
     ModelCfg model;
+    float fs_lo[FWG_MAX_FACTORS], fs_hi[FWG_MAX_FACTORS];   // reward.randomize_scaling: scaling ~ U(lo, hi) where lo < hi
 };
 // The constants of the force / moment model, pre-combined from the parameter table (same names and order as the block at
 // the head of DevCfg).  One set for all envs (DevCfg) unless simulator.model re-samples the table per env and episode: then
@@ -131,6 +133,7 @@ struct DevCfg {
     int obs_log;   // rows per parity of the observation row log (0 = dense observation batch)
     float rise_low, rise_high;
     int model_n;   // > 0: simulator.model -- per-env force/moment constants (L.aero), re-sampled at every reset
+    int randomize_scaling;   // reward.randomize_scaling -- per-env reward scalings (L.fscale), re-sampled at every reset
     fwg_layout L;
 };
 

@@ -311,6 +311,7 @@ struct Env {
     unsigned settle[2];
     float perr[3];
     float sdcmd;
+    float fscale[FWG_MAX_FACTORS];    // reward.randomize_scaling: this env's 1 / scaling per reward factor (read-only in the step)
     float was_emin[3], was_emax[3];   // values as loaded: the rarely-changing groups are written back only when they changed
     unsigned was_rise[3];
 };
@@ -419,6 +420,15 @@ __device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restric
 #pragma unroll
     for (int g = 0; g < 9; ++g)
         if (g < 2 || (g < 8 && c.metrics) || (g == 8 && c.reward_potential)) q[g] = load_group(S, N, g0 + g, e);
+    if (c.randomize_scaling) {
+#pragma unroll
+        for (int g = 0; g < FWG_MAX_FACTORS / 4; ++g) {
+            if (4 * g < c.n_factors) {
+                const float4 v = CGROUP(S, N, (c.L.fscale >> 2) + g, e);
+                E.fscale[4 * g] = v.x; E.fscale[4 * g + 1] = v.y; E.fscale[4 * g + 2] = v.z; E.fscale[4 * g + 3] = v.w;
+            }
+        }
+    }
     E.tgt[0] = q[0].x; E.tgt[1] = q[0].y; E.tgt[2] = q[0].z;
     E.steps = f2u(q[0].w) & 0xFFFFu; E.sft = f2u(q[0].w) >> 16;
     E.flags = f2u(q[1].x); E.wcnt = f2u(q[1].y); E.gcnt[0] = f2u(q[1].z); E.gcnt[1] = f2u(q[1].w);
@@ -1098,6 +1108,11 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
 #pragma unroll
         for (int g = 0; g < FWG_AERO_GROUPS; ++g)
             GROUP(A.S, A.N, (c.L.aero >> 2) + g, e) = CGROUP(A.S, A.N, (c.L.aero_next >> 2) + g, e);
+    }
+    if (c.randomize_scaling) {   // reward.randomize_scaling: likewise (the values are read by the following steps only)
+#pragma unroll
+        for (int g = 0; g < FWG_MAX_FACTORS / 4; ++g)
+            GROUP(A.S, A.N, (c.L.fscale >> 2) + g, e) = CGROUP(A.S, A.N, (c.L.fscale_next >> 2) + g, e);
     }
     E.episode = D.episode;
     E.steps = 0u;

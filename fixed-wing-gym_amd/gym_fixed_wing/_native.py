@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 15
+FWG_ABI_VERSION = 16
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -111,13 +111,15 @@ class Config(C.Structure):
         ("rise_low", C.c_double), ("rise_high", C.c_double),
         ("model_n", C.c_int32), ("model_dist", C.c_int32), ("model_idx", C.c_int32 * N_PARAMS), ("pad_model_", C.c_int32),
         ("model_var", C.c_double * N_PARAMS), ("model_clip_lo", C.c_double * N_PARAMS), ("model_clip_hi", C.c_double * N_PARAMS),
+        ("randomize_scaling", C.c_int32), ("pad_rs_", C.c_int32),
+        ("factor_scaling_low", C.c_double * MAX_FACTORS), ("factor_scaling_high", C.c_double * MAX_FACTORS),
     ]
 
 
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ["rows", "sim", "cold", "derived", "gym", "tprop", "goal", "act_ring", "cmd_ring", "end_ring", "lag_ring",
-                 "window", "lag_depth", "lag_groups", "draw", "aero", "aero_next"]]
+                 "window", "lag_depth", "lag_groups", "draw", "aero", "aero_next", "fscale", "fscale_next"]]
 
 
 class ActorWeights(C.Structure):

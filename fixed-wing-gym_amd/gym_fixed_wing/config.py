@@ -255,8 +255,6 @@ class EnvConfig(object):
         cfg = self.cfg
         if cfg.get("integration_window", 0):
             raise NotImplementedError("integration_window > 0 (integrator observations / int_error rewards)")
-        if cfg["reward"].get("randomize_scaling", False):
-            raise NotImplementedError("reward.randomize_scaling")
         for key in cfg["simulator"]:
             if key not in ("states", "model"):
                 raise NotImplementedError("simulator.{} sampling".format(key))
@@ -475,7 +473,16 @@ class EnvConfig(object):
                 raise KeyError(f["function_class"])   # the reference fails the same way (terms[...] lookup)
             d.shaping = int(bool(f.get("shaping", False)))
             d.sign = float(np.sign(f.get("sign", -1)))
-            d.scaling = float(f["scaling"])
+            # reward.randomize_scaling (fixed_wing.py:330-334): a scaling given as [low, high] is drawn per env at every reset
+            c.randomize_scaling = int(bool(rcfg.get("randomize_scaling", False)))
+            if isinstance(f["scaling"], (list, tuple)):
+                if not c.randomize_scaling:
+                    raise ValueError("reward factor {}: a [low, high] scaling needs reward.randomize_scaling".format(f.get("name")))
+                lo, hi = float(f["scaling"][0]), float(f["scaling"][1])
+            else:
+                lo = hi = float(f["scaling"])
+            d.scaling = lo
+            c.factor_scaling_low[i], c.factor_scaling_high[i] = lo, hi
             d.has_max = int(f.get("max", None) is not None)
             d.max = float(f["max"]) if d.has_max else 0.0
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 15
+#define FWG_ABI_VERSION 16
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -195,6 +195,11 @@ typedef struct fwg_config {
     int32_t model_idx[FWG_N_PARAMS];
     int32_t pad_model_;
     double model_var[FWG_N_PARAMS], model_clip_lo[FWG_N_PARAMS], model_clip_hi[FWG_N_PARAMS];
+
+    /* ---- reward["randomize_scaling"] (fixed_wing.py:330-334): factors whose scaling is given as [low, high] get a
+     * scaling drawn U(low, high) for every env at every reset; low == high: the fixed factor[i].scaling */
+    int32_t randomize_scaling, pad_rs_;
+    double factor_scaling_low[FWG_MAX_FACTORS], factor_scaling_high[FWG_MAX_FACTORS];
 } fwg_config;
 
 /* The caller-owned state arena is an array of 16-byte GROUPS [rows/4][N] of 32-bit words: word w of env e lives at
@@ -217,6 +222,8 @@ typedef struct fwg_layout {
     int32_t draw;        /* 44 (+12 with linear/sinusoidal targets): the NEXT episode's reset draw, prepared ahead of time (cold) */
     int32_t aero;        /* 52 (model randomisation only): this episode's 49 force/moment constants of the env | - - - */
     int32_t aero_next;   /* 52: the next episode's | episode it is for, configuration generation, - */
+    int32_t fscale;      /* 16 (reward.randomize_scaling only): 1 / scaling of every reward factor, this episode */
+    int32_t fscale_next; /* 20: the next episode's | episode it is for, configuration generation, - - */
 } fwg_layout;
 
 /* rows of the metrics block (float32 [FWG_N_METRICS][N], valid where done) -- get_metric, fixed_wing.py:1095-1162 */

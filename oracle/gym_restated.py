@@ -10,8 +10,8 @@ reference's unbounded history lists), so that pinning it
 validates that reformulation.  The simulator underneath is oracle/pyfly_restated.PyFly (PARITY UNPINNED vs real PyFly).
 
 Unsupported (raise NotImplementedError, same as the product): target class attitude_angular (:474-478), sampler hook
-(:273-283), integrator observations / int_error reward (:708-711,:804-810), simulator "model" randomisation (:532-559),
-reward.randomize_scaling (:330-334), FixedWingAircraftGoal (:1165-1277).
+(:273-283), integrator observations / int_error reward (:708-711,:804-810), sampling of simulator keys other than states/model on
+the device path, FixedWingAircraftGoal (:1165-1277).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
@@ -56,6 +56,9 @@ class MTStream:
 
     def model_normal(self, i, loc, scale):
         return self.rs.normal(loc=loc, scale=scale)
+
+    def reward_scale_uniform(self, i, low, high):
+        return self.rs.uniform(low, high)
 
     def model_uniform(self, i, low, high):
         return self.rs.uniform(low=low, high=high)
@@ -118,6 +121,11 @@ class PhiloxStream:
         b = self._bits(self.episode, i, self.ph.STREAM_MODEL)
         return low + (high - low) * self.ph.u01(b[0])
 
+    # reward.randomize_scaling (k_model_draw): factor i of the episode, ctr = (env, episode, i, STREAM_REWARD_SCALE)
+    def reward_scale_uniform(self, i, low, high):
+        b = self._bits(self.episode, i, self.ph.STREAM_REWARD_SCALE)
+        return low + (high - low) * self.ph.u01(b[0])
+
     def init_noise(self, row):
         b = self._bits(self.steps, self.episode, self.ph.STREAM_INIT_NOISE, block=row // 4)
         return 2.0 * self.ph.u01(b[row % 4]) - 1.0
@@ -154,8 +162,7 @@ class FixedWingOracle:
         self.steps_max = cfg["steps_max"]
         if cfg.get("integration_window", 0):
             raise NotImplementedError("integration_window > 0")
-        if cfg["reward"].get("randomize_scaling", False):
-            raise NotImplementedError("reward.randomize_scaling")
+        self._rew_factors_init = copy.deepcopy(cfg["reward"]["factors"])   # fixed_wing.py:62
         self.goal_achieved = False           # sticky for the env's lifetime (fixed_wing.py:51,381-382)
         self.steps_count = None
         self.steps_for_target = None
@@ -429,6 +436,11 @@ class FixedWingOracle:
         self.cmd_prev = None
         self.cmd_var_sum = 0.0
         self.n_cmds = 0
+        if cfg["reward"].get("randomize_scaling", False):   # fixed_wing.py:330-334
+            for i, rew_factor in enumerate(self._rew_factors_init):
+                if isinstance(rew_factor["scaling"], list):
+                    low, high = rew_factor["scaling"]
+                    cfg["reward"]["factors"][i]["scaling"] = self.rng.reward_scale_uniform(i, low, high)
         return obs
 
     def _update_settle(self):

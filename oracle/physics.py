@@ -556,6 +556,7 @@ def box_muller(bits):
 # stream ids (ctr[3]) shared with the kernels
 STREAM_TURB, STREAM_RESET_STATE, STREAM_RESET_TARGET, STREAM_OBS_NOISE, STREAM_INIT_NOISE = 1, 2, 3, 4, 5
 STREAM_MODEL = 7   # simulator.model draws (6: the rollout head's policy noise)
+STREAM_REWARD_SCALE = 8   # reward.randomize_scaling draws
 
 
 def rng_bits(seed, env_ids, counter, stream, sub=0):

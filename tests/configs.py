@@ -54,6 +54,12 @@ def reference_like(kind):
             pars[3]["var"] = 0.5
             cfg["simulator"]["model"] = {"var_type": "absolute", "var": 0.002, "distribution": "uniform", "parameters": pars}
         return cfg
+    if kind == "reward_random_scaling":   # reward["randomize_scaling"]: [low, high] scalings drawn per env at every reset
+        r = cfg["reward"]
+        r["randomize_scaling"] = True
+        for f in r["factors"][:3]:
+            f["scaling"] = [0.5 * f["scaling"], 2.0 * f["scaling"]]
+        return cfg
     raise KeyError(kind)
 
 
@@ -84,6 +90,8 @@ CASES = [
     ("dynamic_targets", "dynamic_targets", {"steps_max": 80}, None),
     ("reward_mix", "reward_mix", {"steps_max": 60}, None),
     ("reward_mix_potential", "reward_mix", {"steps_max": 60, "reward": {"form": "potential"}}, None),
+    ("reward_random_scaling", "reward_random_scaling", {"steps_max": 45}, None),
+    ("reward_random_scaling_potential", "reward_random_scaling", {"steps_max": 45, "reward": {"form": "potential"}}, None),
     ("model_gaussian", "model_gaussian", {"steps_max": 45}, None),
     ("model_uniform", "model_uniform", {"steps_max": 45}, {"turbulence": True, "turbulence_intensity": "light"}),
 ]
