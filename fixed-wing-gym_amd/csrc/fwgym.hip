@@ -837,6 +837,11 @@ __global__ __launch_bounds__(FWG_WAVE) void k_model_draw(const DevCfg* __restric
         }
         P[m.idx[i] * FWG_WAVE] = x;
     }
+    for (int g = 0; 4 * g < m.n; ++g) {   // the sampled values themselves, in list order (get_simulator_parameters)
+        float r[4];
+        for (int i = 0; i < 4; ++i) r[i] = 4 * g + i < m.n ? P[m.idx[4 * g + i] * FWG_WAVE] : 0.f;
+        GROUP(A.S, A.N, (c.L.model_raw_next >> 2) + g, e) = make_float4(r[0], r[1], r[2], r[3]);
+    }
     Aero a;
     derive_aero<float>(LaneColumn{P}, m.rho, m.g, a);
     float v[4 * FWG_AERO_GROUPS];
@@ -973,6 +978,8 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
     L->aero_next = o; o += c.model_n > 0 ? FWG_AERO_GROUPS * 4 : 0;   // ... and the next one's (k_model_draw)
     L->fscale = o; o += c.randomize_scaling ? FWG_MAX_FACTORS : 0;             // per-env 1 / scaling of the reward factors ...
     L->fscale_next = o; o += c.randomize_scaling ? FWG_MAX_FACTORS + 4 : 0;    // ... and the next episode's, + tag group
+    L->model_raw = o; o += ((c.model_n + 3) / 4) * 4;                          // sampled values of the listed parameters ...
+    L->model_raw_next = o; o += ((c.model_n + 3) / 4) * 4;                     // ... and the next episode's
     L->window = window;
     L->rows = o;
     return use_cmd;

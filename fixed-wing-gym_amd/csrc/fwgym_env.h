@@ -1108,6 +1108,9 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
 #pragma unroll
         for (int g = 0; g < FWG_AERO_GROUPS; ++g)
             GROUP(A.S, A.N, (c.L.aero >> 2) + g, e) = CGROUP(A.S, A.N, (c.L.aero_next >> 2) + g, e);
+#pragma unroll
+        for (int g = 0; g < FWG_AERO_GROUPS; ++g)   // (FWG_N_PARAMS <= 4 FWG_AERO_GROUPS)
+            if (4 * g < c.model_n) GROUP(A.S, A.N, (c.L.model_raw >> 2) + g, e) = CGROUP(A.S, A.N, (c.L.model_raw_next >> 2) + g, e);
     }
     if (c.randomize_scaling) {   // reward.randomize_scaling: likewise (the values are read by the following steps only)
 #pragma unroll

@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 16
+FWG_ABI_VERSION = 17
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -119,7 +119,7 @@ class Config(C.Structure):
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ["rows", "sim", "cold", "derived", "gym", "tprop", "goal", "act_ring", "cmd_ring", "end_ring", "lag_ring",
-                 "window", "lag_depth", "lag_groups", "draw", "aero", "aero_next", "fscale", "fscale_next"]]
+                 "window", "lag_depth", "lag_groups", "draw", "aero", "aero_next", "fscale", "fscale_next", "model_raw", "model_raw_next"]]
 
 
 class ActorWeights(C.Structure):

@@ -300,5 +300,9 @@ class FixedWingAircraft(Env):
         res["target"] = {s: h[0] for s, h in self.history["target"].items()}
         return res
 
+    def get_simulator_parameters(self, normalize=True):
+        """reference fixed_wing.py:872-888: the aircraft parameters sampled for this episode (simulator["model"])."""
+        return list(self._vec.get_simulator_parameters(normalize)[0])
+
     def close(self):
         self._vec.close()

@@ -468,6 +468,31 @@ class FixedWingVecEnv(object):
         """Host copy {name: array[N]} of simulator variables (render, tests, checkpoints)."""
         return {n: np.array(self._mem.to_host(self.field(n))) for n in names}
 
+    def get_simulator_parameters(self, normalize=True):
+        """fixed_wing.py:872-888 for every env: [N, n] host array of the aircraft parameters simulator["model"] sampled for
+        the current episodes, in list order (parameters whose original value is 0 are never sampled and, for relative
+        spreads, left out as in the reference); normalised as (value - original) / var with the reference's signed var."""
+        model = self.cfg["simulator"].get("model", None)
+        if model is None:
+            return np.zeros((self.num_envs, 0), dtype=np.float64)
+        L, cols, j = self.layout, [], 0
+        for pa in model["parameters"]:
+            orig_file = float(self.env_config.params[pa["name"]])
+            sampled = orig_file != 0
+            val = np.array(self._mem.to_host(self.word(L.model_raw + j)), dtype=np.float64) if sampled \
+                else np.full(self.num_envs, orig_file)
+            j += int(sampled)
+            if normalize:   # (the reference records `original` in the config at the first reset: the parameter file's value)
+                var = pa.get("var", model["var"])
+                original_value = pa.get("original", orig_file)
+                if model.get("var_type", "relative") == "relative":
+                    if original_value == 0:
+                        continue
+                    var = var * original_value
+                val = (val - original_value) / var
+            cols.append(val)
+        return np.stack(cols, axis=1) if cols else np.zeros((self.num_envs, 0), dtype=np.float64)
+
     def reduce_success(self):
         """Local sums over the episodes finished since the last call (see fwg_reduce_success)."""
         out = (ctypes.c_float * nat.N_REDUCE)()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 16
+#define FWG_ABI_VERSION 17
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -224,6 +224,8 @@ typedef struct fwg_layout {
     int32_t aero_next;   /* 52: the next episode's | episode it is for, configuration generation, - */
     int32_t fscale;      /* 16 (reward.randomize_scaling only): 1 / scaling of every reward factor, this episode */
     int32_t fscale_next; /* 20: the next episode's | episode it is for, configuration generation, - - */
+    int32_t model_raw;      /* model_n rounded up to 4: the sampled values of the listed parameters, this episode (get_simulator_parameters, fixed_wing.py:872-888) */
+    int32_t model_raw_next; /* the same for the next episode (validity: the tag of aero_next) */
 } fwg_layout;
 
 /* rows of the metrics block (float32 [FWG_N_METRICS][N], valid where done) -- get_metric, fixed_wing.py:1095-1162 */

@@ -345,6 +345,23 @@ class FixedWingOracle:
             self.target[name] = init
             self.tprops[name] = vp
 
+    def get_simulator_parameters(self, normalize=True):
+        """fixed_wing.py:872-888."""
+        res = []
+        model = self.cfg["simulator"].get("model", {})
+        for param in model.get("parameters", []):
+            val = self.simulator.params[param["name"]]
+            if normalize:
+                var = param.get("var", model["var"])
+                if model.get("var_type", "relative") == "relative":
+                    original_value = param.get("original", self.simulator.params[param["name"]])
+                    if original_value == 0:
+                        continue
+                    var *= original_value
+                val = (val - param.get("original", 0)) / var
+            res.append(val)
+        return res
+
     def _sample_sim_attrs(self):
         # fixed_wing.py:523-570: keys other than "states" are sampled and set on the simulator at each reset
         for key, value in self.cfg["simulator"].items():

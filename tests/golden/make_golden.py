@@ -108,6 +108,7 @@ def run_case(ref, case, steps=140, episodes=3):
         e = {"state": st, "target": explicit_target, "reset_obs": obs, "reset_target": dict(env.target), "steps": []}
         if "model" in cfg["simulator"]:   # the aircraft this episode flies (sample_simulator_parameters, fixed_wing.py:532-559)
             e["sim_params"] = {k: float(v) for k, v in env.simulator.params.items() if not isinstance(v, str)}
+            e["sim_params_api"] = {"normalized": env.get_simulator_parameters(True), "raw": env.get_simulator_parameters(False)}
         while t < steps:
             a = acts[t]
             t += 1

@@ -196,6 +196,27 @@ def device_aero(vec):
     return np.stack([_np(vec.word(L.aero + i)) for i in range(len(AERO_NAMES))], axis=1).astype(np.float64)
 
 
+def check_parameter_api(vec, oracles, when):
+    """get_simulator_parameters (fixed_wing.py:872-888): the device keeps the sampled values in float32, so the raw values
+    agree to 1e-6 relative and the normalised ones to that resolution divided by the spread."""
+    raw_d, raw_o = vec.get_simulator_parameters(False), np.array([o.get_simulator_parameters(False) for o in oracles])
+    close(raw_d, raw_o, 1e-6, 1e-12, "get_simulator_parameters(False) " + when)
+    nrm_d, nrm_o = vec.get_simulator_parameters(True), np.array([o.get_simulator_parameters(True) for o in oracles])
+    assert nrm_d.shape == nrm_o.shape, (nrm_d.shape, nrm_o.shape)
+    model = vec.cfg["simulator"]["model"]
+    j = 0
+    for pa in model["parameters"]:
+        orig = float(vec.env_config.params[pa["name"]])
+        var = pa.get("var", model["var"])
+        if model.get("var_type", "relative") == "relative":
+            if orig == 0:
+                continue
+            var = var * orig
+        close(nrm_d[:, j], nrm_o[:, j], 0.0, 2e-6 * max(abs(orig), 1e-30) / abs(var) + 1e-9, "normalised {} {}".format(pa["name"], when))
+        j += 1
+    assert j == nrm_d.shape[1]
+
+
 def check_model_randomisation(vec, oracles, steps, action_fn):
     """Resets, then steps through at least one auto-reset: after every (re)start the constants in the arena equal those of
     the oracle env's sampled table (1e-5: float32 sampling and derivation vs float64), and they change between episodes."""
@@ -206,6 +227,7 @@ def check_model_randomisation(vec, oracles, steps, action_fn):
     first = device_aero(vec)
     want = np.stack([aero_from_params(o.simulator.params, rho, g) for o in oracles])
     close(first, want, 1e-5, 1e-7, "per-env constants after reset")
+    check_parameter_api(vec, oracles, "after reset")
     assert np.abs(first[0] - first[1]).max() > 0, "two envs drew the same aircraft"
     changed = 0
     for t in range(steps):
@@ -221,6 +243,7 @@ def check_model_randomisation(vec, oracles, steps, action_fn):
             now = device_aero(vec)
             want = np.stack([aero_from_params(o.simulator.params, rho, g) for o in oracles])
             close(now, want, 1e-5, 1e-7, "per-env constants after the auto-reset at step {}".format(t))
+            check_parameter_api(vec, oracles, "after the auto-reset at step {}".format(t))
             changed += int((np.abs(now - first).max(axis=1) > 0)[done].sum())
             first = now
     assert changed > 0

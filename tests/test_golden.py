@@ -70,6 +70,9 @@ def test_oracle_reproduces_reference_vectors(path):
             parity.close(env.target[k], v, 1e-12, 1e-12, "reset target")
         for k, v in ep.get("sim_params", {}).items():   # simulator["model"]: the aircraft sampled for this episode
             parity.close(float(env.simulator.params[k]), v, 1e-13, 1e-13, "sampled parameter " + k)
+        if "sim_params_api" in ep:   # get_simulator_parameters (fixed_wing.py:872-888)
+            parity.close(np.array(env.get_simulator_parameters(True)), _arr(ep["sim_params_api"]["normalized"]), 1e-12, 1e-12, "normalised parameters")
+            parity.close(np.array(env.get_simulator_parameters(False)), _arr(ep["sim_params_api"]["raw"]), 1e-13, 1e-13, "raw parameters")
         for t, st in enumerate(ep["steps"]):
             obs, rew, done, info = env.step(np.array(st["action"]))
             what = "{} step {}".format(os.path.basename(path), t)
