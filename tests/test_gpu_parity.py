@@ -364,3 +364,46 @@ def test_model_randomisation_on_gpu(kind):
         assert np.all(np.abs(col["CDp"] - 0.0115) <= 0.002 + 1e-6)
     assert np.all(col["CY0"] == 0) and np.all(col["cDq"] == 0)                  # original 0: never sampled
     big.close()
+
+
+def test_randomised_envs_under_graph_replay_equal_eager_launches():
+    """k_model_draw (aircraft parameters, reward scalings of the NEXT episode) is part of every captured step: a replayed
+    graph in which envs end episodes must leave exactly the state that eager launches leave."""
+    import copy
+    import torch
+    from gym_fixed_wing.vec_env import FixedWingVecEnv
+    cfg = configs.reference_like("model_gaussian")
+    cfg["reward"]["randomize_scaling"] = True
+    for f in cfg["reward"]["factors"][:2]:
+        f["scaling"] = [0.5 * f["scaling"], 2.0 * f["scaling"]]
+    kw = dict(config_kw={"steps_max": 11}, seed=4)
+    n = 300
+    eager = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=n, device=0, **copy.deepcopy(kw))
+    graphed = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=n, device=0, **copy.deepcopy(kw))
+    eager.reset(), graphed.reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    acts = [torch.rand((n, 3), device="cuda", generator=gen) * 2 - 1 for _ in range(8)]
+    graphed.set_graph_mode(True)
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for a in acts[:2]:
+            graphed.step_device(a)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    for a in acts[:2]:
+        eager.step_device(a)
+    g = torch.cuda.CUDAGraph()
+    graphed.capture_begin()
+    with torch.cuda.graph(g):
+        for a in acts:
+            graphed.step_device(a)
+    graphed.capture_end()
+    for rep in range(5):   # 42 steps: every env ends three episodes inside the replays
+        g.replay(); graphed.note_replayed_steps(8); torch.cuda.synchronize()
+        for a in acts:
+            oe, re_, de = eager.step_device(a)
+        # (bit patterns: the arena holds integers and tags in float words, NaN as floats)
+        assert torch.equal(eager.state.view(torch.int32), graphed.state.view(torch.int32)), "replay {}".format(rep)
+        assert torch.equal(oe, graphed._obs) and torch.equal(re_, graphed._rew)
+    A = parity.device_aero(graphed)
+    assert np.abs(A - A[0]).max() > 0
+    eager.close(), graphed.close()
