@@ -122,3 +122,30 @@ def test_model_randomisation_constants_follow_the_oracle(emu_lib, kind):
     acts = _actions(9, 30, n, scale=1.0)
     assert parity.check_model_randomisation(vec, orc, 30, lambda t: acts[t]) >= n
     vec.close()
+
+
+def test_randomised_parameters_do_not_depend_on_the_sharding(emu_lib):
+    """The draws are keyed by the GLOBAL env id: two shards (env_id_base 0 and 4) hold the same aircraft and reward scalings,
+    step for step, as one env holding all of them."""
+    cfg = configs.reference_like("model_uniform")
+    cfg["reward"]["randomize_scaling"] = True
+    cfg["reward"]["factors"][0]["scaling"] = [1.0, 9.0]
+    ckw = {"steps_max": 7}
+    mk = lambda n, base: FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, seed=21, as_numpy=True, env_id_base=base,
+                                         _backend=HostBackend(), _lib_path=emu_lib)
+    whole, lo, hi = mk(7, 0), mk(4, 0), mk(3, 4)
+    for v in (whole, lo, hi):
+        v.reset()
+    acts = _actions(2, 20, 7, scale=1.0)
+    for t in range(20):
+        ow, rw, dw, _ = whole.step(acts[t])
+        ol, rl, dl, _ = lo.step(acts[t][:4])
+        oh, rh, dh, _ = hi.step(acts[t][4:])
+        np.testing.assert_array_equal(np.concatenate([ol, oh]), ow)
+        np.testing.assert_array_equal(np.concatenate([rl, rh]), rw)
+        np.testing.assert_array_equal(np.concatenate([dl, dh]), dw)
+    np.testing.assert_array_equal(np.concatenate([parity.device_aero(lo), parity.device_aero(hi)]), parity.device_aero(whole))
+    L = whole.layout
+    np.testing.assert_array_equal(np.concatenate([parity._np(lo.word(L.fscale)), parity._np(hi.word(L.fscale))]), parity._np(whole.word(L.fscale)))
+    for v in (whole, lo, hi):
+        v.close()
