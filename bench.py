@@ -412,7 +412,7 @@ def main():
                        "success_allgather_every": chunk if graphs and chunk else args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_step + k_actor_act" if fused else "k_step",
+                         "kernel": ("k_step2" if vec.spec_index >= 0 and os.environ.get("FWGYM_SPLIT", "1") != "0" else "k_step") + (" + k_actor_act" if fused else ""),
                          "kernel_ms": wall / args.steps * 1e3, "kernel_ms_hip_events": event_ms,
                          "clock": "wall clock of the timed region (the same interval as `value`)",
                          "algorithmic_bytes_per_env_step": ALG_BYTES[args.workload], "source_hash": source_hash()},
