@@ -341,9 +341,9 @@ def main():
     if not args.emulate:
         torch.cuda.synchronize(dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
     if not args.emulate:
-        ev0.record()
+        ev0.record()           # (GPU-side bracket for kernel_ms_hip_events; enqueued on the idle, synchronised stream)
+    t0 = time.perf_counter()
     run(chunk, replays, singles, 0)
     if not args.emulate:
         ev1.record()
