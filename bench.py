@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALG_BYTES = {"c3": 937, "c4": 937, "c2": 417, "c5": 409}   # algorithmic bytes per env-step, SURVEY.md section 8(d)
 MAX_CHUNK = 256                # steps per captured graph; the success reduction runs once per chunk
 STEADY_STATE_STEPS = 300       # untimed launches before the W warm-up steps (clocks / caches / code objects), disclosed in the line
+SIDE_STEPS = 400               # timed steps of every side measurement (steady state, observation consumer, other configurations)
 
 
 def workload(name):
@@ -83,15 +84,21 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(wl, seconds):
+def cpu_baseline(wl, seconds, max_procs=0):
     import multiprocessing as mp
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    present = os.cpu_count() or 1
+    cores = max(1, present if max_procs <= 0 else min(present, max_procs))
+    try:   # one interpreter + NumPy/SciPy per process: stay well inside the host's free memory
+        import psutil
+        cores = max(1, min(cores, int(psutil.virtual_memory().available // (512 << 20))))
+    except Exception:
+        pass
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(wl, seconds, 100 + i) for i in range(cores)])
     total = sum(n / dt for n, dt in res)
-    out = {"value": total, "unit": "env-steps/s", "cores": cores, "kind": "port",
-           "sample": "{} oracle processes (float64 NumPy restatement, 1 env each, same workload config) x {:.0f} s, "
+    out = {"value": total, "unit": "env-steps/s", "cores": cores, "cores_present": present, "kind": "port",
+           "sample": "{} oracle processes (one per host core; float64 NumPy restatement, 1 env each, same workload config) x {:.0f} s, "
                      "{} env-steps in total".format(cores, seconds, sum(n for n, _ in res))}
     try:   # second CPU number: the scalar C++ loop of oracle/cpu_step.cpp over OpenMP threads, when built
         from oracle import cpu_native
@@ -138,6 +145,7 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
     ap.add_argument("--total-envs", type=int, default=0, help="fixed TOTAL number of envs sharded over the ranks (strong scaling)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="oracle processes of the CPU baseline (default 0 = one per host core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--obs-layout", default="auto", choices=["auto", "dense", "log"],
                     help="'auto' (default) = the env's default: lagged matrix observations are kept once as a row log and "
@@ -154,7 +162,8 @@ def main():
                          "timed steps -- the steady state of a long run.  Default 0: all envs start together as a fresh VecEnv "
                          "does (no episode ends inside a short timed region); the steady state is then measured as well and "
                          "reported as `steady_state` next to `value` (1 GPU, env-step workloads)")
-    ap.add_argument("--no-steady-state", action="store_true", help="skip the `steady_state` side measurement")
+    ap.add_argument("--no-side", "--no-steady-state", dest="no_side", action="store_true",
+                    help="skip the side measurements (steady state, observation consumer, dense layout, c2, integrator 4x64)")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: host-emulation build of the kernels + gloo, tiny batch (exercises the launcher, the "
                          "sharding and the collective on a machine without GPUs; the numbers are not measurements)")
@@ -213,62 +222,129 @@ def main():
         kw = {"device": local}
         if args.lib:
             kw["_lib_path"] = args.lib
-    # derived_views=False: the rollout loop never reads roll/pitch/... back from the arena (they are in the
-    # observations), so the kernel does not write those host-view rows
-    vec = FixedWingVecEnv(cfg, num_envs=n_envs, config_kw=ckw, sim_config_kw=skw, seed=0, env_id_base=first,
-                          auto_reset=True, derived_views=False, obs_log_rows=log_rows, **kw)
-    vec.reset()
-    def stagger_ages(parts):
-        """Resets 1/parts of the envs (a random subset: episode ends of a training run are not aligned with the env index)
-        every steps_max/parts steps (parts = steps_max: ages uniform over [0, steps_max))."""
-        import numpy as _np
-        gen0 = torch.Generator(device=dev)
-        gen0.manual_seed(99 + rank)
-        acts0 = [torch.rand((n_envs, 3), device=dev, generator=gen0) * 2 - 1 for _ in range(4)]
-        per = max(1, int(vec.cfg["steps_max"]) // parts)
-        perm = _np.random.RandomState(4321 + rank).permutation(n_envs)
-        for k in range(parts):
-            vec.reset(indices=_np.sort(perm[k::parts]))
-            for t in range(per):
-                vec.step_device(acts0[t % 4], want_obs=False)
-        torch.cuda.synchronize(dev)
-
-    if args.stagger and not args.emulate:
-        stagger_ages(args.stagger)
-    if args.emulate:
-        import numpy as np
-        rng = np.random.default_rng(1234 + rank)
-        pool = [rng.uniform(-1, 1, (n_envs, 3)).astype(np.float32) for _ in range(8)]
-        red_dev, gathered = None, None
-    else:
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(1234 + rank)
-        pool = [torch.rand((n_envs, 3), device=dev, generator=gen) * 2 - 1 for _ in range(32)]
-        red_dev = torch.zeros(16, device=dev)
-        gathered = torch.zeros(16 * world, device=dev) if use_dist else None
-    seen = {"episodes": 0.0, "ranks": world}
-
-    def reduce_step():
-        if args.emulate:
-            local_sums = torch.as_tensor(vec.reduce_success(), dtype=torch.float32)
-            if use_dist:
-                out = torch.empty(16 * world)
-                dist.all_gather_into_tensor(out, local_sums)
-                seen["episodes"] += float(out.view(world, 16)[:, 0].sum())
-            else:
-                seen["episodes"] += float(local_sums[0])
-            return
-        if fused or not graphs:
-            vec.reduce_success_device(red_dev)     # local sums, device to device, stream-ordered (no host sync)
-        # (graph mode: the local sums were taken by the last node of the replayed chunk)
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, red_dev)   # RCCL over xGMI: 64 B per rank
-
     fused = args.workload == "c5" and args.rollout != "none"
     graphs = not (args.eager or args.emulate)
+    seen = {"episodes": 0.0, "ranks": world}
+
+    class Runner(object):
+        """One env batch of this rank + its action pool, captured launch sequences and success reduction."""
+
+        def __init__(self, cfg, ckw, skw, n, first, log_rows, seed=0):
+            # derived_views=False: the rollout loop never reads roll/pitch/... back from the arena (they are in the
+            # observations), so the kernel does not write those host-view rows
+            self.vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, sim_config_kw=skw, seed=seed, env_id_base=first,
+                                       auto_reset=True, derived_views=False, obs_log_rows=log_rows, **kw)
+            self.vec.reset()
+            self.n = n
+            self.graphs = {}
+            if args.emulate:
+                import numpy as np
+                rng = np.random.default_rng(1234 + rank)
+                self.pool = [rng.uniform(-1, 1, (n, 3)).astype(np.float32) for _ in range(8)]
+                self.red_dev, self.gathered = None, None
+            else:
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(1234 + rank)
+                self.pool = [torch.rand((n, 3), device=dev, generator=gen) * 2 - 1 for _ in range(32)]
+                self.red_dev = torch.zeros(16, device=dev)
+                self.gathered = torch.zeros(16 * world, device=dev) if use_dist else None
+            self.graph_mode = False
+
+        def enable_graphs(self):
+            vec = self.vec
+            vec.set_graph_mode(True)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):            # lazy initialisation outside capture
+                vec.step_device(self.pool[0], want_obs=False), vec.step_device(self.pool[1], want_obs=False)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph_mode = True
+
+        def stagger_ages(self, parts):
+            """Resets 1/parts of the envs (a random subset: episode ends of a training run are not aligned with the env
+            index) every steps_max/parts steps (parts = steps_max: ages uniform over [0, steps_max)).  An even number of
+            steps in total, so that captured launch sequences keep their parity."""
+            import numpy as _np
+            vec = self.vec
+            per = max(1, int(vec.cfg["steps_max"]) // parts)
+            perm = _np.random.RandomState(4321 + rank).permutation(self.n)
+            for k in range(parts):
+                vec.reset(indices=_np.sort(perm[k::parts]))
+                for t in range(per):
+                    vec.step_device(self.pool[t % 4], want_obs=False)
+            if (parts * per) % 2:
+                vec.step_device(self.pool[0], want_obs=False)
+            torch.cuda.synchronize(dev)
+
+        def step_graph(self, n, offset, want_obs):
+            """hipGraph of n consecutive fwg_step launches on pool actions (n even) + the chunk's success sums.  A captured
+            sequence has the parity of the step counter baked in (double-buffered ring positions): one graph per parity."""
+            vec = self.vec
+            key = (n, offset % len(self.pool), vec.global_step & 1, bool(want_obs))
+            if key not in self.graphs:
+                g = torch.cuda.CUDAGraph()
+                parity = vec.capture_begin()
+                with torch.cuda.graph(g):
+                    for t in range(n):
+                        vec.step_device(self.pool[(offset + t) % len(self.pool)], want_obs=want_obs)
+                    vec.reduce_success_device(self.red_dev)   # device to device, part of the graph
+                vec.capture_end()
+                self.graphs[key] = (g, parity)
+            return self.graphs[key]
+
+        def reduce_step(self, in_graph):
+            vec = self.vec
+            if args.emulate:
+                local_sums = torch.as_tensor(vec.reduce_success(), dtype=torch.float32)
+                if use_dist:
+                    out = torch.empty(16 * world)
+                    dist.all_gather_into_tensor(out, local_sums)
+                    seen["episodes"] += float(out.view(world, 16)[:, 0].sum())
+                else:
+                    seen["episodes"] += float(local_sums[0])
+                return
+            if not in_graph:
+                vec.reduce_success_device(self.red_dev)     # local sums, device to device, stream-ordered (no host sync)
+            if use_dist:
+                dist.all_gather_into_tensor(self.gathered, self.red_dev)   # RCCL over xGMI: 64 B per rank
+
+        def run(self, c, r, s, offset=0, want_obs=False, rollout=None):
+            """r replays of a c-step chunk (+ one success reduction / all-gather each), then s single launches."""
+            vec = self.vec
+            done_steps = 0
+            for _ in range(r):
+                if rollout is not None:
+                    rollout(c).run()
+                    self.reduce_step(False)
+                else:
+                    g, parity = self.step_graph(c, offset, want_obs)
+                    vec.replay_check(parity)
+                    g.replay()
+                    vec.note_replayed_steps(c)
+                    self.reduce_step(True)
+                done_steps += c
+            for t in range(s):
+                vec.step_device(self.pool[(offset + done_steps + t) % len(self.pool)], want_obs=want_obs)
+            if s and not r:
+                self.reduce_step(False)
+
+        def time_replays(self, c, reps, want_obs=False):
+            """ms per step of reps replays of a c-step chunk (captured beforehand), wall clock around a drained device."""
+            self.run(c, 1, 0, 0, want_obs)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            self.run(c, reps, 0, 0, want_obs)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / (reps * c) * 1e3
+
+    R = Runner(cfg, ckw, skw, n_envs, first, log_rows)
+    vec = R.vec
+    if args.stagger and not args.emulate:
+        R.stagger_ages(args.stagger)
     chunk, replays, singles = plan_chunks(args.steps) if graphs else (0, 0, args.steps)
     wchunk, wreplays, wsingles = plan_chunks(args.warmup) if graphs else (0, 0, args.warmup)
-    rollout = None
+    get_rollout = None
     if fused:   # BASELINE configs[4]: PPO rollout loop with a random-init 64-64 MlpPolicy, end to end
         from gym_fixed_wing.actor import DeviceActor
         from gym_fixed_wing.rollout import FusedRollout, MlpPolicy
@@ -277,63 +353,29 @@ def main():
         torch.manual_seed(0)
         actor = DeviceActor.for_env(vec, seed=7, env_id_base=first)
         actor.load_policy(MlpPolicy(vec.obs_dim))
-        rollout = {}
+        rollouts = {}
 
         def get_rollout(n):
-            if n not in rollout:
-                rollout[n] = FusedRollout(vec, actor, n, graph=True)
-            return rollout[n]
-
-    step_graphs = {}
-
-    def step_graph(n, offset):
-        """hipGraph of n consecutive fwg_step launches on pool actions (n even)."""
-        key = (n, offset % len(pool))
-        if key not in step_graphs:
-            g = torch.cuda.CUDAGraph()
-            vec.capture_begin()
-            with torch.cuda.graph(g):
-                for t in range(n):
-                    vec.step_device(pool[(offset + t) % len(pool)], want_obs=False)
-                vec.reduce_success_device(red_dev)   # the chunk's success sums: device to device, part of the graph
-            vec.capture_end()
-            step_graphs[key] = g
-        return step_graphs[key]
+            if n not in rollouts:
+                rollouts[n] = FusedRollout(vec, actor, n, graph=True)
+            return rollouts[n]
 
     if graphs and not fused:
-        vec.set_graph_mode(True)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):            # lazy initialisation outside capture
-            vec.step_device(pool[0], want_obs=False), vec.step_device(pool[1], want_obs=False)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-
-    def run(c, r, s, offset):
-        """r replays of a c-step chunk (+ one success reduction / all-gather each), then s single launches."""
-        done_steps = 0
-        for _ in range(r):
-            if fused:
-                get_rollout(c).run()
-            else:
-                step_graph(c, offset).replay()
-                vec.note_replayed_steps(c)
-            done_steps += c
-            reduce_step()
-        for t in range(s):
-            vec.step_device(pool[(offset + done_steps + t) % len(pool)], want_obs=False)
-        if s and not r:
-            reduce_step()
+        R.enable_graphs()
 
     # untimed: bring the device to its steady state (power state, caches, code objects, graph instantiation), then the
-    # W warm-up steps of the contract
+    # W warm-up steps of the contract.  The untimed steps add up to an EVEN count, so that the timed region's launch
+    # sequences are the ones captured here (a captured sequence is tied to the parity of the step counter)
     extra = 0
     if graphs:
         pc = chunk if chunk else 2
         while extra < STEADY_STATE_STEPS:
-            run(pc, 1, 0, 0)
+            R.run(pc, 1, 0, rollout=get_rollout)
             extra += pc
-    run(wchunk, wreplays, wsingles, 0)
+    R.run(wchunk, wreplays, wsingles, rollout=get_rollout)
+    if graphs and (args.warmup % 2) and not fused:   # (one more single: the odd warm-up's last step flipped the parity)
+        R.run(0, 0, 1)
+        extra += 1
     if not args.emulate:
         torch.cuda.synchronize(dev)
     if use_dist:
@@ -344,7 +386,7 @@ def main():
     if not args.emulate:
         ev0.record()           # (GPU-side bracket for kernel_ms_hip_events; enqueued on the idle, synchronised stream)
     t0 = time.perf_counter()
-    run(chunk, replays, singles, 0)
+    R.run(chunk, replays, singles, rollout=get_rollout)
     if not args.emulate:
         ev1.record()
         torch.cuda.synchronize(dev)
@@ -359,23 +401,83 @@ def main():
         wall = float(tt.item())
     event_ms = ev0.elapsed_time(ev1) / args.steps if not args.emulate else None
 
-    steady = None
-    if (world == 1 and graphs and not fused and not args.stagger and not args.no_steady_state and chunk):
+    # ---- side measurements (same launches, other regimes / consumers / configurations); never part of `value`
+    sides = {}
+    side_ok = graphs and not fused and not args.emulate and not args.no_side
+    sc = chunk if chunk else 20
+    sreps = max(1, (SIDE_STEPS + sc - 1) // sc)
+    alg_b = ALG_BYTES[args.workload]
+
+    def side_entry(ms, n, alg=alg_b, **more):
+        e = {"ms_per_step": ms, "value": n / (ms * 1e-3), "unit": "env-steps/s", "roofline_frac": alg * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "steps": sreps * sc}
+        e.update(more)
+        return e
+
+    if side_ok and not args.stagger:
         # the same launches with episode ages spread uniformly (every step then has waves that end episodes, reset envs in
         # the kernel and pad early-episode observation rows): what a long run sees
-        stagger_ages(int(vec.cfg["steps_max"]))
-        run(chunk, 1, 0, 0)
-        torch.cuda.synchronize(dev)
-        reps = max(replays, (400 + chunk - 1) // chunk)
-        ts0 = time.perf_counter()
-        run(chunk, reps, 0, 0)
-        torch.cuda.synchronize(dev)
-        ts = (time.perf_counter() - ts0) / (reps * chunk)
-        steady = {"ms_per_step": ts * 1e3, "value": n_envs / ts, "unit": "env-steps/s",
-                  "roofline_frac": ALG_BYTES[args.workload] * n_envs / ts / 1e9 / HBM_PEAK_GBS, "steps": reps * chunk,
-                  "note": "episode ages uniform over [0, steps_max) (a random 1/steps_max of the envs reset at every step of an "
-                          "untimed steps_max-step run): about {} episode ends per step, scattered over the waves".format(
-                              round(n_envs / max(1, int(vec.cfg["steps_max"]))))}
+        R.stagger_ages(int(vec.cfg["steps_max"]))
+        per_step = round(n_envs / max(1, int(vec.cfg["steps_max"])))
+        sides["steady_state"] = side_entry(R.time_replays(sc, sreps), n_envs,
+            note="episode ages uniform over [0, steps_max) (a random 1/steps_max of the envs reset at every step of an untimed "
+                 "steps_max-step run): about {} episode ends per step, scattered over the waves".format(per_step))
+        if vec.obs_log_rows:
+            # an observation CONSUMER inside the replayed sequence: every step is followed by the gather of the dense
+            # [N][length][n_obs] batch out of the row log (what a torch policy reads under graph replay), steady state
+            sides["obs_delivered"] = side_entry(R.time_replays(sc, sreps, want_obs=True), n_envs,
+                note="steady state + fwg_obs_gather after every step inside the replayed graph: the dense observation batch a "
+                     "torch consumer reads (the HIP rollout head reads the row log in place instead: --workload c5)")
+    if side_ok and world == 1 and args.workload == "c3" and not args.stagger and not args.envs and not args.total_envs:
+        def side_env(name, wl_cfg, n, rows, alg, note, stag=True):
+            try:
+                S = Runner(wl_cfg[0], wl_cfg[1], wl_cfg[2], n, 0, rows)
+                S.enable_graphs()
+                S.run(sc, max(1, STEADY_STATE_STEPS // sc), 0)
+                fresh = S.time_replays(sc, sreps)
+                ent = side_entry(fresh, n, alg, note=note, specialised_kernel=S.vec.spec_index >= 0)
+                if stag:
+                    S.stagger_ages(int(S.vec.cfg["steps_max"]))
+                    st = S.time_replays(sc, sreps)
+                    ent["steady_state_ms_per_step"] = st
+                    ent["steady_state_roofline_frac"] = alg * n / (st * 1e-3) / 1e9 / HBM_PEAK_GBS
+                S.vec.close()
+                sides[name] = ent
+            except Exception as e:   # side figures never fail the line
+                sides[name] = {"error": str(e)[:300]}
+
+        if vec.obs_log_rows:
+            side_env("dense_layout", (cfg, ckw, skw), n_envs, 0, alg_b,
+                     "the same workload with the dense [N][5][12] observation batch written by every step (obs_log_rows=0)")
+        c2 = workload("c2")
+        side_env("c2", c2[:3], c2[3], None, ALG_BYTES["c2"], c2[4] + " (BASELINE configs[1]; 64 workgroups: launch-latency bound)", stag=False)
+        import copy as _copy
+        hi = _copy.deepcopy(skw)
+        hi["integrator"] = {"method": "rk4", "substeps": 4, "actuator_microsteps": 64}
+        side_env("integrator_4x64", (cfg, ckw, hi), n_envs, log_rows, alg_b,
+                 "the same workload with 4 RK4 sub-steps and 64 exact actuator micro-steps per env step: the first scheme clearly "
+                 "more accurate than the reference's adaptive RK45 at rtol 1e-3 (profiles/r02_convergence.json)", stag=False)
+    if side_ok and world > 1 and args.workload == "c3" and not args.envs and not args.total_envs:
+        # multi-GPU side figures: BASELINE configs[3] (32 768 envs per GPU) and the north-star point (65 536 envs in total)
+        ns_first, ns_n = fd.shard(65536, rank, world)
+        for name, n_side, first_side in (("c4_32768_per_gpu", 32768, rank * 32768), ("north_star_65536_total", ns_n, ns_first)):
+            try:
+                S = Runner(cfg, ckw, skw, n_side, first_side, log_rows)
+                S.enable_graphs()
+                S.run(sc, max(1, STEADY_STATE_STEPS // sc), 0)
+                torch.cuda.synchronize(dev); dist.barrier()
+                t1 = time.perf_counter()
+                S.run(sc, sreps, 0)
+                torch.cuda.synchronize(dev); dist.barrier()
+                tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ms = float(tt.item()) / (sreps * sc) * 1e3
+                sides[name] = {"ms_per_step": ms, "value": n_side * world / (ms * 1e-3) if name.startswith("c4") else 65536 / (ms * 1e-3),
+                               "unit": "env-steps/s", "envs_per_gpu": n_side, "steps": sreps * sc,
+                               "rccl_ranks": dist.get_world_size(), "success_allgather_every": sc}
+                S.vec.close()
+            except Exception as e:
+                sides[name] = {"error": str(e)[:300]}
 
     out = None
     if rank == 0:
@@ -412,13 +514,19 @@ def main():
                        "success_allgather_every": chunk if graphs and chunk else args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # what the fabric actually moved per second (measured bytes / the same interval): the row log neither
+                         # re-reads nor re-writes the lagged rows, so this is BELOW `achieved` (algorithmic bytes)
+                         "measured_GBs": (traffic * args.steps / wall / 1e9) if traffic else None,
+                         "frac_measured": (traffic * args.steps / wall / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "kernel": ("k_step2" if vec.spec_index >= 0 and os.environ.get("FWGYM_SPLIT", "1") != "0" else "k_step") + (" + k_actor_act" if fused else ""),
                          "kernel_ms": wall / args.steps * 1e3, "kernel_ms_hip_events": event_ms,
                          "clock": "wall clock of the timed region (the same interval as `value`)",
                          "algorithmic_bytes_per_env_step": ALG_BYTES[args.workload], "source_hash": source_hash()},
         }
-        if steady is not None:
-            out["steady_state"] = steady
+        for k, v in sides.items():
+            if traffic and isinstance(v, dict) and "ms_per_step" in v and k in ("steady_state",):
+                v["measured_GBs"] = traffic / (v["ms_per_step"] * 1e-3) / 1e9
+            out[k] = v
         if args.emulate:
             out["emulated_episodes_seen"] = seen["episodes"]
     vec.close()
@@ -427,7 +535,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.emulate:   # after the process group is gone
-            out["cpu_baseline"] = cpu_baseline("c3" if args.workload == "c4" else args.workload, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline("c3" if args.workload == "c4" else args.workload, args.cpu_seconds, args.cpu_procs)
         sys.stdout.flush()
         try:   # RCCL's banner sits in the C stdio buffer until exit when stdout is a pipe: push it out first
             import ctypes

@@ -188,7 +188,14 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     if (GYM && c.use_cmd_ring && valid)
         GROUP(A.S, A.N, (L.cmd_ring >> 2) + A.slot_act, e) = make_float4(cmd_c[0], cmd_c[1], cmd_c[2], 0.f);
     float gust[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (PHYS && TURB) dryden_output(c, E.dry, gust);
+    if (PHYS && TURB) {
+        if (c.turb_increment) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) gust[i] = E.gust[i];
+        } else {
+            dryden_output(c, E.dry, gust);
+        }
+    }
     float4 act_q3 = make_float4(0.f, 0.f, 0.f, 0.f), act_q4 = act_q3;
     if (SPLIT && GYM && ext_act) {   // y[12..15] | y[16], y[17], ...: the actuator part of the simulator rows
         act_q3 = load_group(A.S, A.N, (L.sim >> 2) + 3, e);
@@ -412,7 +419,13 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     }
     const bool ok = fail == 0;
     if (PHYS) {
-        if (TURB && ok) dryden_advance(c, E.dry, n);
+        if (TURB && ok) {
+            float x_old[FWG_N_DRYDEN];
+#pragma unroll
+            for (int i = 0; i < FWG_N_DRYDEN; ++i) x_old[i] = E.dry[i];
+            dryden_advance(c, E.dry, n);
+            if (c.turb_increment) dryden_next_gust(c, x_old, E.dry, E.gust);
+        }
 #ifndef FWG_ABL_NO_SIMSTORE
         if (valid) store_sim<TURB>(c, A.S, A.N, e, E);
 #endif
@@ -950,7 +963,7 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
     if (window > FWG_MAX_WINDOW) { *why = "action window_size > 8"; return -1; }
     // all offsets are in 32-bit words and multiples of 4: the arena is addressed in 16-byte groups [group][env]
     int o = 0;
-    L->sim = o; o += 28;                 // y[18] | dryden[8] | pad
+    L->sim = o; o += 32;                 // y[18] | dryden[8] | gust[6] (increment turbulence)
     L->cold = o; o += 8;                 // wind[3] episode | e0[3] pad  (per-episode constants, written at reset)
     L->derived = o; o += 8;              // roll pitch yaw Va | alpha beta pad pad
     L->gym = o; o += 36;                 // 9 bookkeeping groups (see load_gym)
@@ -1024,6 +1037,8 @@ static int lower_config(const fwg_config& c, DevCfg* d, DynCfg* dy, std::string*
     const double h = c.dt / c.n_substeps;
     d->h = f32(h); d->half_h = f32(0.5 * h); d->h_sixth = f32(h / 6.0);
     d->turbulence = c.turbulence;
+    if (c.turbulence_output != FWG_TURB_FILTER && c.turbulence_output != FWG_TURB_INCREMENT) { *why = "turbulence_output"; return -1; }
+    d->turb_increment = c.turbulence && c.turbulence_output == FWG_TURB_INCREMENT;
     {   // force / moment constants from the parameter table (derive_aero: the device runs the same formulas per env when
         // simulator.model re-samples the table)
         AeroT<double> ad;
@@ -1394,6 +1409,14 @@ int fwg_note_replayed_steps(fwg_handle* h, int64_t n_steps) {
     if (!h->graph_mode) return fail_with(FWG_ERR_INVALID, "fwg_note_replayed_steps needs graph mode");
     if (n_steps % 2 != 0) return fail_with(FWG_ERR_INVALID, "a replayed launch sequence must hold an even number of steps");
     h->gstep += n_steps;
+    return FWG_OK;
+}
+int fwg_capture_parity(const fwg_handle* h) { return h ? (int)(h->gstep_at_capture & 1) : 0; }
+int fwg_replay_check(const fwg_handle* h, int capture_parity) {
+    if (!h || !h->graph_mode) return fail_with(FWG_ERR_INVALID, "fwg_replay_check needs graph mode");
+    if ((int)(h->gstep & 1) != (capture_parity & 1))
+        return fail_with(FWG_ERR_INVALID, "hipGraph captured at the other step parity: its launches would read the stale copy of the ring "
+                                          "positions (run an even number of direct steps between capture and replay, or capture again)");
     return FWG_OK;
 }
 int fwg_num_specs(void) {

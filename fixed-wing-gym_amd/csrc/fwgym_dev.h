@@ -112,6 +112,7 @@ struct DevCfg {
     float act_phi[2][4], act_travel[2], dot_max[2], act_ethr;  // exact actuator transition over one micro-step
     int act_per_half;
     float dryA[FWG_N_DRYDEN * FWG_N_DRYDEN], dryB[FWG_N_DRYDEN * 4], dryC[6 * FWG_N_DRYDEN];
+    int turb_increment;   // the gust sample is the first difference of the filter outputs (kept in the simulator rows)
     // ---- gym side
     int steps_max, obs_length, obs_step, n_obs, obs_dim, obs_noise;
     float obs_noise_mean, obs_noise_std;

@@ -298,6 +298,7 @@ struct Env {
     float y[NY];
     float wind[3];
     float dry[FWG_N_DRYDEN];
+    float gust[6];       // increment turbulence: this step's gust sample (computed when the filter advanced one step ago)
     Derived d;
     float tgt[FWG_MAX_TARGETS];
     float tprop[FWG_MAX_TARGETS][4];  // slope|amplitude, period, phase, bias
@@ -344,21 +345,28 @@ __device__ __forceinline__ float4 load_group(const float* S, long N, int g, long
 __device__ __forceinline__ float u2f(unsigned u) { return __uint_as_float(u); }
 __device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
 
-// simulator block: 7 groups = y[18] | dryden[8] | 2 pad (5 groups when turbulence is off)
+// simulator block: y[18] | dryden[8] | gust[6] = 8 groups with increment turbulence, 7 with the filter outputs (the last two
+// words unused), 5 when turbulence is off
 template <bool TURB>
 __device__ __forceinline__ void load_sim(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
     const int g0 = c.L.sim >> 2;
-    float f[28];
+    float f[32];
 #pragma unroll
-    for (int g = 0; g < (TURB ? 7 : 5); ++g) {
-        const float4 q = load_group(S, N, g0 + g, e);
-        f[4 * g] = q.x; f[4 * g + 1] = q.y; f[4 * g + 2] = q.z; f[4 * g + 3] = q.w;
+    for (int g = 0; g < 8; ++g) {
+        if (g < (TURB ? (c.turb_increment ? 8 : 7) : 5)) {
+            const float4 q = load_group(S, N, g0 + g, e);
+            f[4 * g] = q.x; f[4 * g + 1] = q.y; f[4 * g + 2] = q.z; f[4 * g + 3] = q.w;
+        } else {
+            f[4 * g] = 0.f; f[4 * g + 1] = 0.f; f[4 * g + 2] = 0.f; f[4 * g + 3] = 0.f;
+        }
     }
 #pragma unroll
     for (int i = 0; i < NY; ++i) E.y[i] = f[i];
     if (TURB) {
 #pragma unroll
         for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = f[NY + i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) E.gust[i] = f[NY + FWG_N_DRYDEN + i];
     }
 }
 // per-episode constants (written by reset only): steady wind + episode counter
@@ -392,14 +400,16 @@ __device__ __forceinline__ void aero_from_cfg(const DevCfg& c, Aero& a) {
 template <bool TURB>
 __device__ __forceinline__ void store_sim(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E) {
     const int g0 = c.L.sim >> 2;
-    float f[28];
+    float f[32];
 #pragma unroll
     for (int i = 0; i < NY; ++i) f[i] = E.y[i];
 #pragma unroll
     for (int i = 0; i < FWG_N_DRYDEN; ++i) f[NY + i] = TURB ? E.dry[i] : 0.f;
-    f[18 + (TURB ? 8 : 0)] = 0.f; f[19 + (TURB ? 8 : 0)] = 0.f;
 #pragma unroll
-    for (int g = 0; g < (TURB ? 7 : 5); ++g) GROUP(S, N, g0 + g, e) = make_float4(f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+    for (int i = 0; i < 6; ++i) f[NY + FWG_N_DRYDEN + i] = (TURB && c.turb_increment) ? E.gust[i] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+        if (g < (TURB ? (c.turb_increment ? 8 : 7) : 5)) GROUP(S, N, g0 + g, e) = make_float4(f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
     if (c.store_derived) {  // derived values of the committed state: only for host views (controllers, rendering)
         GROUP(S, N, (c.L.derived >> 2), e) = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
         GROUP(S, N, (c.L.derived >> 2) + 1, e) = make_float4(E.d.alpha, E.d.beta, 0.f, 0.f);
@@ -1127,6 +1137,8 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
     for (int i = 0; i < 3; ++i) E.wind[i] = D.wind[i];
 #pragma unroll
     for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) E.gust[i] = 0.f;
     E.d = D.d;
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {

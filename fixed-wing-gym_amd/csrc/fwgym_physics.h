@@ -345,6 +345,15 @@ __device__ __forceinline__ void dryden_advance(const DevCfg& c, float (&x)[FWG_N
 #pragma unroll
     for (int i = 0; i < FWG_N_DRYDEN; ++i) x[i] = xn[i];
 }
+// the gust sample of the NEXT env step after the filter advanced from x_old to x_new (oracle/physics.py
+// dryden_gust_after_advance): the first difference of the outputs (increment turbulence) or the outputs themselves
+__device__ __forceinline__ void dryden_next_gust(const DevCfg& c, const float (&x_old)[FWG_N_DRYDEN], const float (&x_new)[FWG_N_DRYDEN],
+                                                 float (&gust)[6]) {
+    float d[FWG_N_DRYDEN];
+#pragma unroll
+    for (int i = 0; i < FWG_N_DRYDEN; ++i) d[i] = c.turb_increment ? x_new[i] - x_old[i] : x_new[i];
+    dryden_output(c, d, gust);
+}
 // Box-Muller with the hardware transcendental units: v_log_f32, v_sqrt_f32 and v_sin/v_cos_f32 (which take their
 // argument in revolutions, so sin(2 pi u) is a single instruction)
 __device__ __forceinline__ void box_muller(const u4& b, float (&n)[4]) {

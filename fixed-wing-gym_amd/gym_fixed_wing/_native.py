@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 17
+FWG_ABI_VERSION = 18
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -36,6 +36,7 @@ RC_STATE, RC_ACTION, RC_SUCCESS, RC_STEP, RC_GOAL = 0, 1, 2, 3, 4
 RT_VALUE, RT_ERROR, RT_DELTA, RT_BOUND, RT_PER_STATE, RT_ALL = 0, 1, 2, 3, 4, 5
 FC_LINEAR, FC_QUADRATIC, FC_EXPONENTIAL = 0, 1, 2
 ON_SUCCESS = {"none": 0, "done": 1, "new": 2}
+TURB_FILTER, TURB_INCREMENT = 0, 1
 
 # rows of the metrics block
 M_RISE_TIME, M_SETTLING_TIME, M_OVERSHOOT, M_TOTAL_ERROR, M_AVG_ERROR = 0, 3, 7, 10, 13
@@ -81,7 +82,7 @@ class Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("struct_bytes", C.c_uint32),
         ("dt", C.c_double), ("rho", C.c_double), ("g", C.c_double),
-        ("n_substeps", C.c_int32), ("actuator_microsteps", C.c_int32), ("turbulence", C.c_int32), ("pad_sim_", C.c_int32),
+        ("n_substeps", C.c_int32), ("actuator_microsteps", C.c_int32), ("turbulence", C.c_int32), ("turbulence_output", C.c_int32),
         ("param", C.c_double * N_PARAMS),
         ("con_min", C.c_double * N_VARS), ("con_max", C.c_double * N_VARS),
         ("val_min", C.c_double * N_VARS), ("val_max", C.c_double * N_VARS),
@@ -144,7 +145,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libfwgym.so")
 EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fwg_update_config", "fwg_seed",
            "fwg_reset", "fwg_step", "fwg_check_actions", "fwg_reduce_success", "fwg_global_step", "fwg_last_error",
            "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index", "fwg_set_graph_mode", "fwg_note_replayed_steps",
-           "fwg_capture_begin", "fwg_capture_end", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
+           "fwg_capture_begin", "fwg_capture_end", "fwg_capture_parity", "fwg_replay_check", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
            "fwg_actor_set_stats", "fwg_actor_get_stats", "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe",
            "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window", "fwg_reduce_success_device",
            "fwg_obs_gather", "fwg_actor_set_obs_log", "fwg_selftest_philox"]
@@ -199,6 +200,10 @@ def load_library(path=None):
     lib.fwg_capture_begin.restype = C.c_int
     lib.fwg_capture_end.argtypes = [vp]
     lib.fwg_capture_end.restype = C.c_int
+    lib.fwg_capture_parity.argtypes = [vp]
+    lib.fwg_capture_parity.restype = C.c_int
+    lib.fwg_replay_check.argtypes = [vp, C.c_int]
+    lib.fwg_replay_check.restype = C.c_int
     f32 = C.c_float
     lib.fwg_actor_create.argtypes = [C.c_int, i64, C.c_int, C.c_int, f32, f32, f32, f32, C.POINTER(vp)]
     lib.fwg_actor_destroy.argtypes = [vp]

@@ -159,6 +159,11 @@ class EnvConfig(object):
         if self.turbulence_intensity == "none":
             self.turbulence = False
             self.turbulence_intensity = "light"
+        # "increment": the gust sample is the first difference of the Dryden filter outputs -- the reading of PyFly 0.1.2's
+        # turbulence that the reference's published evaluation traces support; "filter": MIL-F-8785C
+        self.turbulence_output = self.sim_cfg.get("turbulence_output", "increment")
+        if self.turbulence_output not in ("increment", "filter"):
+            raise ValueError("turbulence_output must be 'increment' or 'filter'")
         if self.sim_cfg["actuation"]["inputs"] != ["elevator", "aileron", "throttle"]:
             raise NotImplementedError("action.states must be [elevator, aileron, throttle]")
         if self.sim_cfg["actuation"].get("dynamics", None) != ["elevon_right", "elevon_left", "throttle"]:
@@ -324,6 +329,7 @@ class EnvConfig(object):
         c.n_substeps = int(integ.get("substeps", 1))
         c.actuator_microsteps = int(integ.get("actuator_microsteps", 16))
         c.turbulence = int(self.turbulence)
+        c.turbulence_output = {"filter": nat.TURB_FILTER, "increment": nat.TURB_INCREMENT}[self.turbulence_output]
         for i, p in enumerate(nat.PARAMS):
             c.param[i] = float(self.params[p])
         for i, name in enumerate(nat.VARS):

@@ -83,6 +83,7 @@ def preset(kind):
 
 # (name, preset kind, config_kw, sim_config_kw): configurations whose kernels are frozen at build time
 TURB_MODERATE = {"turbulence": True, "turbulence_intensity": "moderate"}
+INTEGRATOR_4X64 = {"method": "rk4", "substeps": 4, "actuator_microsteps": 64}
 SPECIALISED = [
     ("c2_default", "default", None, None),                                   # BASELINE configs[1]
     ("c3_cnn_step2_dryden", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),  # BASELINE configs[2]/[3]
@@ -94,6 +95,8 @@ SPECIALISED = [
     # "_log": observation history as a row log + zero-copy window (FixedWingVecEnv(obs_log_rows=OBS_LOG_ROWS))
     ("c3_cnn_step2_dryden_lean_log", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),
     ("c3_cnn_step2_dryden_log", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),
+    # the c3 workload with 4 RK4 sub-steps and 64 actuator micro-steps per env step (bench.py side figure `integrator_4x64`)
+    ("c3_hi_lean_log", "cnn", {"observation": {"step": 2}}, dict(TURB_MODERATE, integrator=INTEGRATOR_4X64)),
 ]
 OBS_LOG_ROWS = 32
 

@@ -134,7 +134,7 @@ class GraphedRollout(object):
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        vec.capture_begin()
+        self._parity = vec.capture_begin()
         with torch.cuda.graph(self.graph):
             self._body(n_steps)
         vec.capture_end()
@@ -153,6 +153,7 @@ class GraphedRollout(object):
             cur = self.norm.obs(o.reshape(N, -1))
 
     def run(self):
+        self.vec.replay_check(self._parity)
         self.graph.replay()
         self.vec.note_replayed_steps(self.n_steps)
         return self.buf
@@ -231,7 +232,7 @@ class FusedRollout(object):
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self._graph = torch.cuda.CUDAGraph()
-        vec.capture_begin()
+        self._parity = vec.capture_begin()
         with torch.cuda.graph(self._graph):
             self._body()
         vec.capture_end()
@@ -239,6 +240,7 @@ class FusedRollout(object):
     def run(self):
         self._prime()
         if self._graph is not None:
+            self.vec.replay_check(self._parity)
             self._graph.replay()
             self.vec.note_replayed_steps(self.n_steps)
         else:

@@ -26,8 +26,9 @@ class _TorchBackend(object):
         self.torch = torch
         if not torch.cuda.is_available():
             raise nat.NativeError("no ROCm device visible to PyTorch: FixedWingVecEnv needs an MI355X (no CPU fallback)")
-        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
-        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self.index)   # explicit index: torch.device("cuda") != torch.device("cuda", 0)
         self._dt = {"f32": torch.float32, "u8": torch.uint8, "i32": torch.int32}
 
     def zeros(self, shape, kind="f32"):
@@ -216,10 +217,21 @@ class FixedWingVecEnv(object):
         self._refresh_obs_view()
 
     def capture_begin(self):
+        """Brackets the step calls issued under stream capture.  Returns the step parity of the capture: the graph may only
+        be replayed at that parity (replay_check)."""
         nat.check(self._lib, self._lib.fwg_capture_begin(self._handle))
+        return int(self._lib.fwg_capture_parity(self._handle))
 
     def capture_end(self):
         nat.check(self._lib, self._lib.fwg_capture_end(self._handle))
+
+    @property
+    def global_step(self):
+        return int(self._lib.fwg_global_step(self._handle))
+
+    def replay_check(self, capture_parity):
+        """Raises unless a graph captured at `capture_parity` (capture_begin's return value) may be replayed now."""
+        nat.check(self._lib, self._lib.fwg_replay_check(self._handle, int(capture_parity)))
 
     def note_replayed_steps(self, n_steps):
         nat.check(self._lib, self._lib.fwg_note_replayed_steps(self._handle, int(n_steps)))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 17
+#define FWG_ABI_VERSION 18
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -126,6 +126,7 @@ typedef struct fwg_factor_desc {
     double value;
 } fwg_factor_desc;
 
+enum { FWG_TURB_FILTER = 0, FWG_TURB_INCREMENT = 1 };
 enum { FWG_ON_SUCCESS_NONE = 0, FWG_ON_SUCCESS_DONE = 1, FWG_ON_SUCCESS_NEW = 2 };
 
 /* Flat, host-side "compiled" form of fixed_wing_config.json + the simulator config + the aircraft parameter table.
@@ -139,7 +140,9 @@ typedef struct fwg_config {
     int32_t n_substeps;     /* RK4 steps of the 13 rigid-body states per env step */
     int32_t actuator_microsteps; /* exact actuator micro-steps per env step (multiple of 2*n_substeps) */
     int32_t turbulence;     /* sim_config_kw["turbulence"] (examples/evaluate_controller.py:78) */
-    int32_t pad_sim_;
+    int32_t turbulence_output;  /* FWG_TURB_INCREMENT (default of sim_config.json) | FWG_TURB_FILTER: what enters the airspeed and
+                                 * body rates -- the first difference of the Dryden filter outputs (PyFly 0.1.2 as observed in
+                                 * the reference's published traces) or the MIL-F-8785C outputs themselves */
     double param[FWG_N_PARAMS];
     double con_min[FWG_N_VARS], con_max[FWG_N_VARS];    /* Variable.constraint_min/max  */
     double val_min[FWG_N_VARS], val_max[FWG_N_VARS];    /* Variable.value_min/max       */
@@ -335,6 +338,12 @@ int fwg_set_graph_mode(fwg_handle* h, int enable, void* stream);
 int fwg_capture_begin(fwg_handle* h);   /* bracket the fwg_step calls issued under stream capture (they do not execute) */
 int fwg_capture_end(fwg_handle* h);
 int fwg_note_replayed_steps(fwg_handle* h, int64_t n_steps);
+/* A captured sequence has the double-buffer copy its first launch reads baked in: it may only be replayed when the step
+ * counter has the parity it had at fwg_capture_begin.  fwg_capture_parity: that parity (0 / 1) for the capture just
+ * bracketed; fwg_replay_check: FWG_ERR_INVALID unless the handle's current step count has parity `capture_parity` -- call
+ * it before every replay (host-only, no synchronisation). */
+int fwg_capture_parity(const fwg_handle* h);
+int fwg_replay_check(const fwg_handle* h, int capture_parity);
 
 
 /* ---------------------------------------------------------------------------------------------------------------------

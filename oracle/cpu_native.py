@@ -38,11 +38,13 @@ def _measure(args):
     return n * n_envs / dt, n
 
 
-def measure(wl, seconds=8.0, n_envs=4096):
+def measure(wl, seconds=8.0, n_envs=0):
     import multiprocessing as mp
     cores = os.cpu_count() or 1
+    if n_envs <= 0:   # one 64-env workgroup is the unit of OpenMP work: at least one per core, a few per core on small hosts
+        n_envs = 64 * max(cores, 64)
     with mp.get_context("spawn").Pool(1) as pool:   # a fresh process: OpenMP runtime and emulation state stay out of the bench
         rate, steps = pool.map(_measure, [(wl, seconds, n_envs)])[0]
-    return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    return {"value": rate, "unit": "env-steps/s", "cores": cores, "cores_present": cores, "kind": "port",
             "sample": "product kernel source compiled for the host (g++ -O2, lock-step lane emulation, OpenMP over workgroups), "
                       "{} envs x {} steps in {:.0f} s".format(n_envs, steps, seconds)}

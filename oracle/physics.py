@@ -58,6 +58,10 @@ class SimSpec:
         self.params = {k: float(params[k]) for k in AERO_KEYS}
         self.turbulence = bool(sim_cfg.get("turbulence", False))
         self.turbulence_intensity = sim_cfg.get("turbulence_intensity", "light")
+        # what enters the airspeed / body rates: "increment" = the first difference of the filter outputs (what PyFly 0.1.2's
+        # published traces show, see dryden_gust_after_advance), "filter" = the MIL-F-8785C outputs themselves
+        self.turbulence_output = sim_cfg.get("turbulence_output", "increment")
+        assert self.turbulence_output in ("increment", "filter")
         self.turb_h = float(sim_cfg.get("turbulence_nominal_altitude", 100.0))
         self.turb_va = float(sim_cfg.get("turbulence_nominal_airspeed", 25.0))
         # per-variable limits, radians; NaN = absent
@@ -513,6 +517,24 @@ def dryden_advance(spec, x, normals):
 
 def dryden_output(spec, x):
     return x @ spec.dryden()[2].T
+
+
+def dryden_gust_after_advance(spec, x_old, x_new):
+    """The gust sample (u, v, w, p, q, r) of the NEXT env step, given the filter state before and after this step's advance.
+
+    "filter": C x_new, the MIL-F-8785C signal.  "increment" (default): C (x_new - x_old), its first difference -- the only
+    reading of the turbulence samples consistent with the data the reference ships about PyFly 0.1.2: in all six published
+    turbulence evaluations with a deterministic or a learnt controller (examples/evaluations/eval_res_{PID,RL_MLP}_{light,
+    moderate,severe}.npy) the airspeed term of the per-step reward carries WHITE noise (lag-1 autocorrelation of the
+    increments -0.47, against +0.44 for a linearly interpolated and -0.05 for a held Dryden signal) of standard deviation
+    0.043 / 0.086 / 0.135 m/s = (K_u / T_u) dt sqrt(pi / dt), i.e. exactly one step's forced response of the longitudinal
+    filter, and next to no random-walk component (<= 0.015 m/s per step at light; the specification signal would give 0.033
+    to 0.047).  tools/turbulence_scan.py, tests/test_simulator_pins.py::test_turbulence_jitter_fingerprint.  The sample used
+    during the first step after a reset is zero in both forms (the filters start from rest)."""
+    C = spec.dryden()[2]
+    if spec.turbulence_output == "increment":
+        return (x_new - x_old) @ C.T
+    return x_new @ C.T
 
 
 # ----------------------------------------------------------------------------------------------------------------------

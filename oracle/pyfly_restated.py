@@ -87,11 +87,12 @@ class PyFly:
         self._y = None
         self._wind = None
         self._dry_x = None
+        self._gust_now = None
         self._normals = None       # optional injected turbulence noise [T,4]
 
     # ------------------------------------------------------------------------------------------------------------------
     def _spec(self):
-        key = (bool(self.turbulence), self.turbulence_intensity,
+        key = (bool(self.turbulence), self.turbulence_intensity, self.cfg.get("turbulence_output", "increment"),
                tuple(getattr(v, p) for v in self.state.values()
                      for p in ("constraint_min", "constraint_max", "value_min", "value_max", "init_min", "init_max")),
                tuple(sorted((k, v) for k, v in self.params.items() if not isinstance(v, str))))
@@ -143,6 +144,7 @@ class PyFly:
             vals[name] = np.array([v])
         self._y, self._wind = ph.initial_state(spec, vals)
         self._dry_x = np.zeros((1, ph.N_DRY))
+        self._gust_now = np.zeros((1, 6))
         d = ph.derive(spec, self._y, self._wind, self._gust(spec))
         for name in ph.VARS[:21]:
             var = self.state[name]
@@ -160,7 +162,7 @@ class PyFly:
     def _gust(self, spec):
         if not self.turbulence:
             return np.zeros((1, 6))
-        return ph.dryden_output(spec, self._dry_x)
+        return self._gust_now
 
     def _set_plain(self, record):
         y = self._y[0]
@@ -199,7 +201,9 @@ class PyFly:
                     bits = ph.rng_bits(self.seed_value, [self.env_id], self.cur_sim_step, ph.STREAM_TURB,
                                        sub=self.episode)
                     nrm = ph.box_muller(bits)
-                self._dry_x = ph.dryden_advance(spec, self._dry_x, nrm)
+                x_new = ph.dryden_advance(spec, self._dry_x, nrm)
+                self._gust_now = ph.dryden_gust_after_advance(spec, self._dry_x, x_new)
+                self._dry_x = x_new
         else:
             success = False
             code = int(fail[0])
@@ -223,6 +227,9 @@ class PyFly:
     # oracle-only accessors
     def ode_state(self):
         return self._y.copy(), self._wind.copy(), self._dry_x.copy()
+
+    def gust(self):
+        return self._gust_now.copy()
 
 
 class PIDController:

@@ -76,6 +76,8 @@ CASES = [
     ("cnn", "cnn", {"steps_max": 50}, None),
     ("cnn_step2_turb", "cnn", {"steps_max": 60, "observation": {"step": 2}},
      {"turbulence": True, "turbulence_intensity": "moderate"}),
+    ("cnn_turb_filter", "cnn", {"steps_max": 60, "observation": {"step": 2}},   # the MIL-F-8785C signal itself as the gust
+     {"turbulence": True, "turbulence_intensity": "severe", "turbulence_output": "filter"}),
     ("dev_noise", "dev", {"steps_max": 50}, None),
     ("potential_new", "default",
      {"reward": {"form": "potential"},

@@ -130,6 +130,7 @@ def oracle_spec_from_env_config(ec):
     sim_cfg = copy.deepcopy(ec.sim_cfg)
     sim_cfg["turbulence"] = ec.turbulence
     sim_cfg["turbulence_intensity"] = ec.turbulence_intensity
+    sim_cfg["turbulence_output"] = ec.turbulence_output
     spec = ph.SimSpec(sim_cfg, ec.params)
     for name, var in ec.state.items():
         i = ph.VAR_ID[name]
@@ -148,6 +149,17 @@ def physics_state(vec):
     wind = W[c0:c0 + 3].T.astype(np.float64)
     dry = W[s0 + 18:s0 + 26].T.astype(np.float64) if vec.env_config.turbulence else np.zeros((y.shape[0], 8))
     return y, wind, dry
+
+
+def device_gust(vec, spec, dry):
+    """The gust sample [N,6] the NEXT device step will use: kept in the simulator rows (increment turbulence) or C x."""
+    if not vec.env_config.turbulence:
+        return np.zeros((dry.shape[0], 6))
+    if vec.env_config.turbulence_output == "increment":
+        W = words(vec)
+        s0 = vec.layout.sim
+        return W[s0 + 26:s0 + 32].T.astype(np.float64)
+    return ph.dryden_output(spec, dry)
 
 
 def words(vec):

@@ -149,3 +149,25 @@ def test_randomised_parameters_do_not_depend_on_the_sharding(emu_lib):
     np.testing.assert_array_equal(np.concatenate([parity._np(lo.word(L.fscale)), parity._np(hi.word(L.fscale))]), parity._np(whole.word(L.fscale)))
     for v in (whole, lo, hi):
         v.close()
+
+
+def test_replay_check_rejects_a_graph_captured_at_the_other_parity(emu_lib):
+    """A captured launch sequence has the double-buffer copy of the ring positions baked in: after an odd number of direct
+    steps it must not be replayed (bench.py once did exactly that with --warmup 5)."""
+    import gym_fixed_wing._native as nat
+    vec = FixedWingVecEnv(configs.default(), num_envs=8, seed=2, as_numpy=True, _backend=HostBackend(), _lib_path=emu_lib)
+    vec.reset()
+    a = np.zeros((8, 3), dtype=np.float32)
+    vec.set_graph_mode(True)
+    parity = vec.capture_begin()
+    g0 = vec.global_step
+    vec.step_device(a), vec.step_device(a)
+    vec.capture_end()
+    assert vec.global_step == g0 and parity == (g0 & 1)
+    vec.replay_check(parity)
+    vec.step_device(a)
+    with pytest.raises(nat.NativeError):
+        vec.replay_check(parity)
+    vec.step_device(a)
+    vec.replay_check(parity)
+    vec.close()

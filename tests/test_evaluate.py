@@ -155,85 +155,88 @@ def test_shipped_mlp_controller_flies_the_shipped_test_set():
     np.testing.assert_allclose(table2["settling_time"]["all"], table["settling_time"]["all"], rtol=0.02)
 
 
-# published success rates (%), examples/README.md:36-47: {intensity: {controller: (roll, pitch, Va, all)}}
-PUBLISHED_SUCCESS = {
-    "none": {"PID": (100, 100, 100, 100), "RL_MLP": (100, 100, 100, 100)},
-    "light": {"PID": (100, 100, 100, 100), "RL_MLP": (100, 100, 100, 100)},
-    "moderate": {"PID": (100, 98, 97, 93), "RL_MLP": (98, 97, 97, 97)},
-    "severe": {"PID": (98, 98, 94, 83), "RL_MLP": (93, 92, 91, 91)},
-}
-PUBLISHED_SETTLING = {   # roll, pitch, Va (s)
-    "none": {"PID": (2.018, 1.294, 2.203), "RL_MLP": (2.085, 1.675, 2.308)},
-    "light": {"PID": (2.008, 1.364, 2.225), "RL_MLP": (2.062, 1.845, 2.419)},
-    "moderate": {"PID": (2.131, 1.674, 2.920), "RL_MLP": (2.799, 2.927, 3.660)},
-    "severe": {"PID": (2.463, 2.560, 4.280), "RL_MLP": (3.477, 4.028, 4.975)},
-}
-
-
 @pytest.mark.gpu
 def test_published_table_under_all_four_turbulence_settings():
     """examples/evaluate_controller.py:78 sets turbulence_intensity in {none, light, moderate, severe}; the reference
-    publishes success rates of the PID baseline and of the shipped MLP policy for each (examples/README.md:36-47).  The
-    turbulence rows are the only closed-loop check of the Dryden INTENSITY against the reference.  Each setting is
-    flown with 5 turbulence seeds x 100 scenarios (the reference's turbulence test sets are missing blobs: the shipped
-    no-wind initial conditions are used for every setting); success rates must agree with the published ones within
-    3 standard deviations of the binomial sampling error of both estimates (at least 4 points)."""
-    import torch
+    publishes the per-episode results of the PID baseline and of the shipped MLP policy for each
+    (examples/evaluations/*.npy; their means are the table of examples/README.md:33-47; summarised into
+    tests/golden/eval_turbulence_stats.json by tests/golden/make_turbulence_stats.py).  All four settings are flown for both
+    controllers on the shipped no-wind scenarios (the reference's own sets for the three turbulence settings,
+    test_set_wind_{light,moderate,severe}, are missing blobs) and gated TWO-SIDEDLY on everything those data pin:
+
+      * none and light rows: success rates within the binomial sampling error, settling times within 6 % (MLP: 8 / 10 / 20 %),
+        control variation within 20 % -- published and ours;
+      * the turbulence itself, all three intensities, both controllers: the white jitter the gusts put on the airspeed
+        ((K_u / T_u) dt sqrt(pi / dt): 0.043 / 0.081 / ~0.13 m/s) within 15 % (moderate 25 %, severe 30 %) and its lag-1 signature within
+        0.1 at light and moderate; a simulator without turbulence (or with the MIL-F-8785C signal itself as the gust,
+        `turbulence_output: filter`) fails these.
+
+    The moderate / severe TABLE rows are recorded next to the published ones (gpurun_out/eval_table.json) but not gated: the
+    published traces of those settings start from other initial conditions than the shipped set (their spread over the first
+    5 / 10 / 20 steps is 3.8x / 3.9x / 3.8x the no-wind set's at severe, proportional to the intensity from the first step on
+    -- before any gust filter has built up --, and two episodes end by an angular-rate constraint within 0.36 s), so their
+    success rates and settling times are properties of the missing scenario sets."""
+    import turbulence_stats as ts
     from gym_fixed_wing.actor import DeviceActor, weights_from_stable_baselines
     with open(os.path.join(HERE, "golden", "mlp_controller.json")) as f:
         m = json.load(f)
+    with open(os.path.join(HERE, "golden", "eval_turbulence_stats.json")) as f:
+        pub = json.load(f)
     scen = _scenarios()
-    seeds = (0, 1, 2, 3, 4)
-    table = {}
     actor = DeviceActor(len(scen), 12, training=False, device=0)
     actor.load_policy(weights_from_stable_baselines(m["weights"]))
     actor.set_stats(m["obs_rms"]["mean"], m["obs_rms"]["var"], 1e6)
     mlp = lambda obs: actor.act(obs.reshape(obs.shape[0], -1).contiguous(), deterministic=True)[1]
+    table = {}
     for intensity in ("none", "light", "moderate", "severe"):
         table[intensity] = {}
         for name, cfg_kind, policy in (("PID", "examples", None), ("RL_MLP", "mlp", mlp)):
-            succ = {k: [] for k in ("roll", "pitch", "Va", "all")}
-            settle = {k: [] for k in ("roll", "pitch", "Va")}
-            cv = []
-            for seed in (seeds if intensity != "none" else seeds[:1]):
+            metrics = {k: {} for k in ts.METRICS}
+            rewards = []
+            for seed in ((0, 1, 2) if intensity != "none" else (0,)):
                 res = ev.evaluate_on_set(scen, configs.reference_like(cfg_kind), policy=policy, device=0, seed=seed,
                                          turbulence_intensity=intensity)
-                t = ev.summarize(res)
-                for k in succ:
-                    succ[k].append(t["success_%"][k])
-                for k in settle:
-                    settle[k].append(t["settling_time"][k])
-                cv.append(t["control_variation"]["all"])
-            row = {"success_%": {k: float(np.mean(v)) for k, v in succ.items()},
-                   "settling_time": {k: float(np.nanmean(v)) for k, v in settle.items()},
-                   "control_variation": float(np.mean(cv)), "episodes": 100 * len(succ["all"]),
-                   "published_success_%": dict(zip(("roll", "pitch", "Va", "all"), PUBLISHED_SUCCESS[intensity][name])),
-                   "published_settling_time": dict(zip(("roll", "pitch", "Va"), PUBLISHED_SETTLING[intensity][name]))}
+                for k in ts.METRICS:
+                    for st, vals in res[k].items():
+                        metrics[k].setdefault(st, []).extend(vals)
+                rewards += res["rewards"]
+            row = ts.table_stats(metrics, rewards)
+            row["episodes"] = len(rewards)
+            row["published"] = {k: pub[name][intensity][k] for k in ("success_%", "settling_time", "rise_time", "overshoot",
+                                                                      "control_variation", "jitter", "early", "length")}
             table[intensity][name] = row
-    print(json.dumps(table, indent=1))
     os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(HERE), "gpurun_out", "eval_table.json"), "w") as f:
         json.dump(table, f, indent=1)
-    # Gate: the calm and light rows must reproduce the published success rates within the binomial sampling error of both
-    # estimates (3 sigma, at least 4 points).  The moderate / severe rows are flown on the no-wind initial conditions --
-    # the reference's own sets for those settings (test_set_wind_moderate / _severe, with steady wind) are missing blobs --
-    # and come out MORE benign here (PID severe: 99 % vs 83 % published, attitude settling times barely grow): the Dryden
-    # intensity of PyFly 0.1.2 stays unpinned (DESIGN.md section 2).  They are gated one-sidedly (not worse than
-    # published) and through the ordering none < moderate < severe of the airspeed settling time and control variation.
     for intensity, rows in table.items():
         for name, row in rows.items():
-            n_ours = row["episodes"]
-            for k, pub in row["published_success_%"].items():
-                p = pub / 100.0
-                sigma = np.sqrt(p * (1 - p) / 100.0 + p * (1 - p) / n_ours)
-                band = max(3.0 * sigma, 0.04)
-                got = row["success_%"][k] / 100.0
-                if intensity in ("none", "light"):
-                    assert abs(got - p) <= band, (intensity, name, k, row["success_%"][k], pub, band)
-                else:
-                    assert got >= p - band, (intensity, name, k, row["success_%"][k], pub, band)
+            p_ = row["published"]
+            print(intensity, name, "success", row["success_%"], "published", p_["success_%"], "| settling",
+                  {k: round(v, 3) for k, v in row["settling_time"].items()}, "published", {k: round(v, 3) for k, v in p_["settling_time"].items()},
+                  "| cv %.3f published %.3f" % (row["control_variation"], p_["control_variation"]),
+                  "| jitter", row["jitter"].get("30-130"), "published", p_["jitter"].get("30-130"))
+    for intensity in ("none", "light"):
+        for name, row in table[intensity].items():
+            p_ = row["published"]
+            for k, pv in p_["success_%"].items():
+                p = pv / 100.0
+                band = max(3.0 * np.sqrt(p * (1 - p) / 100.0 + p * (1 - p) / row["episodes"]), 0.04)
+                assert abs(row["success_%"][k] / 100.0 - p) <= band, (intensity, name, k, row["success_%"][k], pv)
+            for k, pv in p_["settling_time"].items():
+                tol = {"roll": 0.08, "pitch": 0.10, "Va": 0.20}[k] if name == "RL_MLP" else 0.06
+                assert abs(row["settling_time"][k] - pv) <= tol * pv, (intensity, name, k, row["settling_time"][k], pv)
+        row = table[intensity]["PID"]
+        assert abs(row["control_variation"] - row["published"]["control_variation"]) <= 0.20 * row["published"]["control_variation"], \
+            (intensity, row["control_variation"], row["published"]["control_variation"])
     for name in ("PID", "RL_MLP"):
-        s = [table[i][name]["settling_time"]["Va"] for i in ("none", "light", "moderate", "severe")]
-        cvs = [table[i][name]["control_variation"] for i in ("none", "light", "moderate", "severe")]
-        assert s[0] < s[2] < s[3], (name, s)
-        assert cvs[0] < cvs[1] < cvs[2] < cvs[3], (name, cvs)
+        assert table["none"][name]["jitter"]["30-130"]["white_Va"] < 0.01
+        for intensity, tol in (("light", 0.15), ("moderate", 0.25)):
+            got, want = table[intensity][name]["jitter"]["30-130"], table[intensity][name]["published"]["jitter"]["30-130"]
+            assert abs(got["white_Va"] - want["white_Va"]) <= tol * want["white_Va"], (name, intensity, got, want)
+            assert abs(got["lag1"] - want["lag1"]) <= 0.10, (name, intensity, got, want)
+            assert got["walk_Va"] <= want["walk_Va"] + 0.02, (name, intensity, got, want)
+    # severe: the published early window is dominated by the violent transients of its (missing) scenario set; the PID runs'
+    # later windows give the gust level (0.128 / 0.143 / 0.135 m/s at 130-300 / 300-600 / 600-1500 steps)
+    got = table["severe"]["PID"]["jitter"]["30-130"]["white_Va"]
+    want = float(np.mean([table["severe"]["PID"]["published"]["jitter"][w]["white_Va"] for w in ("130-300", "300-600", "600-1500")]))
+    assert abs(got - want) <= 0.30 * want, (got, want)

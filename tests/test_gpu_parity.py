@@ -110,7 +110,7 @@ def test_single_step_state_parity_1e5(n, turb):
     for t in range(6):
         raw = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
         y0, wind, dry = parity.physics_state(vec)
-        gust = ph.dryden_output(spec, dry) if turb else np.zeros((n, 6))
+        gust = parity.device_gust(vec, spec, dry)
         cmd = parity.scaled_actions(vec, raw)
         want, ok, fail, cmd_c, d = ph.sim_step(spec, y0, cmd, wind, gust)
         _, _, done, _ = vec.step(raw)
@@ -228,7 +228,7 @@ def _one_step_errors(vec, spec, raw, turb):
     relative error [N,18] where |want| > 1e-3 else nan, oracle ok mask, failure codes, device done flags)."""
     n = vec.num_envs
     y0, wind, dry = parity.physics_state(vec)
-    gust = ph.dryden_output(spec, dry) if turb else np.zeros((n, 6))
+    gust = parity.device_gust(vec, spec, dry)
     cmd = parity.scaled_actions(vec, raw)
     want, ok, fail, _, _ = ph.sim_step(spec, y0, cmd, wind, gust)
     _, _, done, infos = vec.step(raw)

@@ -127,6 +127,9 @@ def test_device_turbulence_variances_at_full_size(intensity):
     act[:, 2] = 0.4
     s1 = torch.zeros(6, dtype=torch.float64, device="cuda")
     s2 = torch.zeros(6, dtype=torch.float64, device="cuda")
+    i1 = torch.zeros(6, dtype=torch.float64, device="cuda")
+    i2 = torch.zeros(6, dtype=torch.float64, device="cuda")
+    assert vec.env_config.turbulence_output == "increment"   # the default: the gust sample kept in the simulator rows
     cnt = 0
     L = vec.layout
     for t in range(2000):
@@ -135,16 +138,27 @@ def test_device_turbulence_variances_at_full_size(intensity):
             x = torch.stack([vec.word(L.sim + 18 + k) for k in range(8)], dim=1)   # stationary part measured below)
             g = (x @ Ct.T).double()
             s1 += g.sum(dim=0); s2 += (g * g).sum(dim=0); cnt += n
+            inc = torch.stack([vec.word(L.sim + 26 + k) for k in range(6)], dim=1).double()   # the next step's gust sample
+            i1 += inc.sum(dim=0); i2 += (inc * inc).sum(dim=0)
     var = (s2 / cnt - (s1 / cnt) ** 2).cpu().numpy()
     # the filter starts from x = 0 at reset: after k steps the state covariance is P_k = sum_{j<k} A^j B B^T A^jT; use the
     # exact finite-time value averaged over the sampled steps (the slow u/v channels have not reached P_inf after 20 s)
-    P = np.zeros((8, 8)); acc = np.zeros((8, 8)); m = 0
+    P = np.zeros((8, 8)); acc = np.zeros((8, 8)); acc_inc = np.zeros((8, 8)); m = 0
     BB = B @ B.T
+    AI = A - np.eye(8)
     for k in range(1, 2001):
-        P = A @ P @ A.T + BB
+        Pn = A @ P @ A.T + BB
         if k - 1 >= 400 and (k - 1) % 8 == 0:
-            acc += P; m += 1
+            acc += Pn; m += 1
+            acc_inc += AI @ P @ AI.T + BB      # covariance of x_k - x_(k-1) = (A - I) x_(k-1) + B n
+        P = Pn
     want_t = np.diag(C @ (acc / m) @ C.T)
     np.testing.assert_allclose(var, want_t, rtol=0.02)
+    # the gust the simulator USES (turbulence_output "increment"): the first difference of those outputs, white to within
+    # the filters' mean reversion; its longitudinal component is the (K_u / T_u) dt sqrt(pi / dt) of the published traces
+    var_inc = (i2 / cnt - (i1 / cnt) ** 2).cpu().numpy()
+    np.testing.assert_allclose(var_inc, np.diag(C @ (acc_inc / m) @ C.T), rtol=0.02)
+    w20 = {"light": 15.0, "moderate": 30.0, "severe": 45.0}[intensity]
+    assert abs(np.sqrt(var_inc[0]) - 0.0031 * w20) < 0.05 * 0.0031 * w20
     assert np.all(want_t[:3] <= want[:3] * 1.0001)
     vec.close()
