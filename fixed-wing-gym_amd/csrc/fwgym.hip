@@ -270,7 +270,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // ends at steps_max is known before the integration: everything its episode-end branch reads from memory -- the
     // prepared draw, the end-error record, the lagged rows of the terminal observation -- is requested here, so that the
     // round trips run while the physics wave integrates
-    bool pre_end = false, pre_draw = false;
+    bool pre_end = false, pre_draw = false, pre_rows = false;
     float4 pre_tag = make_float4(0.f, 0.f, 0.f, 0.f), pre_old = make_float4(0.f, 0.f, 0.f, 0.f);
     ResetDraw RD;
     // lanes in the first steps of an episode: the padding rows of their observation, up to the "action" entries
@@ -313,6 +313,24 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         }
         E.sft += 1u;
         if (c.steps_max > 0 && E.steps >= (unsigned)c.steps_max) { done = true; term = FWG_TERM_STEPS; }
+        // an episode that ends at steps_max is known here: everything its episode-end branch reads from memory is requested
+        // now -- the prepared draw, the end-error record, the lagged rows of the terminal observation --, so that the round
+        // trips run under the rest of this block and the partner's integration
+        if (c.auto_reset && c.steps_max > 0 && __ballot(valid && done) != 0ull) {
+            if (valid && done) {
+                pre_end = true;
+                if (draw_stage_of(E.flags) == FWG_DRAW_READY) {
+                    pre_draw = true;
+                    pre_tag = draw_tag(A.S, A.N, e, c);
+                    draw_load_final(c, A.S, A.N, e, RD);   // used only if the tag checks out
+                }
+                if (c.metrics) {
+                    int slot = A.slot_end + 1; slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
+                    pre_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                }
+                if (c.obs_log > 0) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
+            }
+        }
 #pragma unroll
         for (int f = 0; f < FWG_MAX_FACTORS; ++f) {
             fval_action[f] = 0.f;
@@ -360,21 +378,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             // kind of piece per wave and step (the least advanced lanes first): a wave whose lanes sit at different stages
             // would otherwise run all the pieces back to back and outlast the integration it hides behind
             const unsigned stage = draw_stage_of(E.flags);
-            if (c.steps_max > 0 && __ballot(valid && done) != 0ull) {   // done: E.steps reached steps_max
-                if (valid && done) {
-                    pre_end = true;
-                    if (stage == FWG_DRAW_READY) {
-                        pre_draw = true;
-                        pre_tag = draw_tag(A.S, A.N, e, c);
-                        draw_load_final(c, A.S, A.N, e, RD);   // used only if the tag checks out
-                    }
-                    if (c.metrics) {
-                        int slot = A.slot_end + 1; slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
-                        pre_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
-                    }
-                    if (c.obs_log > 0) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
-                }
-            }
             // (not in the first steps of an episode, whose lanes have their padding rows to compute in this same interval)
             const bool work = valid && stage < FWG_DRAW_READY && !early_now;
             unsigned long long m = 0ull;
@@ -396,6 +399,17 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         }
         if (__ballot(early_now) != 0ull) {
             if (early_now) { pre_early = true; early_rows_pre(c, A, e, E, ob, rec0, early_noise); }
+        }
+        // foreseen episode end with a valid prepared draw (row-log mode, no attached observer): the NEW episode's observation
+        // window does not depend on how the old one ends -- it goes into the log now, while the partner still integrates (the
+        // terminal observation's lagged rows were read from those planes above: same wave, in order)
+        if (SPLIT && c.auto_reset && c.obs_log > 0 && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 && A.acc == nullptr) {
+            if (__ballot(pre_draw) != 0ull) {
+                if (pre_draw && f2u(pre_tag.x) == dc.generation && f2u(pre_tag.y) == E.episode + 1u) {
+                    reset_rows_to_log(c, A, e, RD, c.use_cmd_ring ? cring : aring, A.slot_lag, A.log_win);
+                    pre_rows = true;
+                }
+            }
         }
     };
     if (SPLIT && GYM) {
@@ -605,71 +619,39 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     if (A.acc != nullptr && done_mask == 0ull) step_moments(c, A, ob, reward, done, valid, lane, e);
     if (SPLIT) FWG_BLOCK_SYNC_LDS();   // barrier B (the physics wave arrived long ago: its rows are in memory)
     if (done_mask != 0ull) {
-        float red[FWG_N_REDUCE];
-#pragma unroll
-        for (int i = 0; i < FWG_N_REDUCE; ++i) red[i] = 0.f;
         if (done && valid) {
-            const unsigned n_rec = ok ? E.steps + 1u : E.steps;  // records in the episode histories
-            float mt[FWG_N_METRICS];
-#pragma unroll
-            for (int i = 0; i < FWG_N_METRICS; ++i) mt[i] = NAN;
             if (c.metrics) {
-                // end_error: |mean of the last <= 50 errors| = (S_last - S_(last-50)) / count over the cumulative sums; S_last
-                // is E.esum (this step's record when the step was valid, the previous one otherwise) and the record 50
-                // before it sits in the slot after the last written one of the 51-slot ring
-                const int end_cnt = (int)min(n_rec, (unsigned)FWG_END_WINDOW);
-                float end_sum[3] = {E.esum[0], E.esum[1], E.esum[2]};
-                if (n_rec > (unsigned)FWG_END_WINDOW) {
+                // the episode's accumulators go into the env's finished-episode record; metrics and success sums are computed
+                // from it by k_finish.  end_sum: the sum of the last <= 50 errors = S_last - S_(last-50) over the cumulative
+                // sums; S_last is E.esum (this step's record when the step was valid, the previous one otherwise) and the
+                // record 50 before it sits in the slot after the last written one of the 51-slot ring
+                FinRec R;
+                R.steps = E.steps; R.n_rec = ok ? E.steps + 1u : E.steps;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    R.e0[k] = E.e0[k]; R.esum[k] = E.esum[k]; R.eabs[k] = E.eabs[k]; R.emin[k] = E.emin[k]; R.emax[k] = E.emax[k];
+                    R.end_sum[k] = E.esum[k]; R.rise[k] = E.rise[k];
+                }
+                R.settle[0] = E.settle[0]; R.settle[1] = E.settle[1]; R.gcnt[0] = E.gcnt[0]; R.gcnt[1] = E.gcnt[1]; R.sdcmd = E.sdcmd;
+                if (R.n_rec > (unsigned)FWG_END_WINDOW) {
                     float4 r = pre_old;   // requested before the integration for foreseen ends
                     if (!(pre_end && ok)) {
                         int slot = ok ? A.slot_end + 1 : A.slot_end;
                         slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
                         r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
                     }
-                    end_sum[0] -= r.x; end_sum[1] -= r.y; end_sum[2] -= r.z;
+                    R.end_sum[0] -= r.x; R.end_sum[1] -= r.y; R.end_sum[2] -= r.z;
                 }
-#pragma unroll
-                for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
-                    if (k >= c.n_targets) continue;
-                    const unsigned lo = E.rise[k] & 0xFFFFu, hi = E.rise[k] >> 16;
-                    mt[FWG_M_RISE_TIME + k] = (lo == 0xFFFFu || hi == 0xFFFFu) ? NAN : (float)lo - (float)hi;
-                    const float ext = E.e0[k] > 0.f ? E.emin[k] : E.emax[k];
-                    mt[FWG_M_OVERSHOOT + k] = (fsignf(ext) == fsignf(E.e0[k])) ? NAN : fabsf(fast_div(ext, E.e0[k]));
-                    mt[FWG_M_TOTAL_ERROR + k] = E.eabs[k];
-                    mt[FWG_M_AVG_ERROR + k] = fabsf(E.e0[k]) >= 0.01f ? fabsf(fast_div(E.esum[k], (float)n_rec * E.e0[k])) : NAN;
-                    mt[FWG_M_END_ERROR + k] = fabsf(fast_div(end_sum[k], (float)end_cnt));
+                if (E.flags & FWG_FLAG_FIN_PENDING) {   // (rare) the previous record was never collected: fold it now
+                    FinRec old;
+                    fin_load(c, A.S, A.N, e, old);
+                    fin_collect_lane(c, A, e, old);
                 }
-                mt[FWG_M_CONTROL_VARIATION] = fast_div(E.sdcmd, 3.f * c.dt * (float)(E.steps - 1u));
-                if (c.goal_enabled) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool present = (r == 3) || (r < c.n_targets && c.target[r < 3 ? r : 0].has_bound);
-                        if (present) {
-                            const unsigned st = pack16_get(E.settle, r);
-                            mt[FWG_M_SETTLING_TIME + r] = st == 0xFFFFu ? NAN : (float)st;
-                            mt[FWG_M_SUCCESS + r] = st == 0xFFFFu ? 0.f : 1.f;
-                            mt[FWG_M_SUCCESS_TIME_FRAC + r] = fast_div((float)pack16_get(E.gcnt, r), (float)n_rec);
-                        }
-                    }
-                }
-                if (A.metrics != nullptr) {
-#pragma unroll
-                    for (int i = 0; i < FWG_N_METRICS; ++i) A.metrics[(unsigned)i * (unsigned)A.N + (unsigned)e] = mt[i];
-                }
-                red[0] = 1.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    red[1 + r] = mt[FWG_M_SUCCESS + r] == 1.f ? 1.f : 0.f;
-                    red[12 + r] = mt[FWG_M_SUCCESS_TIME_FRAC + r] == mt[FWG_M_SUCCESS_TIME_FRAC + r] ? mt[FWG_M_SUCCESS_TIME_FRAC + r] : 0.f;
-                }
-                red[5] = mt[FWG_M_CONTROL_VARIATION] == mt[FWG_M_CONTROL_VARIATION] ? mt[FWG_M_CONTROL_VARIATION] : 0.f;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    red[6 + k] = mt[FWG_M_END_ERROR + k] == mt[FWG_M_END_ERROR + k] ? mt[FWG_M_END_ERROR + k] : 0.f;
-                    red[9 + k] = mt[FWG_M_TOTAL_ERROR + k] == mt[FWG_M_TOTAL_ERROR + k] ? mt[FWG_M_TOTAL_ERROR + k] : 0.f;
-                }
+                fin_store(c, A.S, A.N, e, R);
+                E.flags |= FWG_FLAG_FIN_PENDING;
+                if (!c.auto_reset) GROUP(A.S, A.N, (L.gym >> 2) + 1, e) = make_float4(u2f(E.flags), u2f(E.wcnt), u2f(E.gcnt[0]), u2f(E.gcnt[1]));
             } else {
-                red[0] = 1.f;
+                atomicAdd(A.reduce, 1ull);   // episodes finished
             }
         }
         FWG_TL(A, 11);
@@ -686,16 +668,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
         }
         FWG_TL(A, 12);
-        // per-wave reduction by shuffles, one atomic per value per wave (the per-GPU part of the success reduction of
-        // examples/train_rl_controller.py:51-66,80-85)
-        {
-            float v32[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) v32[i] = i < FWG_N_REDUCE ? red[i] : 0.f;
-            const float tot = wave_totals32(v32, lane);   // lane l holds the total of value l & 31
-            if (lane < FWG_N_REDUCE && tot != 0.f)   // counts (0..4) as integers, the rest in 2^-20 fixed point: exact, order-free
-                atomicAdd(A.reduce + lane, (unsigned long long)(long long)rintf(lane < 5 ? tot : tot * FWG_ACC_SCALE));
-        }
         FWG_TL(A, 13);
         if (c.auto_reset && done && valid) {
             bool ready = draw_stage_of(E.flags) == FWG_DRAW_READY;
@@ -706,7 +678,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
             if (ready) { if (!pre_draw) draw_load_final(c, A.S, A.N, e, RD); }
             else reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);   // episode ended before its successor's draw was complete
-            reset_finish<TURB>(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal, RD, true);
+            reset_finish<TURB>(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal, RD, true, pre_rows);
             store_sim<TURB>(c, A.S, A.N, e, E);
             store_gym(c, A.S, A.N, e, E, A.bit_goal, true, true);
         }
@@ -719,11 +691,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     if (c.obs_log == 0) {
         write_obs<ROLE>(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull);
     } else {
-        if (valid) log_store_row(c, A.obs, A.N, e, log_win, 0, ob);   // the new record: 64 consecutive rows per wave
-        if (__ballot((done || early) && valid) != 0ull) {
+        if (valid && !pre_rows) log_store_row(c, A.obs, A.N, e, log_win, 0, ob);   // the new record: 64 consecutive rows per wave
+        if (__ballot((done || early) && valid && !pre_rows) != 0ull) {
 #pragma unroll
             for (int r = 1; r < FWG_MAX_ROWS; ++r)
-                if (r < c.obs_length && valid && (done || (early && r * c.obs_step >= (int)log_pad_t)))
+                if (r < c.obs_length && valid && !pre_rows && (done || (early && r * c.obs_step >= (int)log_pad_t)))
                     log_store_row(c, A.obs, A.N, e, log_win, r, ob);
         }
     }
@@ -883,6 +855,39 @@ __global__ void k_reduce_take(unsigned long long* __restrict__ acc, float* __res
     }
 }
 
+// fwg_finish_episodes: finished-episode records not yet collected -> metrics block + success sums (per-wave reduction by
+// shuffles, one atomic per value per wave: the per-GPU part of the success reduction of examples/train_rl_controller.py:51-66,
+// 80-85); the pending mark is cleared.  One lane per env; a wave without a pending record leaves after one 16-byte load.
+__global__ __launch_bounds__(FWG_WAVE) void k_finish(const DevCfg* __restrict__ cp, const KArgs A) {
+    const DevCfg& c = *cp;
+    const int lane = threadIdx.x;
+    const long e0 = (long)blockIdx.x * FWG_WAVE + lane;
+    const bool valid = e0 < A.N;
+    const long e = valid ? e0 : A.N - 1;
+    const float4 fl = CGROUP(A.S, A.N, (c.L.gym >> 2) + 1, e);
+    const bool pending = valid && (f2u(fl.x) & FWG_FLAG_FIN_PENDING);
+    if (__ballot(pending) == 0ull) return;
+    float red[FWG_N_REDUCE];
+#pragma unroll
+    for (int i = 0; i < FWG_N_REDUCE; ++i) red[i] = 0.f;
+    if (pending) {
+        FinRec R;
+        fin_load(c, A.S, A.N, e, R);
+        float mt[FWG_N_METRICS];
+        finish_metrics(c, R, mt, red);
+        if (A.metrics != nullptr) {
+#pragma unroll
+            for (int i = 0; i < FWG_N_METRICS; ++i) A.metrics[(unsigned)i * (unsigned)A.N + (unsigned)e] = mt[i];
+        }
+        GROUP(A.S, A.N, (c.L.gym >> 2) + 1, e) = make_float4(u2f(f2u(fl.x) & ~FWG_FLAG_FIN_PENDING), fl.y, fl.z, fl.w);
+    }
+    float v32[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v32[i] = i < FWG_N_REDUCE ? red[i] : 0.f;
+    const float tot = wave_totals32(v32, lane);   // lane l holds the total of value l & 31
+    if (lane < FWG_N_REDUCE && tot != 0.f) atomicAdd(A.reduce + lane, reduce_fixed(lane, tot));
+}
+
 // known-answer hook for the device Philox4x32-10 (fwg_selftest_philox): in[i] = counter[4] | key[2]
 __global__ void k_selftest_philox(const unsigned* __restrict__ in, unsigned* __restrict__ out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -933,6 +938,7 @@ struct fwg_handle {
     int64_t gstep_at_capture;
     StepSlots* d_slots;
     size_t lds_bytes;
+    float* last_metrics_out;      // metrics block of the last fwg_step (what fwg_reduce_success* collect into)
     struct fwg_actor* observer;   // attached rollout head (fwg_attach_observer) or null
     int split;                    // specialised configurations: the step runs as k_step2 (two waves per 64 envs)
 #ifdef FWG_TIMELINE
@@ -993,6 +999,7 @@ static int compute_layout(const fwg_config& c, fwg_layout* L, std::string* why) 
     L->fscale_next = o; o += c.randomize_scaling ? FWG_MAX_FACTORS + 4 : 0;    // ... and the next episode's, + tag group
     L->model_raw = o; o += ((c.model_n + 3) / 4) * 4;                          // sampled values of the listed parameters ...
     L->model_raw_next = o; o += ((c.model_n + 3) / 4) * 4;                     // ... and the next episode's
+    L->fin = o; o += c.metrics ? 28 : 0;                                       // finished-episode record (fwgym_env.h FinRec)
     L->window = window;
     L->rows = o;
     return use_cmd;
@@ -1292,6 +1299,7 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
     base_args(h, &A);
     A.actions = actions; A.obs = obs_out; A.rew = reward_out; A.done = done_out; A.term = term_code_out;
     A.term_obs = terminal_obs_out; A.metrics = metrics_out; A.tgt_out = target_out;
+    h->last_metrics_out = metrics_out;
     fill_slots(h, h->gstep, &A);
     if (h->graph_mode) { A.slots_in = h->d_slots + (h->gstep & 1); A.slots_out = h->d_slots + ((h->gstep + 1) & 1); }
     observer_args(h, &A);
@@ -1349,12 +1357,27 @@ int fwg_check_actions(fwg_handle* h, const float* actions, void* stream) {
     return FWG_OK;
 }
 
+static void launch_finish(fwg_handle* h, float* metrics_out, hipStream_t stream) {
+    if (!h->h.metrics) return;
+    KArgs A;
+    base_args(h, &A);
+    A.metrics = metrics_out;
+    hipLaunchKernelGGL(k_finish, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), 0, stream, h->d_cfg, A);
+}
+int fwg_finish_episodes(fwg_handle* h, float* metrics_out, void* stream) {
+    if (!h) return fail_with(FWG_ERR_INVALID, "null handle");
+    launch_finish(h, metrics_out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return FWG_OK;
+}
+
 static inline float reduce_to_float(int i, unsigned long long q) {
     return i < 5 ? (float)(long long)q : (float)((double)(long long)q / (double)FWG_ACC_SCALE);
 }
 int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream) {
     if (!h || !out_host) return fail_with(FWG_ERR_INVALID, "null argument");
     unsigned long long q[FWG_N_REDUCE];
+    launch_finish(h, h->last_metrics_out, (hipStream_t)stream);
     HIP_TRY(hipMemcpyAsync(q, h->d_reduce, sizeof(q), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipMemsetAsync(h->d_reduce, 0, sizeof(q), (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -1364,6 +1387,7 @@ int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream) {
 
 int fwg_reduce_success_device(fwg_handle* h, float* out_dev, void* stream) {
     if (!h || !out_dev) return fail_with(FWG_ERR_INVALID, "null argument");
+    launch_finish(h, h->last_metrics_out, (hipStream_t)stream);
     hipLaunchKernelGGL(k_reduce_take, dim3(1), dim3(FWG_WAVE), 0, (hipStream_t)stream, h->d_reduce, out_dev);
     HIP_TRY(hipGetLastError());
     return FWG_OK;

@@ -10,6 +10,7 @@
 // flags word (counters row 2)
 #define FWG_FLAG_GOAL_ACHIEVED 1u        // sticky for the env's lifetime (fixed_wing.py:51,381-382)
 #define FWG_FLAG_PREV_VALID_SHIFT 1      // bits 1..3: prev_shaping[fclass] is not None (fixed_wing.py:327-328,756,765)
+#define FWG_FLAG_FIN_PENDING (1u << 7)    // the env's finished-episode record (L.fin) has not been collected yet (k_finish)
 #define FWG_FLAG_RESAMPLE_SHIFT 8        // bits 8..31: target resample counter inside the episode (RNG sub-stream)
 
 // Philox stream ids (shared with oracle/physics.py)

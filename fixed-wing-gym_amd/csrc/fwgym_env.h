@@ -909,6 +909,98 @@ __device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ o
     }
 }
 
+// ---- finished-episode record.  An episode end costs the wave that hosts it the length of everything its ONE ending lane
+// does, so the step kernel only parks the episode's raw accumulators (7 groups, section L.fin) and marks the env
+// (FWG_FLAG_FIN_PENDING); the episodic metrics (get_metric, fixed_wing.py:1095-1162) and the success sums are computed from
+// the record by k_finish (fwg_finish_episodes / fwg_reduce_success*), off the step's critical path.
+struct FinRec {
+    float e0[3], esum[3], eabs[3], emin[3], emax[3], end_sum[3];   // end_sum: sum of the last <= 50 errors
+    unsigned rise[3], settle[2], gcnt[2];
+    float sdcmd;
+    unsigned steps, n_rec;   // steps taken; records in the episode histories (steps + 1 unless the last step failed)
+};
+__device__ __forceinline__ void fin_store(const DevCfg& c, float* __restrict__ S, long N, long e, const FinRec& R) {
+    const int g0 = c.L.fin >> 2;
+    GROUP(S, N, g0 + 0, e) = make_float4(R.e0[0], R.e0[1], R.e0[2], u2f(R.steps | ((R.n_rec - R.steps) << 16)));
+    GROUP(S, N, g0 + 1, e) = make_float4(R.esum[0], R.esum[1], R.esum[2], R.sdcmd);
+    GROUP(S, N, g0 + 2, e) = make_float4(R.eabs[0], R.eabs[1], R.eabs[2], u2f(R.settle[0]));
+    GROUP(S, N, g0 + 3, e) = make_float4(R.emin[0], R.emin[1], R.emin[2], u2f(R.settle[1]));
+    GROUP(S, N, g0 + 4, e) = make_float4(R.emax[0], R.emax[1], R.emax[2], u2f(R.gcnt[0]));
+    GROUP(S, N, g0 + 5, e) = make_float4(R.end_sum[0], R.end_sum[1], R.end_sum[2], u2f(R.gcnt[1]));
+    GROUP(S, N, g0 + 6, e) = make_float4(u2f(R.rise[0]), u2f(R.rise[1]), u2f(R.rise[2]), 0.f);
+}
+__device__ __forceinline__ void fin_load(const DevCfg& c, const float* __restrict__ S, long N, long e, FinRec& R) {
+    const int g0 = c.L.fin >> 2;
+    float4 q[7];
+#pragma unroll
+    for (int g = 0; g < 7; ++g) q[g] = CGROUP(S, N, g0 + g, e);
+    R.e0[0] = q[0].x; R.e0[1] = q[0].y; R.e0[2] = q[0].z; R.steps = f2u(q[0].w) & 0xFFFFu; R.n_rec = R.steps + (f2u(q[0].w) >> 16);
+    R.esum[0] = q[1].x; R.esum[1] = q[1].y; R.esum[2] = q[1].z; R.sdcmd = q[1].w;
+    R.eabs[0] = q[2].x; R.eabs[1] = q[2].y; R.eabs[2] = q[2].z; R.settle[0] = f2u(q[2].w);
+    R.emin[0] = q[3].x; R.emin[1] = q[3].y; R.emin[2] = q[3].z; R.settle[1] = f2u(q[3].w);
+    R.emax[0] = q[4].x; R.emax[1] = q[4].y; R.emax[2] = q[4].z; R.gcnt[0] = f2u(q[4].w);
+    R.end_sum[0] = q[5].x; R.end_sum[1] = q[5].y; R.end_sum[2] = q[5].z; R.gcnt[1] = f2u(q[5].w);
+    R.rise[0] = f2u(q[6].x); R.rise[1] = f2u(q[6].y); R.rise[2] = f2u(q[6].z);
+}
+// the metrics block column and the contributions to the success sums of one finished episode
+__device__ __forceinline__ void finish_metrics(const DevCfg& c, const FinRec& R, float (&mt)[FWG_N_METRICS], float (&red)[FWG_N_REDUCE]) {
+#pragma unroll
+    for (int i = 0; i < FWG_N_METRICS; ++i) mt[i] = NAN;
+#pragma unroll
+    for (int i = 0; i < FWG_N_REDUCE; ++i) red[i] = 0.f;
+    const int end_cnt = (int)min(R.n_rec, (unsigned)FWG_END_WINDOW);
+#pragma unroll
+    for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+        if (k >= c.n_targets) continue;
+        const unsigned lo = R.rise[k] & 0xFFFFu, hi = R.rise[k] >> 16;
+        mt[FWG_M_RISE_TIME + k] = (lo == 0xFFFFu || hi == 0xFFFFu) ? NAN : (float)lo - (float)hi;
+        const float ext = R.e0[k] > 0.f ? R.emin[k] : R.emax[k];
+        mt[FWG_M_OVERSHOOT + k] = (fsignf(ext) == fsignf(R.e0[k])) ? NAN : fabsf(fast_div(ext, R.e0[k]));
+        mt[FWG_M_TOTAL_ERROR + k] = R.eabs[k];
+        mt[FWG_M_AVG_ERROR + k] = fabsf(R.e0[k]) >= 0.01f ? fabsf(fast_div(R.esum[k], (float)R.n_rec * R.e0[k])) : NAN;
+        mt[FWG_M_END_ERROR + k] = fabsf(fast_div(R.end_sum[k], (float)end_cnt));
+    }
+    mt[FWG_M_CONTROL_VARIATION] = fast_div(R.sdcmd, 3.f * c.dt * (float)(R.steps - 1u));
+    if (c.goal_enabled) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool present = (r == 3) || (r < c.n_targets && c.target[r < 3 ? r : 0].has_bound);
+            if (present) {
+                const unsigned st = pack16_get(R.settle, r);
+                mt[FWG_M_SETTLING_TIME + r] = st == 0xFFFFu ? NAN : (float)st;
+                mt[FWG_M_SUCCESS + r] = st == 0xFFFFu ? 0.f : 1.f;
+                mt[FWG_M_SUCCESS_TIME_FRAC + r] = fast_div((float)pack16_get(R.gcnt, r), (float)R.n_rec);
+            }
+        }
+    }
+    red[0] = 1.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[1 + r] = mt[FWG_M_SUCCESS + r] == 1.f ? 1.f : 0.f;
+        red[12 + r] = mt[FWG_M_SUCCESS_TIME_FRAC + r] == mt[FWG_M_SUCCESS_TIME_FRAC + r] ? mt[FWG_M_SUCCESS_TIME_FRAC + r] : 0.f;
+    }
+    red[5] = mt[FWG_M_CONTROL_VARIATION] == mt[FWG_M_CONTROL_VARIATION] ? mt[FWG_M_CONTROL_VARIATION] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        red[6 + k] = mt[FWG_M_END_ERROR + k] == mt[FWG_M_END_ERROR + k] ? mt[FWG_M_END_ERROR + k] : 0.f;
+        red[9 + k] = mt[FWG_M_TOTAL_ERROR + k] == mt[FWG_M_TOTAL_ERROR + k] ? mt[FWG_M_TOTAL_ERROR + k] : 0.f;
+    }
+}
+// success sums: counts (0..4) as integers, the rest in 2^-20 fixed point (exact, order-free)
+__device__ __forceinline__ unsigned long long reduce_fixed(int i, float v) {
+    return (unsigned long long)(long long)rintf(i < 5 ? v : v * FWG_ACC_SCALE);
+}
+// one lane collects one record on its own (rare: the env ends a second episode before any fwg_finish_episodes)
+__device__ __forceinline__ void fin_collect_lane(const DevCfg& c, const KArgs& A, long e, const FinRec& R) {
+    float mt[FWG_N_METRICS], red[FWG_N_REDUCE];
+    finish_metrics(c, R, mt, red);
+    if (A.metrics != nullptr) {
+        for (int i = 0; i < FWG_N_METRICS; ++i) A.metrics[(unsigned)i * (unsigned)A.N + (unsigned)e] = mt[i];
+    }
+    for (int i = 0; i < FWG_N_REDUCE; ++i)
+        if (red[i] != 0.f) atomicAdd(A.reduce + i, reduce_fixed(i, red[i]));
+}
+
 // FixedWingAircraft.reset (fixed_wing.py:287-336) for one lane, in two parts:
 //   reset_sample : everything that depends only on (env id, episode index, seed) and the optional given values -- the
 //                  sampled initial state and targets, the derived angles, the per-row initial noise.  Pure (no memory
@@ -1111,9 +1203,57 @@ __device__ __forceinline__ unsigned draw_stage_step(const DevCfg& c, const DynCf
     return FWG_DRAW_READY;
 }
 
+// The new episode's observation window straight into the row log (row-log mode, k_step2): for an episode end that is known
+// before the integration (time limit) the gym wave does this while its partner integrates -- the window does not depend on
+// how the old episode ends.  Also pushes the episode's clean record 0 (build_row0).  Same arithmetic as reset_finish.
+__device__ __forceinline__ void reset_rows_to_log(const DevCfg& c, const KArgs& A, long e, const ResetDraw& D, const float* ring,
+                                                  int g_lag, long long win) {
+    Env R;
+    R.steps = 0u;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) R.y[i] = D.y[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) R.wind[i] = D.wind[i];
+    R.d = D.d;
+    RegTable<FWG_TAB_ROWS> T2;
+    fill_vars(R, T2);
+#pragma unroll
+    for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+        if (k < c.n_targets) {
+            T2.put(FWG_TAB_TGT + k, D.tgt[k]);
+            T2.put(FWG_TAB_ERR + k, target_error(c.target[k], D.tgt[k], T2.get(c.target[k].var)));
+        }
+    }
+    RegTable<FWG_MAX_OBS> row;
+    build_row0(c, A, e, R, T2, row, ring, g_lag, true, 0);
+#pragma unroll
+    for (int r = 0; r < FWG_MAX_ROWS; ++r) {
+        if (r >= c.obs_length) continue;
+        const float noise = D.row_noise[r];
+        float* dst = log_row(c, A.obs, A.N, e, win + r);
+        if ((c.n_obs & 3) == 0) {
+#pragma unroll
+            for (int q = 0; q < FWG_MAX_OBS / 4; ++q) {
+                if (4 * q < c.n_obs) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = row.get(4 * q + i) + noise * (c.obs[4 * q + i].norm ? c.obs[4 * q + i].inv_var : 1.f);
+                    reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < FWG_MAX_OBS; ++j)
+                if (j < c.n_obs) dst[j] = row.get(j) + noise * (c.obs[j].norm ? c.obs[j].inv_var : 1.f);
+        }
+    }
+}
+
+// rows_done: the observation window is in the row log already (reset_rows_to_log): ob is left as it is
 template <bool TURB, class TAB, class OB>
 __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, long e, Env& E, TAB& T, OB& ob, const float* ring,
-                                             int g_end, int g_lag, int g_bit, const ResetDraw& D, bool have_gw = false) {
+                                             int g_end, int g_lag, int g_bit, const ResetDraw& D, bool have_gw = false,
+                                             bool rows_done = false) {
     if (c.model_n > 0) {   // simulator.model: the set prepared for this episode by k_model_draw becomes the current one
 #pragma unroll
         for (int g = 0; g < FWG_AERO_GROUPS; ++g)
@@ -1130,7 +1270,8 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
     E.episode = D.episode;
     E.steps = 0u;
     E.sft = 0u;
-    E.flags = (E.flags & FWG_FLAG_GOAL_ACHIEVED) | (D.flags & ~FWG_FLAG_GOAL_ACHIEVED);   // the sticky bit may date from this very step
+    // (the sticky goal bit may date from this very step; a finished-episode record stays pending across the reset)
+    E.flags = (E.flags & (FWG_FLAG_GOAL_ACHIEVED | FWG_FLAG_FIN_PENDING)) | (D.flags & ~(FWG_FLAG_GOAL_ACHIEVED | FWG_FLAG_FIN_PENDING));
 #pragma unroll
     for (int i = 0; i < NY; ++i) E.y[i] = D.y[i];
 #pragma unroll
@@ -1173,6 +1314,7 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
         goal_push(c, E, goal_flags(c, err), g_bit, 0u);   // ... and written back by store_gym
     }
     store_cold(c, A.S, A.N, e, E);
+    if (rows_done) return;
     // ---- observation: every row is the initial record (+ per-row init noise when length > 1)
     build_row0(c, A, e, E, T, ob, ring, g_lag, true, 0);
     if (c.obs_length > 1) {

@@ -120,7 +120,7 @@ class Config(C.Structure):
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ["rows", "sim", "cold", "derived", "gym", "tprop", "goal", "act_ring", "cmd_ring", "end_ring", "lag_ring",
-                 "window", "lag_depth", "lag_groups", "draw", "aero", "aero_next", "fscale", "fscale_next", "model_raw", "model_raw_next"]]
+                 "window", "lag_depth", "lag_groups", "draw", "aero", "aero_next", "fscale", "fscale_next", "model_raw", "model_raw_next", "fin"]]
 
 
 class ActorWeights(C.Structure):
@@ -145,7 +145,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libfwgym.so")
 EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fwg_update_config", "fwg_seed",
            "fwg_reset", "fwg_step", "fwg_check_actions", "fwg_reduce_success", "fwg_global_step", "fwg_last_error",
            "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index", "fwg_set_graph_mode", "fwg_note_replayed_steps",
-           "fwg_capture_begin", "fwg_capture_end", "fwg_capture_parity", "fwg_replay_check", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
+           "fwg_capture_begin", "fwg_capture_end", "fwg_capture_parity", "fwg_replay_check", "fwg_finish_episodes", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
            "fwg_actor_set_stats", "fwg_actor_get_stats", "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe",
            "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window", "fwg_reduce_success_device",
            "fwg_obs_gather", "fwg_actor_set_obs_log", "fwg_selftest_philox"]
@@ -204,6 +204,8 @@ def load_library(path=None):
     lib.fwg_capture_parity.restype = C.c_int
     lib.fwg_replay_check.argtypes = [vp, C.c_int]
     lib.fwg_replay_check.restype = C.c_int
+    lib.fwg_finish_episodes.argtypes = [vp, vp, vp]
+    lib.fwg_finish_episodes.restype = C.c_int
     f32 = C.c_float
     lib.fwg_actor_create.argtypes = [C.c_int, i64, C.c_int, C.c_int, f32, f32, f32, f32, C.POINTER(vp)]
     lib.fwg_actor_destroy.argtypes = [vp]

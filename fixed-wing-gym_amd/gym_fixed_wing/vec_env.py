@@ -382,6 +382,11 @@ class FixedWingVecEnv(object):
         return actions
 
     # ------------------------------------------------------------------------------------------------------------------
+    def finish_episodes(self):
+        """Turns the finished-episode records of the envs that ended since the last call into the metrics block (and the
+        success sums): fwg_finish_episodes, one small launch, stream-ordered.  The step itself only parks the accumulators."""
+        nat.check(self._lib, self._lib.fwg_finish_episodes(self._handle, self._mem.ptr(self._metrics), self._mem.stream()))
+
     def _host(self, name, t):
         cache = self.__dict__.setdefault("_host_cache", {})
         key = (name, int(self._lib.fwg_global_step(self._handle)))
@@ -389,6 +394,8 @@ class FixedWingVecEnv(object):
             cache.clear()
             cache["key"] = key
         if name not in cache:
+            if name == "metrics":
+                self.finish_episodes()
             cache[name] = self._mem.to_host(t)
         return cache[name]
 

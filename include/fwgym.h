@@ -229,6 +229,8 @@ typedef struct fwg_layout {
     int32_t fscale_next; /* 20: the next episode's | episode it is for, configuration generation, - - */
     int32_t model_raw;      /* model_n rounded up to 4: the sampled values of the listed parameters, this episode (get_simulator_parameters, fixed_wing.py:872-888) */
     int32_t model_raw_next; /* the same for the next episode (validity: the tag of aero_next) */
+    int32_t fin;         /* 28 (metrics only): the raw accumulators of the env's last finished episode, turned into the metrics
+                          * block and the success sums by fwg_finish_episodes / fwg_reduce_success* (flag bit 7 of the flags word) */
 } fwg_layout;
 
 /* rows of the metrics block (float32 [FWG_N_METRICS][N], valid where done) -- get_metric, fixed_wing.py:1095-1162 */
@@ -283,7 +285,8 @@ int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const
  *   done_out         : uint8 [N]
  *   term_code_out    : uint8 [N]  FWG_TERM_*
  *   terminal_obs_out : NULL or float32 [N][obs_dim]; written for done envs only (VecEnv "terminal_observation")
- *   metrics_out      : NULL or float32 [FWG_N_METRICS][N]; written for done envs only
+ *   metrics_out      : NULL or float32 [FWG_N_METRICS][N]; written for done envs, by the NEXT fwg_finish_episodes /
+ *                      fwg_reduce_success* call (the step itself only records the episode's accumulators)
  *   target_out       : NULL or float32 [N][n_targets] = info["target"] (fixed_wing.py:435) after the step */
 int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_out, uint8_t* done_out,
              uint8_t* term_code_out, float* terminal_obs_out, float* metrics_out, float* target_out, void* stream);
@@ -317,6 +320,12 @@ int fwg_check_actions(fwg_handle* h, const float* actions, void* stream);
  * examples/train_rl_controller.py:51-66,80-85; the caller all-gathers them over RCCL.  Synchronises the stream and
  * clears the accumulators. */
 int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream);
+/* Episode ends are recorded by fwg_step as a compact per-env record; THIS call (one small launch, stream-ordered, no
+ * synchronisation) turns the records not yet collected into the metrics block (metrics_out: NULL or float32
+ * [FWG_N_METRICS][N], written for the envs collected) and adds them to the success sums.  fwg_reduce_success and
+ * fwg_reduce_success_device collect first (with the metrics_out of the last fwg_step).  Call it before reading the metrics of
+ * the envs a step reported done; an env that ends a second episode before any collection folds the first record itself. */
+int fwg_finish_episodes(fwg_handle* h, float* metrics_out, void* stream);
 /* The same sums into a DEVICE buffer (16 floats), stream-ordered and without synchronising: the form to hand to the
  * RCCL all-gather directly, so that the rollout never drains the GPU for the success reduction. */
 int fwg_reduce_success_device(fwg_handle* h, float* out_dev, void* stream);

@@ -171,3 +171,28 @@ def test_replay_check_rejects_a_graph_captured_at_the_other_parity(emu_lib):
     vec.step_device(a)
     vec.replay_check(parity)
     vec.close()
+
+
+def test_two_wave_kernel_through_foreseen_episode_ends_emulated():
+    """k_step2 (two waves per 64 envs) with the row log through time-limit episode ends: the next episode's prepared draw is
+    installed and its observation window written before the integration has finished (reset_rows_to_log), the finished
+    episode's accumulators are parked and collected by fwg_finish_episodes.  The configuration is not a preset, so the
+    emulation library is specialised for it (tests/emu build_emu_spec, the host counterpart of gym_fixed_wing/jit.py)."""
+    from emu.host_backend import build_emu_spec
+    from gym_fixed_wing.config import EnvConfig
+    from gym_fixed_wing import presets
+    cfg = configs.reference_like("cnn")
+    ckw = {"steps_max": 33, "observation": {"step": 2}}
+    skw = {"turbulence": True, "turbulence_intensity": "moderate"}
+    import copy
+    ec = EnvConfig(copy.deepcopy(cfg), config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
+    lib = build_emu_spec(ec, auto_reset=True, store_derived=True, obs_log_rows=presets.OBS_LOG_ROWS)
+    n, steps = 5, 150
+    vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True,
+                          _backend=HostBackend(), _lib_path=lib)
+    assert vec.spec_index == 0 and vec.obs_log_rows == presets.OBS_LOG_ROWS
+    orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
+    acts = _actions(7, steps, n)
+    res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3)
+    assert res["episodes"] >= 4 * n
+    vec.close()
