@@ -169,6 +169,21 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     Env E;
     if (PHYS) load_sim<TURB>(c, A.S, A.N, e, E);
     load_cold(c, A.S, A.N, e, E);
+    // k_step2, row-log mode, no attached observer: the padding rows of lanes in the first steps of an episode are built by the
+    // PHYSICS wave in its idle tail (after the integration, while the gym wave runs its post-barrier chain) from the env's
+    // record 0, the per-row noise the gym wave computed in its slack before the barrier, and the new actuator values.
+    // (the gym wave builds them itself when the step fails or ends the episode)
+    const bool tail_rows = SPLIT && c.obs_log > 0 && c.obs_length > 1 && A.acc == nullptr;
+    bool early_p = false;
+    unsigned steps_p = 0u;
+    float rec0_p[FWG_MAX_OBS];
+    if (SPLIT && PHYS && tail_rows) {
+        steps_p = (f2u(load_group(A.S, A.N, (L.gym >> 2), e).w) & 0xFFFFu) + 1u;   // this step's index within the episode
+        early_p = valid && (int)steps_p <= (c.obs_length - 1) * c.obs_step;
+        if (__ballot(early_p) != 0ull) {
+            if (early_p) early_rows_request(c, A, e, rec0_p);
+        }
+    }
 
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
     // LDS copy once the streamed window has landed, i.e. after the integration)
@@ -308,7 +323,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // the end of this block
         const bool early_now = c.obs_log > 0 && c.obs_length > 1 && valid && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
         float rec0[FWG_MAX_OBS];
-        if (__ballot(early_now) != 0ull) {
+        if (!tail_rows && __ballot(early_now) != 0ull) {
             if (early_now) early_rows_request(c, A, e, rec0);
         }
         E.sft += 1u;
@@ -398,7 +413,14 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
         }
         if (__ballot(early_now) != 0ull) {
-            if (early_now) { pre_early = true; early_rows_pre(c, A, e, E, ob, rec0, early_noise); }
+            if (tail_rows) {   // only the noise here (one Philox block, inside the slack); handed to the partner through LDS
+                if (early_now) {
+                    early_row_noise(c, A, e, E.steps, E.episode, early_noise);
+                    float4* w = reinterpret_cast<float4*>(acts);
+                    w[0] = make_float4(early_noise[0], early_noise[1], early_noise[2], early_noise[3]);
+                    w[1] = make_float4(early_noise[4], early_noise[5], early_noise[6], early_noise[7]);
+                }
+            } else if (early_now) { pre_early = true; early_rows_pre(c, A, e, E, ob, rec0, early_noise); }
         }
         // foreseen episode end with a valid prepared draw (row-log mode, no attached observer): the NEW episode's observation
         // window does not depend on how the old one ends -- it goes into the log now, while the partner still integrates (the
@@ -444,6 +466,15 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (valid) store_sim<TURB>(c, A.S, A.N, e, E);
 #endif
         FWG_TL(A, 3);
+        if (SPLIT && tail_rows && __ballot(early_p && ok) != 0ull) {
+            if (early_p && ok) {
+                const float4* w = reinterpret_cast<const float4*>(acts);
+                const float4 n0 = w[0], n1 = w[1];
+                const float rn[FWG_MAX_ROWS] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+                const float actuator[3] = {0.5f * (E.y[13] + E.y[14]), 0.5f * (E.y[14] - E.y[13]), E.y[15]};
+                early_rows_to_log(c, A, e, steps_p, rec0_p, rn, actuator, A.log_win);
+            }
+        }
     }
     if (SPLIT && PHYS) {   // barrier B: the simulator rows are written before the gym wave may overwrite them (auto-reset)
         FWG_DMA_DRAIN();   // s_waitcnt vmcnt(0): covers stores as well
@@ -607,7 +638,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     if (__ballot(reload) != 0ull) {
         if (reload) log_load_rows(c, A.obs, A.N, e, log_win, ob);
     }
-    if (c.obs_length > 1 && (!ok || early)) fix_lagged_rows(c, A, e, E, T, ob, ok, pre_early && !reload, early_noise);
+    // (tail_rows: the partner writes the padding rows of lanes that neither fail nor finish; the others build them here)
+    if (c.obs_length > 1 && (!ok || (early && (!tail_rows || done)))) fix_lagged_rows(c, A, e, E, T, ob, ok, pre_early && !reload, early_noise);
     FWG_TL(A, 15);
     if (c.obs_noise) add_obs_noise(c, A, e, E, ob);
 
@@ -692,10 +724,10 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         write_obs<ROLE>(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull);
     } else {
         if (valid && !pre_rows) log_store_row(c, A.obs, A.N, e, log_win, 0, ob);   // the new record: 64 consecutive rows per wave
-        if (__ballot((done || early) && valid && !pre_rows) != 0ull) {
+        if (__ballot((done || (early && !tail_rows)) && valid && !pre_rows) != 0ull) {
 #pragma unroll
             for (int r = 1; r < FWG_MAX_ROWS; ++r)
-                if (r < c.obs_length && valid && !pre_rows && (done || (early && r * c.obs_step >= (int)log_pad_t)))
+                if (r < c.obs_length && valid && !pre_rows && (done || (early && !tail_rows && r * c.obs_step >= (int)log_pad_t)))
                     log_store_row(c, A.obs, A.N, e, log_win, r, ob);
         }
     }

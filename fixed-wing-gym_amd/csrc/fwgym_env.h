@@ -751,16 +751,64 @@ __device__ __forceinline__ float lag_entry(const DevCfg& c, const KArgs& A, long
 // only fills in the "action" entries.
 // the per-row uniform bits of the "initial record" noise: one Philox block per four rows (stream FWG_STREAM_INIT_NOISE + 256 q,
 // component r & 3), each block computed once
+// STEPPED (every draw after the reset's, c1 = steps >= 1): row 0 is never a padding row then, so row r takes component r - 1
+// -- a window of up to five rows needs ONE Philox block per step instead of two (oracle PhiloxStream.init_noise)
+template <bool STEPPED>
 __device__ __forceinline__ void init_noise_bits(const DevCfg& c, unsigned env_id, unsigned c1, unsigned c2, unsigned seed_lo,
                                                 unsigned seed_hi, unsigned (&bits)[FWG_MAX_ROWS]) {
+    constexpr int SH = STEPPED ? 1 : 0;
+    if (STEPPED) bits[0] = 0u;
 #pragma unroll
     for (int q = 0; q < (FWG_MAX_ROWS + 3) / 4; ++q) {
         u4 b = u4{0u, 0u, 0u, 0u};
-        if (q * 4 < c.obs_length) b = philox4x32(env_id, c1, c2, FWG_STREAM_INIT_NOISE + 256u * q, seed_lo, seed_hi);
-        if (4 * q < FWG_MAX_ROWS) bits[4 * q] = b.x;
-        if (4 * q + 1 < FWG_MAX_ROWS) bits[4 * q + 1] = b.y;
-        if (4 * q + 2 < FWG_MAX_ROWS) bits[4 * q + 2] = b.z;
-        if (4 * q + 3 < FWG_MAX_ROWS) bits[4 * q + 3] = b.w;
+        if (q * 4 + SH < c.obs_length) b = philox4x32(env_id, c1, c2, FWG_STREAM_INIT_NOISE + 256u * q, seed_lo, seed_hi);
+        if (4 * q + SH < FWG_MAX_ROWS) bits[4 * q + SH] = b.x;
+        if (4 * q + 1 + SH < FWG_MAX_ROWS) bits[4 * q + 1 + SH] = b.y;
+        if (4 * q + 2 + SH < FWG_MAX_ROWS) bits[4 * q + 2 + SH] = b.z;
+        if (4 * q + 3 + SH < FWG_MAX_ROWS) bits[4 * q + 3 + SH] = b.w;
+    }
+}
+// the per-row noise U(-1, 1) dt of the padding rows of an env `t` steps into its episode (0 for rows that are not padding)
+__device__ __forceinline__ void early_row_noise(const DevCfg& c, const KArgs& A, long e, unsigned steps, unsigned episode,
+                                                float (&row_noise)[FWG_MAX_ROWS]) {
+    unsigned bits[FWG_MAX_ROWS];
+    init_noise_bits<true>(c, (unsigned)(A.env_base + e), steps, episode, A.seed_lo, A.seed_hi, bits);
+#pragma unroll
+    for (int r = 0; r < FWG_MAX_ROWS; ++r) {
+        row_noise[r] = 0.f;
+        if (r >= 1 && r < c.obs_length && r * c.obs_step >= (int)steps) row_noise[r] = rounded((2.f * u01(bits[r]) - 1.f) * c.dt);
+    }
+}
+// the padding rows of one env from its record 0 and the per-row noise, straight into the row log (k_step2, physics wave,
+// after the integration): "action" entries = the CURRENT actuator value, back-scaled (fixed_wing.py:814-820)
+__device__ __forceinline__ void early_rows_to_log(const DevCfg& c, const KArgs& A, long e, unsigned steps, const float (&rec)[FWG_MAX_OBS],
+                                                  const float (&row_noise)[FWG_MAX_ROWS], const float (&actuator)[3], long long win) {
+#pragma unroll
+    for (int r = 1; r < FWG_MAX_ROWS; ++r) {
+        if (r >= c.obs_length || r * c.obs_step < (int)steps) continue;
+        const float noise = row_noise[r];
+        float v[FWG_MAX_OBS];
+#pragma unroll
+        for (int j = 0; j < FWG_MAX_OBS; ++j) {
+            if (j >= c.n_obs) continue;
+            const DevObs& o = c.obs[j];
+            if (o.type == FWG_OBS_ACTION) {
+                v[j] = backscale_action(c, o.src, actuator[o.src]) + noise;
+                if (o.norm) v[j] = (v[j] - o.mean) * o.inv_var;
+            } else {
+                v[j] = rec[j] + noise * (o.norm ? o.inv_var : 1.f);
+            }
+        }
+        float* dst = log_row(c, A.obs, A.N, e, win + r);
+        if ((c.n_obs & 3) == 0) {
+#pragma unroll
+            for (int q = 0; q < FWG_MAX_OBS / 4; ++q)
+                if (4 * q < c.n_obs) reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < FWG_MAX_OBS; ++j)
+                if (j < c.n_obs) dst[j] = v[j];
+        }
     }
 }
 __device__ __forceinline__ void early_rows_request(const DevCfg& c, const KArgs& A, long e, float (&rec)[FWG_MAX_OBS]) {
@@ -777,7 +825,7 @@ __device__ __forceinline__ void early_rows_pre(const DevCfg& c, const KArgs& A, 
                                                float (&row_noise)[FWG_MAX_ROWS]) {
     const int t = (int)E.steps;
     unsigned bits[FWG_MAX_ROWS];
-    init_noise_bits(c, (unsigned)(A.env_base + e), E.steps, E.episode, A.seed_lo, A.seed_hi, bits);
+    init_noise_bits<true>(c, (unsigned)(A.env_base + e), E.steps, E.episode, A.seed_lo, A.seed_hi, bits);
 #pragma unroll
     for (int r = 1; r < FWG_MAX_ROWS; ++r) {
         row_noise[r] = 0.f;
@@ -796,7 +844,7 @@ __device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A,
     const int depth = c.L.lag_depth;
     const int t = (int)E.steps;
     unsigned bits[FWG_MAX_ROWS] = {};
-    if (!pre && t <= (c.obs_length - 1) * c.obs_step) init_noise_bits(c, (unsigned)(A.env_base + e), E.steps, E.episode, A.seed_lo, A.seed_hi, bits);
+    if (!pre && t <= (c.obs_length - 1) * c.obs_step) init_noise_bits<true>(c, (unsigned)(A.env_base + e), E.steps, E.episode, A.seed_lo, A.seed_hi, bits);
 #pragma unroll
     for (int r = 1; r < FWG_MAX_ROWS; ++r) {
         if (r >= c.obs_length) continue;
@@ -1042,42 +1090,44 @@ __device__ __forceinline__ void draw_state_values(const DynCfg& dc, const KArgs&
         }
     }
 }
-// (2) state vector, derived angles and the sampled targets from the initial values
-template <class TAB>
-__device__ __forceinline__ void draw_state_and_targets(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_new,
-                                                       const float (&v0)[FWG_N_RESET_VARS + 3], TAB& T, ResetDraw& D) {
-    Env R;   // scratch: only the fields sample_targets / fill_vars touch
-    R.episode = episode_new;
-    R.steps = 0u;
-    R.flags = 0u;   // prev_shaping := None, resample counter := 0 (the sticky goal bit is merged by reset_finish)
+// (2a) state vector and derived angles from the initial values
+__device__ __forceinline__ void draw_state(const DevCfg& c, const float (&v0)[FWG_N_RESET_VARS + 3], ResetDraw& D) {
     {
         float sr, cr, sp, cp, sy, cy;
         sincosf(0.5f * v0[FWG_V_ROLL], &sr, &cr);
         sincosf(0.5f * v0[FWG_V_PITCH], &sp, &cp);
         sincosf(0.5f * v0[FWG_V_YAW], &sy, &cy);
-        R.y[0] = cy * cp * cr + sy * sp * sr; R.y[1] = cy * cp * sr - sy * sp * cr;
-        R.y[2] = cy * sp * cr + sy * cp * sr; R.y[3] = sy * cp * cr - cy * sp * sr;
+        D.y[0] = cy * cp * cr + sy * sp * sr; D.y[1] = cy * cp * sr - sy * sp * cr;
+        D.y[2] = cy * sp * cr + sy * cp * sr; D.y[3] = sy * cp * cr - cy * sp * sr;
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) R.y[4 + i] = v0[FWG_V_OMEGA_P + i];
+    for (int i = 0; i < 9; ++i) D.y[4 + i] = v0[FWG_V_OMEGA_P + i];
     {
         const float el = fclampf(v0[FWG_V_ELEVATOR], c.val_min[FWG_V_ELEVATOR], c.val_max[FWG_V_ELEVATOR]);
         const float ai = fclampf(v0[FWG_V_AILERON], c.val_min[FWG_V_AILERON], c.val_max[FWG_V_AILERON]);
-        R.y[13] = el - ai; R.y[14] = el + ai;
-        R.y[15] = fclampf(v0[FWG_V_THROTTLE], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
-        R.y[16] = 0.f; R.y[17] = 0.f;
+        D.y[13] = el - ai; D.y[14] = el + ai;
+        D.y[15] = fclampf(v0[FWG_V_THROTTLE], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
+        D.y[16] = 0.f; D.y[17] = 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) R.wind[i] = v0[FWG_V_WIND_N + i];
+    for (int i = 0; i < 3; ++i) D.wind[i] = v0[FWG_V_WIND_N + i];
     const float gust0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    R.d = derive<false>(R.y, R.wind, gust0);
+    D.d = derive<false>(D.y, D.wind, gust0);
+}
+// (2b) the sampled targets for that state (D.y, D.wind, D.d set)
+template <class TAB>
+__device__ __forceinline__ void draw_targets(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_new, TAB& T, ResetDraw& D) {
+    Env R;   // scratch: only the fields sample_targets / fill_vars touch
+    R.episode = episode_new;
+    R.steps = 0u;
+    R.flags = 0u;   // prev_shaping := None, resample counter := 0 (the sticky goal bit is merged by reset_finish)
+#pragma unroll
+    for (int i = 0; i < NY; ++i) R.y[i] = D.y[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) R.wind[i] = D.wind[i];
+    R.d = D.d;
     fill_vars(R, T);
     sample_targets(c, dc, A, e, R, T, A.init_target);
-#pragma unroll
-    for (int i = 0; i < NY; ++i) D.y[i] = R.y[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) D.wind[i] = R.wind[i];
-    D.d = R.d;
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
         D.tgt[k] = R.tgt[k];
@@ -1086,10 +1136,16 @@ __device__ __forceinline__ void draw_state_and_targets(const DevCfg& c, const Dy
     }
     D.flags = R.flags; D.episode = R.episode;
 }
+template <class TAB>
+__device__ __forceinline__ void draw_state_and_targets(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_new,
+                                                       const float (&v0)[FWG_N_RESET_VARS + 3], TAB& T, ResetDraw& D) {
+    draw_state(c, v0, D);
+    draw_targets(c, dc, A, e, episode_new, T, D);
+}
 // (3) per-row initial noise of the lagged rows (fixed_wing.py:792-795,831-832)
 __device__ __forceinline__ void draw_row_noise(const DevCfg& c, const KArgs& A, long e, unsigned episode_new, ResetDraw& D) {
     unsigned bits[FWG_MAX_ROWS] = {};
-    if (c.obs_length > 1) init_noise_bits(c, (unsigned)(A.env_base + e), 0u, episode_new, A.seed_lo, A.seed_hi, bits);
+    if (c.obs_length > 1) init_noise_bits<false>(c, (unsigned)(A.env_base + e), 0u, episode_new, A.seed_lo, A.seed_hi, bits);
 #pragma unroll
     for (int r = 0; r < FWG_MAX_ROWS; ++r) {
         D.row_noise[r] = 0.f;
@@ -1110,22 +1166,25 @@ __device__ __forceinline__ void reset_sample(const DevCfg& c, const DynCfg& dc, 
 // ---- The NEXT episode's draw, prepared ahead of time.  After every reset the step kernel computes the draw of the episode
 // that will follow, one piece per env step in the gym wave's idle time before the barrier (4 steps), into a cold arena
 // section (L.draw, 11 groups + 3 with dynamic targets); when the episode ends -- time limit, failure or success alike --
-// reset_finish only has to load it.  Stage (flags bits 4..6): 0 nothing yet | 1 values 0..11 | 2 values 0..20 | 3 state,
-// angles, targets | 4 complete.  Every piece carries the configuration generation (DynCfg::generation, bumped by
+// reset_finish only has to load it.  Stage (flags bits 4..6): 0 nothing yet | 1 values 0..7 | 2 values 0..15 | 3 values 0..20 |
+// 4 state, angles | 5 targets | 6 complete.  Every piece carries the configuration generation (DynCfg::generation, bumped by
 // fwg_update_config / fwg_seed): a draw sampled from other ranges or another seed is discarded.
 // Final layout (groups): 0-3 y[0..15] | 4 wind, - | 5 roll pitch yaw Va | 6 alpha beta tgt0 tgt1 | 7 tgt2 - - - |
 // 8-9 row noise | 10 generation, episode, flags, - | 11-13 target properties.  Stages 1-2 keep the raw values in groups 0-5.
 #define FWG_DRAW_STAGE_SHIFT 4
 #define FWG_DRAW_STAGE_MASK (7u << FWG_DRAW_STAGE_SHIFT)
-#define FWG_DRAW_READY 4u
+#define FWG_DRAW_READY 6u
 __device__ __forceinline__ unsigned draw_stage_of(unsigned flags) { return (flags & FWG_DRAW_STAGE_MASK) >> FWG_DRAW_STAGE_SHIFT; }
-__device__ __forceinline__ void draw_store_final(const DevCfg& c, float* __restrict__ S, long N, long e, const ResetDraw& D, bool with_noise) {
+// part 0: state, wind, derived angles | part 1: targets (+ alpha, beta, which share their group) | part 2: row noise
+__device__ __forceinline__ void draw_store_final(const DevCfg& c, float* __restrict__ S, long N, long e, const ResetDraw& D, int part) {
     const int g0 = c.L.draw >> 2;
-    if (!with_noise) {
+    if (part == 0) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) GROUP(S, N, g0 + g, e) = make_float4(D.y[4 * g], D.y[4 * g + 1], D.y[4 * g + 2], D.y[4 * g + 3]);
         GROUP(S, N, g0 + 4, e) = make_float4(D.wind[0], D.wind[1], D.wind[2], 0.f);
         GROUP(S, N, g0 + 5, e) = make_float4(D.d.roll, D.d.pitch, D.d.yaw, D.d.Va);
+        GROUP(S, N, g0 + 6, e) = make_float4(D.d.alpha, D.d.beta, 0.f, 0.f);
+    } else if (part == 1) {
         GROUP(S, N, g0 + 6, e) = make_float4(D.d.alpha, D.d.beta, D.tgt[0], D.tgt[1]);
         GROUP(S, N, g0 + 7, e) = make_float4(D.tgt[2], 0.f, 0.f, 0.f);
         if (c.any_dynamic_target) {
@@ -1160,7 +1219,9 @@ __device__ __forceinline__ void draw_load_final(const DevCfg& c, const float* __
 }
 // generation | episode the draw is for | flags after sample_targets
 __device__ __forceinline__ float4 draw_tag(const float* __restrict__ S, long N, long e, const DevCfg& c) { return CGROUP(S, N, (c.L.draw >> 2) + 10, e); }
-// one piece of the next episode's draw (called for lanes whose stage is below FWG_DRAW_READY); returns the new stage
+// one piece of the next episode's draw (called for lanes whose stage is below FWG_DRAW_READY); returns the new stage.
+// Six pieces of at most two or three Philox blocks each, so that a piece fits into the gym wave's wait for its partner:
+// 0-2 the sampled initial values (two blocks each) | 3 state vector and derived angles | 4 targets | 5 per-row noise
 template <class TAB>
 __device__ __forceinline__ unsigned draw_stage_step(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_now,
                                                     unsigned stage, TAB& T) {
@@ -1172,34 +1233,52 @@ __device__ __forceinline__ unsigned draw_stage_step(const DevCfg& c, const DynCf
     }
     float v0[FWG_N_RESET_VARS + 3];
     if (stage == 0u) {
-        draw_state_values<0, 3>(dc, A, e, episode_new, v0);
+        draw_state_values<0, 2>(dc, A, e, episode_new, v0);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) GROUP(A.S, A.N, g0 + g, e) = make_float4(v0[4 * g], v0[4 * g + 1], v0[4 * g + 2], v0[4 * g + 3]);
+        for (int g = 0; g < 2; ++g) GROUP(A.S, A.N, g0 + g, e) = make_float4(v0[4 * g], v0[4 * g + 1], v0[4 * g + 2], v0[4 * g + 3]);
         GROUP(A.S, A.N, g0 + 10, e) = make_float4(u2f(dc.generation), u2f(episode_new), 0.f, 0.f);
         return 1u;
     }
     if (stage == 1u) {
-        draw_state_values<3, 3>(dc, A, e, episode_new, v0);
-        GROUP(A.S, A.N, g0 + 3, e) = make_float4(v0[12], v0[13], v0[14], v0[15]);
-        GROUP(A.S, A.N, g0 + 4, e) = make_float4(v0[16], v0[17], v0[18], v0[19]);
-        GROUP(A.S, A.N, g0 + 5, e) = make_float4(v0[20], 0.f, 0.f, 0.f);
+        draw_state_values<2, 2>(dc, A, e, episode_new, v0);
+#pragma unroll
+        for (int g = 2; g < 4; ++g) GROUP(A.S, A.N, g0 + g, e) = make_float4(v0[4 * g], v0[4 * g + 1], v0[4 * g + 2], v0[4 * g + 3]);
         return 2u;
     }
-    ResetDraw D;
     if (stage == 2u) {
+        draw_state_values<4, 2>(dc, A, e, episode_new, v0);
+        GROUP(A.S, A.N, g0 + 4, e) = make_float4(v0[16], v0[17], v0[18], v0[19]);
+        GROUP(A.S, A.N, g0 + 5, e) = make_float4(v0[20], 0.f, 0.f, 0.f);
+        return 3u;
+    }
+    ResetDraw D;
+    if (stage == 3u) {
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
             const float4 q = CGROUP(A.S, A.N, g0 + g, e);
             v0[4 * g] = q.x;
             if (4 * g + 1 < FWG_N_RESET_VARS + 3) { v0[4 * g + 1] = q.y; v0[4 * g + 2] = q.z; v0[4 * g + 3] = q.w; }
         }
-        draw_state_and_targets(c, dc, A, e, episode_new, v0, T, D);
-        draw_store_final(c, A.S, A.N, e, D, false);
+        draw_state(c, v0, D);
+        draw_store_final(c, A.S, A.N, e, D, 0);
+        return 4u;
+    }
+    if (stage == 4u) {
+        float4 q[7];
+#pragma unroll
+        for (int g = 0; g < 7; ++g) q[g] = CGROUP(A.S, A.N, g0 + g, e);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { D.y[4 * g] = q[g].x; D.y[4 * g + 1] = q[g].y; D.y[4 * g + 2] = q[g].z; D.y[4 * g + 3] = q[g].w; }
+        D.y[16] = 0.f; D.y[17] = 0.f;
+        D.wind[0] = q[4].x; D.wind[1] = q[4].y; D.wind[2] = q[4].z;
+        D.d.roll = q[5].x; D.d.pitch = q[5].y; D.d.yaw = q[5].z; D.d.Va = q[5].w; D.d.alpha = q[6].x; D.d.beta = q[6].y;
+        draw_targets(c, dc, A, e, episode_new, T, D);
+        draw_store_final(c, A.S, A.N, e, D, 1);
         GROUP(A.S, A.N, g0 + 10, e) = make_float4(u2f(dc.generation), u2f(episode_new), u2f(D.flags), 0.f);
-        return 3u;
+        return 5u;
     }
     draw_row_noise(c, A, e, episode_new, D);
-    draw_store_final(c, A.S, A.N, e, D, true);
+    draw_store_final(c, A.S, A.N, e, D, 2);
     return FWG_DRAW_READY;
 }
 

@@ -127,8 +127,11 @@ class PhiloxStream:
         return low + (high - low) * self.ph.u01(b[0])
 
     def init_noise(self, row):
-        b = self._bits(self.steps, self.episode, self.ph.STREAM_INIT_NOISE, block=row // 4)
-        return 2.0 * self.ph.u01(b[row % 4]) - 1.0
+        # after the reset's own draw (steps >= 1) row 0 is never a padding row: row r takes component r - 1, so that a window
+        # of up to five rows costs the device ONE Philox block per step (csrc/fwgym_env.h init_noise_bits<true>)
+        idx = row if self.steps == 0 else row - 1
+        b = self._bits(self.steps, self.episode, self.ph.STREAM_INIT_NOISE, block=idx // 4)
+        return 2.0 * self.ph.u01(b[idx % 4]) - 1.0
 
     def obs_normal(self, idx, mean, std):
         if std == 0 and mean == 0:
