@@ -169,20 +169,20 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     Env E;
     if (PHYS) load_sim<TURB>(c, A.S, A.N, e, E);
     load_cold(c, A.S, A.N, e, E);
-    // k_step2, row-log mode, no attached observer: the padding rows of lanes in the first steps of an episode are built by the
-    // PHYSICS wave in its idle tail (after the integration, while the gym wave runs its post-barrier chain) from the env's
-    // record 0, the per-row noise the gym wave computed in its slack before the barrier, and the new actuator values.
-    // (the gym wave builds them itself when the step fails or ends the episode)
+    // k_step2, row-log mode, no attached observer: the PHYSICS wave owns the work that prepares the state the NEXT step starts
+    // from, in its idle tail (after the integration, while the gym wave runs its post-barrier chain):
+    //  * tail_rows   -- the padding rows of lanes in the first steps of an episode (record 0 + fresh per-row noise + the new
+    //                   actuator values), written straight into the row log;
+    //  * pre_install -- for an episode end known before the integration (time limit) with a valid prepared draw: the new
+    //                   episode's observation window, its record 0, its simulator and cold rows.
+    // It reads the step counter and the flags word itself; the loads are issued here and not looked at before the
+    // integration is done.  (steps that fail or end an episode otherwise are completed by the gym wave as before)
     const bool tail_rows = SPLIT && c.obs_log > 0 && c.obs_length > 1 && A.acc == nullptr;
-    bool early_p = false;
-    unsigned steps_p = 0u;
-    float rec0_p[FWG_MAX_OBS];
-    if (SPLIT && PHYS && tail_rows) {
-        steps_p = (f2u(load_group(A.S, A.N, (L.gym >> 2), e).w) & 0xFFFFu) + 1u;   // this step's index within the episode
-        early_p = valid && (int)steps_p <= (c.obs_length - 1) * c.obs_step;
-        if (__ballot(early_p) != 0ull) {
-            if (early_p) early_rows_request(c, A, e, rec0_p);
-        }
+    const bool pre_install = SPLIT && c.auto_reset && c.obs_log > 0 && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 && A.acc == nullptr;
+    float4 pg0 = make_float4(0.f, 0.f, 0.f, 0.f), pg1 = pg0;
+    if (SPLIT && PHYS && (tail_rows || pre_install)) {
+        pg0 = load_group(A.S, A.N, (L.gym >> 2), e);
+        pg1 = load_group(A.S, A.N, (L.gym >> 2) + 1, e);
     }
 
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
@@ -267,6 +267,23 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         h4[2] = make_float4(E.y[12], E.y[13], E.y[14], E.y[15]);
         h4[3] = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
         h4[4] = make_float4(E.d.alpha, E.d.beta, u2f((unsigned)fail), 0.f);
+    }
+    // physics wave: what its tail work needs from memory is requested now (the round trips run under the barrier wait)
+    unsigned steps_p = 0u;
+    bool early_p = false, end_p = false;
+    float rec0_p[FWG_MAX_OBS];
+    float4 tag_p = make_float4(0.f, 0.f, 0.f, 0.f);
+    ResetDraw RDp;
+    if (SPLIT && PHYS && (tail_rows || pre_install)) {
+        steps_p = (f2u(pg0.w) & 0xFFFFu) + 1u;   // this step's index within the episode
+        early_p = tail_rows && valid && fail == 0 && (int)steps_p <= (c.obs_length - 1) * c.obs_step;
+        end_p = pre_install && valid && steps_p >= (unsigned)c.steps_max && draw_stage_of(f2u(pg1.x)) == FWG_DRAW_READY;
+        if (__ballot(early_p) != 0ull) {
+            if (early_p) early_rows_request(c, A, e, rec0_p);
+        }
+        if (__ballot(end_p) != 0ull) {
+            if (end_p) { tag_p = draw_tag(A.S, A.N, e, c); draw_load_final(c, A.S, A.N, e, RDp); }
+        }
     }
     float n[4] = {0.f, 0.f, 0.f, 0.f};   // the step's four standard normals for the Dryden filter
     if (TURB && GYM) {   // (counters: the step and episode indices BEFORE this step; independent of the integration)
@@ -412,32 +429,20 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 }
             }
         }
-        if (__ballot(early_now) != 0ull) {
-            if (tail_rows) {   // only the noise here (one Philox block, inside the slack); handed to the partner through LDS
-                if (early_now) {
-                    early_row_noise(c, A, e, E.steps, E.episode, early_noise);
-                    float4* w = reinterpret_cast<float4*>(acts);
-                    w[0] = make_float4(early_noise[0], early_noise[1], early_noise[2], early_noise[3]);
-                    w[1] = make_float4(early_noise[4], early_noise[5], early_noise[6], early_noise[7]);
-                }
-            } else if (early_now) { pre_early = true; early_rows_pre(c, A, e, E, ob, rec0, early_noise); }
+        if (!tail_rows && __ballot(early_now) != 0ull) {
+            if (early_now) { pre_early = true; early_rows_pre(c, A, e, E, ob, rec0, early_noise); }
         }
-        // foreseen episode end with a valid prepared draw (row-log mode, no attached observer): the NEW episode's observation
-        // window does not depend on how the old one ends -- it goes into the log now, while the partner still integrates (the
-        // terminal observation's lagged rows were read from those planes above: same wave, in order)
-        if (SPLIT && c.auto_reset && c.obs_log > 0 && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 && A.acc == nullptr) {
-            if (__ballot(pre_draw) != 0ull) {
-                if (pre_draw && f2u(pre_tag.x) == dc.generation && f2u(pre_tag.y) == E.episode + 1u) {
-                    reset_rows_to_log(c, A, e, RD, c.use_cmd_ring ? cring : aring, A.slot_lag, A.log_win);
-                    pre_rows = true;
-                }
-            }
-        }
+        // foreseen episode end with a valid prepared draw: the partner installs the new episode (see above); this wave only
+        // needs to know that it does.  Both waves decide from the same words (stage, tag, generation, episode)
+        if (pre_install) pre_rows = pre_draw && f2u(pre_tag.x) == dc.generation && f2u(pre_tag.y) == E.episode + 1u;
     };
     if (SPLIT && GYM) {
         FWG_DMA_DRAIN();   // this wave's own streamed windows have landed (no other wave reads them)
         FWG_WAVE_SYNC();
         gym_prework();
+        // (a foreseen end whose new window the partner writes after the barrier: the terminal observation's lagged rows,
+        // requested above from the planes it will overwrite, must have landed)
+        if (pre_install && __ballot(pre_rows) != 0ull) FWG_DMA_DRAIN();
         FWG_TL(A, 2);
     }
     if (SPLIT) FWG_BLOCK_SYNC_LDS();     // barrier A
@@ -462,15 +467,31 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             dryden_advance(c, E.dry, n);
             if (c.turb_increment) dryden_next_gust(c, x_old, E.dry, E.gust);
         }
+        if (SPLIT && pre_install && __ballot(end_p) != 0ull) {
+            // foreseen episode end: the NEXT episode goes into the simulator / cold rows and the row log (the old episode's final
+            // state went to the partner through LDS above)
+            if (end_p && f2u(tag_p.x) == dc.generation && f2u(tag_p.y) == E.episode + 1u) {
+                reset_rows_to_log(c, A, e, RDp, aring, A.slot_lag, A.log_win);
+#pragma unroll
+                for (int i = 0; i < NY; ++i) E.y[i] = RDp.y[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) E.wind[i] = RDp.wind[i];
+                E.episode += 1u;
+#pragma unroll
+                for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) E.gust[i] = 0.f;
+                store_cold(c, A.S, A.N, e, E);
+            }
+        }
 #ifndef FWG_ABL_NO_SIMSTORE
         if (valid) store_sim<TURB>(c, A.S, A.N, e, E);
 #endif
         FWG_TL(A, 3);
-        if (SPLIT && tail_rows && __ballot(early_p && ok) != 0ull) {
-            if (early_p && ok) {
-                const float4* w = reinterpret_cast<const float4*>(acts);
-                const float4 n0 = w[0], n1 = w[1];
-                const float rn[FWG_MAX_ROWS] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+        if (SPLIT && tail_rows && __ballot(early_p) != 0ull) {
+            if (early_p) {   // (fail == 0: a failed step's rows are the gym wave's)
+                float rn[FWG_MAX_ROWS];
+                early_row_noise(c, A, e, steps_p, E.episode, rn);
                 const float actuator[3] = {0.5f * (E.y[13] + E.y[14]), 0.5f * (E.y[14] - E.y[13]), E.y[15]};
                 early_rows_to_log(c, A, e, steps_p, rec0_p, rn, actuator, A.log_win);
             }
@@ -674,11 +695,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                     }
                     R.end_sum[0] -= r.x; R.end_sum[1] -= r.y; R.end_sum[2] -= r.z;
                 }
-                if (E.flags & FWG_FLAG_FIN_PENDING) {   // (rare) the previous record was never collected: fold it now
-                    FinRec old;
-                    fin_load(c, A.S, A.N, e, old);
-                    fin_collect_lane(c, A, e, old);
-                }
+                if (E.flags & FWG_FLAG_FIN_PENDING) fin_collect_pending(c, A, e);   // (rare) never collected: fold it now
                 fin_store(c, A.S, A.N, e, R);
                 E.flags |= FWG_FLAG_FIN_PENDING;
                 if (!c.auto_reset) GROUP(A.S, A.N, (L.gym >> 2) + 1, e) = make_float4(u2f(E.flags), u2f(E.wcnt), u2f(E.gcnt[0]), u2f(E.gcnt[1]));
@@ -711,7 +728,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             if (ready) { if (!pre_draw) draw_load_final(c, A.S, A.N, e, RD); }
             else reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);   // episode ended before its successor's draw was complete
             reset_finish<TURB>(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal, RD, true, pre_rows);
-            store_sim<TURB>(c, A.S, A.N, e, E);
+            if (!pre_rows) store_sim<TURB>(c, A.S, A.N, e, E);   // (pre_rows: the partner wrote the new simulator rows)
             store_gym(c, A.S, A.N, e, E, A.bit_goal, true, true);
         }
     }

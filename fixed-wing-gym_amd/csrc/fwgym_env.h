@@ -228,9 +228,20 @@ __device__ __forceinline__ void log_load_rows(const DevCfg& c, const float* log,
     for (int r = 1; r < FWG_MAX_ROWS; ++r) {
         if (r < c.obs_length) {
             const float* row = log + (((win + r) * N + e) * c.n_obs);
+            if ((c.n_obs & 3) == 0) {   // 16 bytes per load (the rows are 16-byte aligned then)
 #pragma unroll
-            for (int j = 0; j < FWG_MAX_OBS; ++j)
-                if (j < c.n_obs) ob.put(r * c.n_obs + j, row[j]);
+                for (int q = 0; q < FWG_MAX_OBS / 4; ++q) {
+                    if (4 * q < c.n_obs) {
+                        const float4 v = reinterpret_cast<const float4*>(row)[q];
+                        ob.put(r * c.n_obs + 4 * q, v.x); ob.put(r * c.n_obs + 4 * q + 1, v.y);
+                        ob.put(r * c.n_obs + 4 * q + 2, v.z); ob.put(r * c.n_obs + 4 * q + 3, v.w);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < FWG_MAX_OBS; ++j)
+                    if (j < c.n_obs) ob.put(r * c.n_obs + j, row[j]);
+            }
         }
     }
 }
@@ -262,7 +273,7 @@ __host__ __device__ inline int obs_stage_stride(int obs_dim) { return obs_vec4(o
 // the staging area comes after workgroup barrier B, every hand-off access before it.  Workgroup residency is bounded by
 // LDS (4 workgroups per CU need <= 40 KiB each; a fifth area would cost a fourth of the chip).
 #define FWG_HAND_WORDS 20   /* y[4..15] | roll pitch yaw Va alpha beta | failure code | pad: five 16-byte LDS accesses per lane */
-#define FWG_ACT_WORDS 12    /* actuator states at t + h/2 and t + h (2 x 5) | pad: three 16-byte LDS accesses per lane */
+#define FWG_ACT_WORDS 12    /* actuator states at t + h/2 and t + h (2 x 5) | pad: three 16-byte LDS accesses per lane (FWG_EXT_ACTUATORS) */
 #define FWG_SPLIT_WORDS (FWG_HAND_WORDS + 4 + FWG_ACT_WORDS)
 __host__ __device__ inline LdsMap lds_map(int obs_dim, int n_obs, int window, int use_cmd_ring, bool generic, int obs_log = 0,
                                           bool split = false) {
@@ -1038,8 +1049,12 @@ __device__ __forceinline__ void finish_metrics(const DevCfg& c, const FinRec& R,
 __device__ __forceinline__ unsigned long long reduce_fixed(int i, float v) {
     return (unsigned long long)(long long)rintf(i < 5 ? v : v * FWG_ACC_SCALE);
 }
-// one lane collects one record on its own (rare: the env ends a second episode before any fwg_finish_episodes)
-__device__ __forceinline__ void fin_collect_lane(const DevCfg& c, const KArgs& A, long e, const FinRec& R) {
+// one lane collects its own pending record (rare: the env ends a second episode before any fwg_finish_episodes).
+// (measured: as a real -- noinline, cold -- function it made EVERY launch 40 % slower, 16.8 instead of 12.1 us per C3 step:
+// a call anywhere in the kernel brings the stack set-up to every wave's entry, 0.7k -> 4.7k ticks)
+__device__ __forceinline__ void fin_collect_pending(const DevCfg& c, const KArgs& A, long e) {
+    FinRec R;
+    fin_load(c, A.S, A.N, e, R);
     float mt[FWG_N_METRICS], red[FWG_N_REDUCE];
     finish_metrics(c, R, mt, red);
     if (A.metrics != nullptr) {
@@ -1392,8 +1407,8 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
         if (!have_gw) E.gw = reinterpret_cast<const unsigned*>(A.S)[((unsigned)c.L.goal + (unsigned)(g_bit >> 3)) * (unsigned)A.N + (unsigned)e];
         goal_push(c, E, goal_flags(c, err), g_bit, 0u);   // ... and written back by store_gym
     }
+    if (rows_done) return;   // (k_step2, foreseen end: the partner wave wrote the cold and simulator rows as well)
     store_cold(c, A.S, A.N, e, E);
-    if (rows_done) return;
     // ---- observation: every row is the initial record (+ per-row init noise when length > 1)
     build_row0(c, A, e, E, T, ob, ring, g_lag, true, 0);
     if (c.obs_length > 1) {

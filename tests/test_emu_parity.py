@@ -196,3 +196,24 @@ def test_two_wave_kernel_through_foreseen_episode_ends_emulated():
     res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3)
     assert res["episodes"] >= 4 * n
     vec.close()
+
+
+def test_uncollected_episode_records_are_folded_not_lost(emu_lib):
+    """Episode ends park a record; fwg_finish_episodes / fwg_reduce_success* turn it into metrics and success sums.  An env
+    that ends a SECOND episode before any collection folds the first record itself (fin_collect_pending): the sums of a run
+    that never collects until the end equal those of a run that collects after every step."""
+    cfg = configs.default()
+    n, steps = 8, 40
+    a = _actions(3, steps, n)
+    sums = []
+    for collect_every_step in (False, True):
+        vec = FixedWingVecEnv(cfg, num_envs=n, config_kw={"steps_max": 12}, seed=4, as_numpy=True, _backend=HostBackend(), _lib_path=emu_lib)
+        vec.reset()
+        for t in range(steps):
+            vec.step_device(a[t])
+            if collect_every_step:
+                vec.finish_episodes()
+        sums.append(vec.reduce_success())
+        vec.close()
+    assert sums[0][0] == n * (steps // 12)
+    np.testing.assert_allclose(sums[0], sums[1], rtol=0, atol=2e-6 * n * steps)

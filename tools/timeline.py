@@ -96,6 +96,23 @@ def run():
         worst = int(np.nanargmax(np.nanmax(last, axis=(1, 2))))
         order = np.argsort(-np.nanmax(last, axis=(1, 2)))
         steps_now = vec.field("steps_count").cpu().numpy()
+        # lifetimes by what the block hosted in the last launch: an ending lane, lanes in their first steps, a piece of the next
+        # episode's draw (flags bits 4..6 below the ready mark), or nothing special
+        life_b = np.nanmax(last, axis=(1, 2))
+        done_b = vec._done.cpu().numpy().reshape(-1, 64).sum(axis=1) > 0
+        flags = vec.field("flags").cpu().numpy()
+        early_b = (steps_now.reshape(-1, 64) <= 8).sum(axis=1) > 0 if steps_now is not None else np.zeros_like(done_b)
+        stage = (flags.reshape(-1, 64) >> 4) & 7
+        draw_b = ((stage > 0) & (stage < 6)).sum(axis=1) > 0        # (a piece was computed in this or an earlier launch)
+        classes = {"episode end": done_b, "early lanes (no end)": early_b & ~done_b, "draw piece (no end, not early)": draw_b & ~done_b & ~early_b,
+                   "plain": ~done_b & ~early_b & ~draw_b}
+        res[key]["lifetime_by_class"] = {}
+        for name, m in classes.items():
+            if m.sum():
+                res[key]["lifetime_by_class"][name] = {"blocks": int(m.sum()), "median": float(np.median(life_b[m])), "p90": float(np.percentile(life_b[m], 90)),
+                                                        "max": float(life_b[m].max())}
+                print("   {:34s} blocks {:4d}  lifetime median {:.0f}  p90 {:.0f}  max {:.0f}".format(name, int(m.sum()), np.median(life_b[m]),
+                                                                                                       np.percentile(life_b[m], 90), life_b[m].max()))
         for worst in [int(order[0]), int(order[8]), int(order[40]), int(order[200])]:
             print("   block {} of the last launch (lifetime {:.0f}, done lanes in the wave: {}{}):".format(
                 worst, np.nanmax(last[worst]), int(vec._done[worst * 64:(worst + 1) * 64].sum().item()),
