@@ -36,7 +36,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALG_BYTES = {"c3": 937, "c4": 937, "c2": 417, "c5": 409}   # algorithmic bytes per env-step, SURVEY.md section 8(d)
 MAX_CHUNK = 256                # steps per captured graph; the success reduction runs once per chunk
 STEADY_STATE_STEPS = 300       # untimed launches before the W warm-up steps (clocks / caches / code objects), disclosed in the line
-SIDE_STEPS = 400               # timed steps of every side measurement (steady state, observation consumer, other configurations)
+SIDE_STEPS = 512               # timed steps of every side measurement (steady state, observation consumer, other configurations)
+SIDE_CHUNK = 128               # ... replayed as hipGraphs of one rollout each (success reduction / all-gather once per rollout)
 
 
 def workload(name):
@@ -404,13 +405,16 @@ def main():
     # ---- side measurements (same launches, other regimes / consumers / configurations); never part of `value`
     sides = {}
     side_ok = graphs and not fused and not args.emulate and not args.no_side
-    sc = chunk if chunk else 20
+    # side measurements replay chunks of one PPO rollout (128 steps, the n_steps of the reference's shipped models and the
+    # all-gather interval of BASELINE configs[3]) whatever --steps is: a 20-step chunk would put the per-chunk costs -- graph
+    # launch, episode collection, success sums, all-gather -- on every 20th step, which no training run does
+    sc = SIDE_CHUNK
     sreps = max(1, (SIDE_STEPS + sc - 1) // sc)
     alg_b = ALG_BYTES[args.workload]
 
     def side_entry(ms, n, alg=alg_b, **more):
         e = {"ms_per_step": ms, "value": n / (ms * 1e-3), "unit": "env-steps/s", "roofline_frac": alg * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-             "steps": sreps * sc}
+             "steps": sreps * sc, "chunk": sc}
         e.update(more)
         return e
 

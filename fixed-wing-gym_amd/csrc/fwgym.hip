@@ -175,15 +175,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     //                   actuator values), written straight into the row log;
     //  * pre_install -- for an episode end known before the integration (time limit) with a valid prepared draw: the new
     //                   episode's observation window, its record 0, its simulator and cold rows.
-    // It reads the step counter and the flags word itself; the loads are issued here and not looked at before the
-    // integration is done.  (steps that fail or end an episode otherwise are completed by the gym wave as before)
+    // Which lanes are concerned it learns from the gym wave through LDS at the barrier (a load of the counters of its own would
+    // have to be waited for at the kernel entry or be kept from the scheduler's hoisting: both measured slower).
+    // (steps that fail or end an episode otherwise are completed by the gym wave as before)
     const bool tail_rows = SPLIT && c.obs_log > 0 && c.obs_length > 1 && A.acc == nullptr;
     const bool pre_install = SPLIT && c.auto_reset && c.obs_log > 0 && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 && A.acc == nullptr;
-    float4 pg0 = make_float4(0.f, 0.f, 0.f, 0.f), pg1 = pg0;
-    if (SPLIT && PHYS && (tail_rows || pre_install)) {
-        pg0 = load_group(A.S, A.N, (L.gym >> 2), e);
-        pg1 = load_group(A.S, A.N, (L.gym >> 2) + 1, e);
-    }
 
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
     // LDS copy once the streamed window has landed, i.e. after the integration)
@@ -267,23 +263,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         h4[2] = make_float4(E.y[12], E.y[13], E.y[14], E.y[15]);
         h4[3] = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
         h4[4] = make_float4(E.d.alpha, E.d.beta, u2f((unsigned)fail), 0.f);
-    }
-    // physics wave: what its tail work needs from memory is requested now (the round trips run under the barrier wait)
-    unsigned steps_p = 0u;
-    bool early_p = false, end_p = false;
-    float rec0_p[FWG_MAX_OBS];
-    float4 tag_p = make_float4(0.f, 0.f, 0.f, 0.f);
-    ResetDraw RDp;
-    if (SPLIT && PHYS && (tail_rows || pre_install)) {
-        steps_p = (f2u(pg0.w) & 0xFFFFu) + 1u;   // this step's index within the episode
-        early_p = tail_rows && valid && fail == 0 && (int)steps_p <= (c.obs_length - 1) * c.obs_step;
-        end_p = pre_install && valid && steps_p >= (unsigned)c.steps_max && draw_stage_of(f2u(pg1.x)) == FWG_DRAW_READY;
-        if (__ballot(early_p) != 0ull) {
-            if (early_p) early_rows_request(c, A, e, rec0_p);
-        }
-        if (__ballot(end_p) != 0ull) {
-            if (end_p) { tag_p = draw_tag(A.S, A.N, e, c); draw_load_final(c, A.S, A.N, e, RDp); }
-        }
     }
     float n[4] = {0.f, 0.f, 0.f, 0.f};   // the step's four standard normals for the Dryden filter
     if (TURB && GYM) {   // (counters: the step and episode indices BEFORE this step; independent of the integration)
@@ -435,6 +414,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // foreseen episode end with a valid prepared draw: the partner installs the new episode (see above); this wave only
         // needs to know that it does.  Both waves decide from the same words (stage, tag, generation, episode)
         if (pre_install) pre_rows = pre_draw && f2u(pre_tag.x) == dc.generation && f2u(pre_tag.y) == E.episode + 1u;
+        if (tail_rows || pre_install)   // (every lane) for the partner: this step's index if its rows need padding | install flag
+            *reinterpret_cast<float4*>(acts) = make_float4(u2f((tail_rows && early_now) ? E.steps : 0u), u2f(pre_rows ? 1u : 0u), 0.f, 0.f);
     };
     if (SPLIT && GYM) {
         FWG_DMA_DRAIN();   // this wave's own streamed windows have landed (no other wave reads them)
@@ -449,6 +430,23 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     if (SPLIT && PHYS && TURB) {
         const float4 q = *reinterpret_cast<const float4*>(noise);
         n[0] = q.x; n[1] = q.y; n[2] = q.z; n[3] = q.w;
+    }
+    // physics wave: what its tail work needs from memory is requested first thing after the barrier
+    unsigned steps_p = 0u;
+    bool early_p = false, end_p = false;
+    float rec0_p[FWG_MAX_OBS];
+    ResetDraw RDp;
+    if (SPLIT && PHYS && (tail_rows || pre_install)) {
+        const float4 w = *reinterpret_cast<const float4*>(acts);
+        steps_p = f2u(w.x);
+        early_p = tail_rows && valid && fail == 0 && steps_p != 0u;
+        end_p = pre_install && valid && f2u(w.y) != 0u;
+        if (__ballot(early_p) != 0ull) {
+            if (early_p) early_rows_request(c, A, e, rec0_p);
+        }
+        if (__ballot(end_p) != 0ull) {
+            if (end_p) draw_load_final(c, A.S, A.N, e, RDp);   // (just read by the partner: served from the cache)
+        }
     }
     if (SPLIT && GYM) {
         const float4* h4 = reinterpret_cast<const float4*>(hand);
@@ -470,7 +468,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (SPLIT && pre_install && __ballot(end_p) != 0ull) {
             // foreseen episode end: the NEXT episode goes into the simulator / cold rows and the row log (the old episode's final
             // state went to the partner through LDS above)
-            if (end_p && f2u(tag_p.x) == dc.generation && f2u(tag_p.y) == E.episode + 1u) {
+            if (end_p) {   // (the partner checked the draw's tag)
                 reset_rows_to_log(c, A, e, RDp, aring, A.slot_lag, A.log_win);
 #pragma unroll
                 for (int i = 0; i < NY; ++i) E.y[i] = RDp.y[i];
