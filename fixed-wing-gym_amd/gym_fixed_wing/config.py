@@ -270,8 +270,6 @@ class EnvConfig(object):
             for pa in m["parameters"]:
                 if pa["name"] not in nat.PARAMS:
                     raise NotImplementedError("simulator.model parameter {} is not part of the force/moment model".format(pa["name"]))
-        if "goals" in cfg["observation"]:
-            raise NotImplementedError("FixedWingAircraftGoal observations")
         for t in cfg["target"]["states"]:
             if t.get("class", "constant") not in ("constant", "compensate", "linear", "sinusoidal"):
                 raise NotImplementedError("target class {}".format(t.get("class")))

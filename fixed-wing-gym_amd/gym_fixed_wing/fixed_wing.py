@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _native as nat
-from .spaces import Env
+from .spaces import Box, DictSpace, Env, GoalEnv
 from .vec_env import FixedWingVecEnv
 
 _RECORDED = ["roll", "pitch", "yaw", "omega_p", "omega_q", "omega_r", "position_n", "position_e", "position_d",
@@ -306,3 +306,165 @@ class FixedWingAircraft(Env):
 
     def close(self):
         self._vec.close()
+
+
+class FixedWingAircraftGoal(FixedWingAircraft, GoalEnv):
+    """The reference's goal-conditioned variant (fixed_wing.py:1165-1277, gym.GoalEnv for hindsight replay): dict
+    observations {observation, achieved_goal, desired_goal} with the goal states of cfg["observation"]["goals"] scaled by
+    (x - mean) / var, get_goal_limits and compute_reward(achieved_goal, desired_goal, info).
+
+    reset / step run on the device like the parent's.  compute_reward re-evaluates the reward function for SUBSTITUTED goal
+    states and targets on transitions of the episode held in this object (the reference does it by temporarily overwriting its
+    simulator / target / history attributes, :1218-1277); it is the relabelling call of a replay buffer, off the step path, and
+    is evaluated here on the host in float64 from the same configuration (the reward of step() itself always comes from the
+    kernel)."""
+
+    def __init__(self, config_path=None, sampler=None, sim_config_path=None, sim_parameter_path=None, config_kw=None,
+                 sim_config_kw=None, device=0, **vec_kw):
+        super().__init__(config_path, sampler=sampler, sim_config_path=sim_config_path, sim_parameter_path=sim_parameter_path,
+                         config_kw=config_kw, sim_config_kw=sim_config_kw, device=device, **vec_kw)
+        goals = self.cfg["observation"]["goals"]
+        self.goal_states = [g["name"] for g in goals]
+        self.goal_means = np.array([g["mean"] for g in goals], dtype=np.float64)
+        self.goal_vars = np.array([g["var"] for g in goals], dtype=np.float64)
+        shape = self.observation_space.shape
+        gshape = (len(self.goal_states),) if len(shape) == 1 else (shape[0], len(self.goal_states))
+        self.observation_space = DictSpace(dict(desired_goal=Box(-np.inf, np.inf, shape=gshape, dtype="float32"),
+                                                achieved_goal=Box(-np.inf, np.inf, shape=gshape, dtype="float32"),
+                                                observation=self.observation_space))
+        self.prev_shaping = {t["function_class"]: None for t in self.cfg["reward"]["terms"]}
+
+    # -- observations -----------------------------------------------------------------------------------------------------
+    def _goal_obs(self, obs):
+        ach = (np.array([self.simulator.state[s].value for s in self.goal_states]) - self.goal_means) / self.goal_vars
+        des = (np.array([self.target[s] for s in self.goal_states]) - self.goal_means) / self.goal_vars
+        length = self.cfg["observation"]["length"]
+        if length > 1:
+            ach = np.repeat(ach[np.newaxis, :], length, axis=0)
+            des = np.repeat(des[np.newaxis, :], length, axis=0)
+        return dict(desired_goal=des, achieved_goal=ach, observation=obs)
+
+    def reset(self, state=None, target=None):
+        super().reset()          # (the reference resets twice, fixed_wing.py:1197-1199: one episode's draws are consumed)
+        obs = super().reset(state, target)
+        out = self._goal_obs(obs)
+        self.history["observation"] = [out]
+        return out
+
+    def step(self, action):
+        obs, rew, done, info = super().step(action)
+        out = self._goal_obs(obs)
+        if self.history["observation"] and self.history["observation"][-1] is obs:
+            self.history["observation"][-1] = out
+        return out, rew, done, info
+
+    def get_goal_limits(self):
+        low, high = [], []
+        for i, name in enumerate(self.goal_states):
+            g = [t for t in self.cfg["target"]["states"] if t["name"] == name][0]
+            lo, hi = g["low"], g["high"]
+            if g.get("convert_to_radians", False):
+                lo, hi = np.radians(lo), np.radians(hi)
+            low.append((lo - self.goal_means[i]) / self.goal_vars[i])
+            high.append((hi - self.goal_means[i]) / self.goal_vars[i])
+        return np.array(low), np.array(high)
+
+    # -- reward for substituted goals -------------------------------------------------------------------------------------
+    def _host_reward(self, values, targets, action, actions, steps_count, prev_shaping, potential):
+        """get_reward (fixed_wing.py:674-774) with success = False, for the given state values / targets / raw-action history.
+        Returns (reward, shaping values per function class)."""
+        cfg = self.cfg
+
+        def value(name):
+            return values[name] if name in values else self.simulator.state[name].value
+
+        def error(name):
+            if self.simulator.state[name].wrap:
+                d = (value(name) - targets[name] + np.pi) % (2 * np.pi) - np.pi
+                return d + 2 * np.pi if d < -np.pi else d
+            return targets[name] - value(name)
+
+        def goal_status():
+            st = {}
+            for name, props in self._vec.env_config.target_props_init["states"].items():
+                if props.get("bound", None) is not None:
+                    b = np.radians(props["bound"]) if props.get("convert_to_radians", False) else props["bound"]
+                    st[name] = bool(np.abs(error(name)) <= b)
+            st["all"] = all(st.values())
+            return st
+
+        ec = self._vec.env_config
+        terms = {t["function_class"]: {"val": 0.0, "weight": t["weight"], "val_shaping": 0.0} for t in cfg["reward"]["terms"]}
+        for f in cfg["reward"]["factors"]:
+            cls = f["class"]
+            if cls == "action":
+                if f["type"] == "value":
+                    val = np.sum(np.abs(actions[-1]))
+                elif f["type"] == "delta":
+                    val = np.sum(np.abs(np.diff(actions[-f["window_size"]:], axis=0))) if steps_count > 1 else 0
+                elif f["type"] == "bound":
+                    hi, lo = ec.action_bounds_max, ec.action_bounds_min
+                    val = 0 if action is None else float(np.sum(np.where(action > hi, action - hi, 0)) + np.sum(np.where(action < lo, lo - action, 0)))
+                else:
+                    raise ValueError("Unexpected type {} for reward class action".format(f["type"]))
+            elif cls == "state":
+                if f["type"] == "value":
+                    val = value(f["name"])
+                elif f["type"] == "error":
+                    val = error(f["name"])
+                else:
+                    raise NotImplementedError("compute_reward with reward type {}".format(f["type"]))
+            elif cls == "success":
+                val = 0
+            elif cls == "step":
+                val = f["value"]
+            elif cls == "goal":
+                st = goal_status()
+                if f["type"] == "per_state":
+                    val = sum(f["value"] / len(targets) for k, ok in st.items() if k != "all" and ok)
+                else:
+                    val = f["value"] if st["all"] else 0
+            else:
+                raise ValueError("Unexpected reward component type {}".format(cls))
+            if f["function_class"] == "linear":
+                val = np.clip(np.abs(val) / f["scaling"], 0, f.get("max", None))
+            else:
+                val = val ** 2 / f["scaling"]
+            terms[f["function_class"]]["val_shaping" if f.get("shaping", False) else "val"] += val * np.sign(f.get("sign", -1))
+        reward, shaping = 0.0, {}
+        for fc, t in terms.items():
+            prev = prev_shaping.get(fc, None) if prev_shaping is not None else None
+            if fc == "exponential":
+                arg = t["val"] + ((t["val_shaping"] - prev) if prev is not None else 0.0) if potential else t["val"] + t["val_shaping"]
+                val = -1 + np.exp(arg)
+            else:
+                val = t["val"]
+                if potential:
+                    if prev is not None:
+                        val += t["val_shaping"] - prev
+                else:
+                    val += t["val_shaping"]
+            shaping[fc] = t["val_shaping"]
+            reward += t["weight"] * val
+        return float(reward), shaping
+
+    def compute_reward(self, achieved_goal, desired_goal, info):
+        """fixed_wing.py:1218-1277.  info: {"step": index of the transition in this episode, "action": its raw action,
+        "prev_state": the goal states before the transition (potential rewards)}."""
+        achieved = np.asarray(achieved_goal, dtype=np.float64) * self.goal_vars + self.goal_means
+        desired = np.asarray(desired_goal, dtype=np.float64) * self.goal_vars + self.goal_means
+        action = np.asarray(info.get("action", np.zeros(len(self.cfg["action"]["states"]))), dtype=np.float64)
+        actions = list(self.history["action"][:info["step"]]) + [action]
+        steps_count = info["step"]
+        targets = dict(self.target)
+        for i, s in enumerate(self.goal_states):
+            targets[s] = desired[i]
+        potential = self.cfg["reward"]["form"] == "potential"
+        prev_shaping = None
+        if potential and info["step"] > 0:   # shaping value of the state before the transition, with the action before it
+            prev_action = actions[-2] if len(actions) >= 2 else None
+            _, prev_shaping = self._host_reward({s: info["prev_state"][i] for i, s in enumerate(self.goal_states)}, targets,
+                                                prev_action, actions, steps_count, None, potential)
+        reward, _ = self._host_reward({s: achieved[i] for i, s in enumerate(self.goal_states)}, targets, action, actions,
+                                      steps_count, prev_shaping, potential)
+        return reward

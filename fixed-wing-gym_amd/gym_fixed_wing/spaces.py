@@ -5,10 +5,19 @@ import numpy as np
 try:  # pragma: no cover - depends on the environment
     import gym as _gym
     Env = _gym.Env
+    GoalEnv = getattr(_gym, "GoalEnv", _gym.Env)
     Box = _gym.spaces.Box
+    DictSpace = _gym.spaces.Dict
     HAVE_GYM = True
 except Exception:  # gym is optional
     HAVE_GYM = False
+
+    class DictSpace(dict):
+        """gym.spaces.Dict stand-in: a dict of spaces (fixed_wing.py:1183-1187 only builds it)."""
+
+        def __init__(self, spaces):
+            super().__init__(spaces)
+            self.spaces = spaces
 
     class Env(object):
         metadata = {}
@@ -34,3 +43,6 @@ except Exception:  # gym is optional
 
         def __repr__(self):
             return "Box{}".format(self.shape)
+
+    class GoalEnv(Env):
+        pass

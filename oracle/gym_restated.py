@@ -63,6 +63,13 @@ class MTStream:
     def model_uniform(self, i, low, high):
         return self.rs.uniform(low=low, high=high)
 
+    # simulator.<key> sampling (fixed_wing.py:560-569)
+    def sim_choice(self, i, values, probs):
+        return self.rs.choice(values, p=probs)
+
+    def sim_uniform(self, i, low, high):
+        return self.rs.uniform(low, high)
+
     def begin_obs(self, steps_count):
         pass
 
@@ -120,6 +127,18 @@ class PhiloxStream:
     def model_uniform(self, i, low, high):
         b = self._bits(self.episode, i, self.ph.STREAM_MODEL)
         return low + (high - low) * self.ph.u01(b[0])
+
+    # simulator.<key> sampling (fixed_wing.py:560-569; csrc/fwgym_env.h draw_sim_keys): key i of the episode,
+    # ctr = (env, episode, i, STREAM_SIM_KEY); a choice takes the first value whose cumulative probability exceeds u
+    def sim_choice(self, i, values, probs):
+        u = self.ph.u01(self._bits(self.episode, i, self.ph.STREAM_SIM_KEY)[0])
+        p = np.full(len(values), 1.0 / len(values)) if probs is None else np.asarray(probs, dtype=np.float64)
+        cum = np.cumsum(p)
+        k = int(np.searchsorted(cum, u, side="right"))
+        return values[min(k, len(values) - 1)]
+
+    def sim_uniform(self, i, low, high):
+        return low + (high - low) * self.ph.u01(self._bits(self.episode, i, self.ph.STREAM_SIM_KEY)[0])
 
     # reward.randomize_scaling (k_model_draw): factor i of the episode, ctr = (env, episode, i, STREAM_REWARD_SCALE)
     def reward_scale_uniform(self, i, low, high):
@@ -397,11 +416,12 @@ class FixedWingOracle:
                     n_drawn += 1
                     self.simulator.params[pa["name"]] = x
                 continue
+            k_idx = [k for k in self.cfg["simulator"] if k not in ("states", "model")].index(key)
             if "values" in value:
                 probs = value.get("probabilities", None)
-                val = self.rng.rs.choice(value["values"], p=None if probs is None else np.array(probs))
+                val = self.rng.sim_choice(k_idx, value["values"], None if probs is None else np.array(probs))
             else:
-                val = self.rng.uniform(value["low"], value["high"])
+                val = self.rng.sim_uniform(k_idx, value["low"], value["high"])
                 if isinstance(value["low"], bool):
                     val = bool(val)
             setattr(self.simulator, key, val)

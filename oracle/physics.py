@@ -579,6 +579,7 @@ def box_muller(bits):
 STREAM_TURB, STREAM_RESET_STATE, STREAM_RESET_TARGET, STREAM_OBS_NOISE, STREAM_INIT_NOISE = 1, 2, 3, 4, 5
 STREAM_MODEL = 7   # simulator.model draws (6: the rollout head's policy noise)
 STREAM_REWARD_SCALE = 8   # reward.randomize_scaling draws
+STREAM_SIM_KEY = 9        # simulator.<key> draws (turbulence, turbulence_intensity)
 
 
 def rng_bits(seed, env_ids, counter, stream, sub=0):

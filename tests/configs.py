@@ -54,6 +54,10 @@ def reference_like(kind):
             pars[3]["var"] = 0.5
             cfg["simulator"]["model"] = {"var_type": "absolute", "var": 0.002, "distribution": "uniform", "parameters": pars}
         return cfg
+    if kind == "sim_keys":   # simulator.<key> sampled at every reset (fixed_wing.py:560-569)
+        cfg["simulator"]["turbulence_intensity"] = {"values": ["light", "moderate", "severe"], "probabilities": [0.5, 0.3, 0.2]}
+        cfg["simulator"]["turbulence"] = {"values": [True, False], "probabilities": [0.75, 0.25]}
+        return cfg
     if kind == "reward_random_scaling":   # reward["randomize_scaling"]: [low, high] scalings drawn per env at every reset
         r = cfg["reward"]
         r["randomize_scaling"] = True
@@ -94,6 +98,7 @@ CASES = [
     ("reward_mix_potential", "reward_mix", {"steps_max": 60, "reward": {"form": "potential"}}, None),
     ("reward_random_scaling", "reward_random_scaling", {"steps_max": 45}, None),
     ("reward_random_scaling_potential", "reward_random_scaling", {"steps_max": 45, "reward": {"form": "potential"}}, None),
+    ("sim_keys", "sim_keys", {"steps_max": 25}, {"turbulence": True, "turbulence_intensity": "moderate", "turbulence_output": "filter"}),
     ("model_gaussian", "model_gaussian", {"steps_max": 45}, None),
     ("model_uniform", "model_uniform", {"steps_max": 45}, {"turbulence": True, "turbulence_intensity": "light"}),
 ]

@@ -50,6 +50,11 @@ class ScriptedRNG:
     def normal(self, loc=0.0, scale=1.0):
         return loc + scale * (2.0 * self._u() - 1.0)
 
+    def choice(self, values, p=None):
+        u = self._u()
+        p = np.full(len(values), 1.0 / len(values)) if p is None else np.asarray(p, dtype=np.float64)
+        return values[min(int(np.searchsorted(np.cumsum(p), u, side="right")), len(values) - 1)]
+
 
 def _clean(x):
     if isinstance(x, dict):
@@ -136,6 +141,40 @@ def main():
             json.dump(_clean(rec), f)
         print("g1", case[0], sum(len(e["steps"]) for e in rec["episodes"]), "steps",
               [e["steps"][-1]["termination"] for e in rec["episodes"]])
+
+    # G4: FixedWingAircraftGoal (fixed_wing.py:1165-1277): dict observations, goal limits, compute_reward for substituted goals
+    for form in ("absolute", "potential"):
+        cfg = configs.reference_like("default")
+        cfg["observation"]["goals"] = [{"name": "roll", "mean": 0.0, "var": 1.0}, {"name": "pitch", "mean": 0.1, "var": 0.5},
+                                       {"name": "Va", "mean": 22.0, "var": 10.0}]
+        cfg["reward"]["form"] = form
+        path = "/tmp/golden_cfg_goal_{}.json".format(form)
+        with open(path, "w") as f:
+            json.dump(cfg, f)
+        env = ref.FixedWingAircraftGoal(path)
+        env.seed(7)
+        env.np_random = ScriptedRNG()
+        obs = env.reset(state=dict(SCENARIO_STATE), target=dict(SCENARIO_TARGET))
+        rec = {"config": cfg, "state": dict(SCENARIO_STATE), "target": dict(SCENARIO_TARGET), "reset_obs": obs,
+               "goal_limits": env.get_goal_limits(), "steps": [], "relabel": []}
+        acts = actions_for(5, 14, 1.3)
+        prev_goal = [env.simulator.state[s].value for s in env.goal_states]
+        trans = []
+        for t, a in enumerate(acts):
+            o, r, d, info = env.step(a.copy())
+            rec["steps"].append({"action": a, "obs": o, "reward": r, "done": d})
+            trans.append({"step": t, "action": a, "prev_state": list(prev_goal), "achieved": o["achieved_goal"], "desired": o["desired_goal"]})
+            prev_goal = [env.simulator.state[s].value for s in env.goal_states]
+        rng = np.random.default_rng(11)
+        for tr in (trans[0], trans[1], trans[4], trans[9], trans[13]):
+            for k in range(2):
+                des = np.array(tr["desired"]) if k == 0 else np.array(tr["desired"]) + rng.normal(0, 0.3, 3)
+                ach = np.array(tr["achieved"]) if k == 0 else np.array(tr["achieved"]) + rng.normal(0, 0.1, 3)
+                info = {"step": tr["step"], "action": tr["action"].copy(), "prev_state": list(tr["prev_state"])}
+                rec["relabel"].append({"achieved": ach, "desired": des, "info": info, "reward": env.compute_reward(ach, des, info)})
+        with open(os.path.join(HERE, "g4_goal_{}.json".format(form)), "w") as f:
+            json.dump(_clean(rec), f)
+        print("g4 goal", form, [round(x["reward"], 5) for x in rec["relabel"][:4]])
 
     # G2: curriculum ranges (fixed_wing.py:224-285)
     cfg = configs.reference_like("default")

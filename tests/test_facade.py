@@ -115,3 +115,35 @@ def test_vecenv_contract(backend):
     with pytest.raises(AssertionError):
         vec.step(np.full((4, 3), np.nan, dtype=np.float32))
     vec.close()
+
+
+@pytest.mark.parametrize("form", ["absolute", "potential"])
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_goal_env_reproduces_the_reference_goal_env(backend, form):
+    """FixedWingAircraftGoal (fixed_wing.py:1165-1277): dict observations, goal limits and compute_reward for substituted
+    (relabelled) goals against vectors recorded from the VERBATIM reference class (tests/golden/g4_goal_*.json,
+    tests/golden/make_golden.py).  Observations / step rewards come from the kernels (fp32: 2e-3 as elsewhere); the
+    relabelled rewards are evaluated on the host in float64 on the kernel's fp32 states."""
+    import json
+    from gym_fixed_wing.fixed_wing import FixedWingAircraftGoal
+    with open(os.path.join(os.path.dirname(__file__), "golden", "g4_goal_{}.json".format(form))) as f:
+        rec = json.load(f)
+    env = FixedWingAircraftGoal(rec["config"], **_kw(backend))
+    env.seed(7)
+    assert set(env.observation_space.spaces) == {"desired_goal", "achieved_goal", "observation"}
+    assert env.observation_space.spaces["achieved_goal"].shape == (3,)
+    obs = env.reset(state=rec["state"], target=rec["target"])
+    for k in ("observation", "achieved_goal", "desired_goal"):
+        np.testing.assert_allclose(obs[k], np.array(rec["reset_obs"][k], dtype=np.float64), atol=1e-5, err_msg=k)
+    lo, hi = env.get_goal_limits()
+    np.testing.assert_allclose(lo, rec["goal_limits"][0], rtol=1e-12)
+    np.testing.assert_allclose(hi, rec["goal_limits"][1], rtol=1e-12)
+    for st in rec["steps"]:
+        o, r, d, info = env.step(np.array(st["action"]))
+        for k in ("observation", "achieved_goal", "desired_goal"):
+            np.testing.assert_allclose(o[k], np.array(st["obs"][k], dtype=np.float64), atol=2e-3, rtol=2e-3, err_msg=k)
+        assert r == pytest.approx(st["reward"], abs=2e-3) and d == st["done"]
+    for rl in rec["relabel"]:
+        got = env.compute_reward(np.array(rl["achieved"]), np.array(rl["desired"]), rl["info"])
+        assert got == pytest.approx(rl["reward"], abs=2e-4), (rl["info"]["step"], got, rl["reward"])
+    env.close()

@@ -35,6 +35,11 @@ class ScriptedRNG:  # same generator as tests/golden/make_golden.py
     def normal(self, loc=0.0, scale=1.0):
         return loc + scale * (2.0 * self._u() - 1.0)
 
+    def choice(self, values, p=None):
+        u = self._u()
+        p = np.full(len(values), 1.0 / len(values)) if p is None else np.asarray(p, dtype=np.float64)
+        return values[min(int(np.searchsorted(np.cumsum(p), u, side="right")), len(values) - 1)]
+
 
 def _nan(x):
     return math.nan if x is None else x
