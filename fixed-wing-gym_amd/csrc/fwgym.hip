@@ -206,6 +206,10 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         } else {
             dryden_output(c, E.dry, gust);
         }
+        if (c.sim_keys) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) gust[i] *= E.gust_gain;
+        }
     }
     float4 act_q3 = make_float4(0.f, 0.f, 0.f, 0.f), act_q4 = act_q3;
     if (SPLIT && GYM && ext_act) {   // y[12..15] | y[16], y[17], ...: the actuator part of the simulator rows
@@ -479,6 +483,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = 0.f;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) E.gust[i] = 0.f;
+                E.gust_gain = RDp.gust_gain;
                 store_cold(c, A.S, A.N, e, E);
             }
         }
@@ -1113,6 +1118,13 @@ static int lower_config(const fwg_config& c, DevCfg* d, DynCfg* dy, std::string*
         dy->model.lo[i] = lim32(c.model_clip_lo[i], true); dy->model.hi[i] = lim32(c.model_clip_hi[i], false);
     }
     d->randomize_scaling = c.randomize_scaling ? 1 : 0;
+    if (c.sk_n_intensity < 0 || c.sk_n_intensity > 4 || c.sk_n_turbulence < 0 || c.sk_n_turbulence > 2) { *why = "sk_n_* out of range"; return -1; }
+    d->sim_keys = (c.sk_n_intensity > 0 || c.sk_n_turbulence > 0) ? 1 : 0;
+    if (d->sim_keys && !c.turbulence) { *why = "sampled turbulence keys need the turbulence kernels (turbulence = 1)"; return -1; }
+    dy->sk_n_int = c.sk_n_intensity; dy->sk_n_turb = c.sk_n_turbulence; dy->sk_idx_int = c.sk_index_intensity; dy->sk_idx_turb = c.sk_index_turbulence;
+    for (int i = 0; i < 4; ++i) { dy->sk_cum_int[i] = f32(c.sk_cum_intensity[i]); dy->sk_gain_int[i] = f32(c.sk_gain_intensity[i]); }
+    for (int i = 0; i < 2; ++i) { dy->sk_cum_turb[i] = f32(c.sk_cum_turbulence[i]); dy->sk_on_turb[i] = f32(c.sk_on_turbulence[i]); }
+    dy->sk_base_gain = f32(c.sk_base_gain);
     for (int f = 0; f < FWG_MAX_FACTORS; ++f) {
         const bool listed = c.randomize_scaling && f < c.n_factors;
         dy->fs_lo[f] = f32(listed ? c.factor_scaling_low[f] : 1.0); dy->fs_hi[f] = f32(listed ? c.factor_scaling_high[f] : 1.0);

@@ -20,6 +20,7 @@
 #define FWG_STREAM_OBS_NOISE 4u
 #define FWG_STREAM_INIT_NOISE 5u
 #define FWG_STREAM_MODEL 7u              // simulator.model draws (6 = the rollout head's policy noise)
+#define FWG_STREAM_SIM_KEY 9u
 #define FWG_STREAM_REWARD_SCALE 8u       // reward.randomize_scaling draws
 
 struct DevObs { int type, src, window, norm; float mean, inv_var; };
@@ -40,6 +41,10 @@ struct DynCfg {
     unsigned generation;   // bumped whenever what a reset draw depends on changes (ranges, seed): prepared draws are then discarded
     ModelCfg model;
     float fs_lo[FWG_MAX_FACTORS], fs_hi[FWG_MAX_FACTORS];   // reward.randomize_scaling: scaling ~ U(lo, hi) where lo < hi
+    // simulator.turbulence / simulator.turbulence_intensity sampled at every reset (fixed_wing.py:560-569): tables of the
+    // per-env gust gain (see fwg_config sk_*)
+    int sk_n_int, sk_n_turb, sk_idx_int, sk_idx_turb;
+    float sk_cum_int[4], sk_gain_int[4], sk_cum_turb[2], sk_on_turb[2], sk_base_gain;
 };
 // The constants of the force / moment model, pre-combined from the parameter table (same names and order as the block at
 // the head of DevCfg).  One set for all envs (DevCfg) unless simulator.model re-samples the table per env and episode: then
@@ -114,6 +119,7 @@ struct DevCfg {
     int act_per_half;
     float dryA[FWG_N_DRYDEN * FWG_N_DRYDEN], dryB[FWG_N_DRYDEN * 4], dryC[6 * FWG_N_DRYDEN];
     int turb_increment;   // the gust sample is the first difference of the filter outputs (kept in the simulator rows)
+    int sim_keys;         // simulator.turbulence / turbulence_intensity are sampled per env at every reset: per-env gust gain
     // ---- gym side
     int steps_max, obs_length, obs_step, n_obs, obs_dim, obs_noise;
     float obs_noise_mean, obs_noise_std;

@@ -310,6 +310,7 @@ struct Env {
     float wind[3];
     float dry[FWG_N_DRYDEN];
     float gust[6];       // increment turbulence: this step's gust sample (computed when the filter advanced one step ago)
+    float gust_gain;     // simulator.turbulence / turbulence_intensity sampled per env and episode: gain on the gust (cold row)
     Derived d;
     float tgt[FWG_MAX_TARGETS];
     float tprop[FWG_MAX_TARGETS][4];  // slope|amplitude, period, phase, bias
@@ -384,6 +385,8 @@ __device__ __forceinline__ void load_sim(const DevCfg& c, const float* __restric
 __device__ __forceinline__ void load_cold(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E) {
     const float4 w = CGROUP(S, N, (c.L.cold >> 2), e);
     E.wind[0] = w.x; E.wind[1] = w.y; E.wind[2] = w.z; E.episode = f2u(w.w);
+    E.gust_gain = 1.f;
+    if (c.sim_keys) E.gust_gain = CGROUP(S, N, (c.L.cold >> 2) + 1, e).x;
 }
 
 // simulator.model: this lane's force / moment constants (arena section L.aero) / the shared set of the configuration
@@ -428,6 +431,7 @@ __device__ __forceinline__ void store_sim(const DevCfg& c, float* __restrict__ S
 }
 __device__ __forceinline__ void store_cold(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E) {
     GROUP(S, N, (c.L.cold >> 2), e) = make_float4(E.wind[0], E.wind[1], E.wind[2], u2f(E.episode));
+    if (c.sim_keys) GROUP(S, N, (c.L.cold >> 2) + 1, e) = make_float4(E.gust_gain, 0.f, 0.f, 0.f);
 }
 
 // bookkeeping block, 9 groups.  Written every step: 0: tgt0 tgt1 tgt2 steps|sft<<16 | 1: flags wcnt gcnt0 gcnt1 and, with
@@ -1073,6 +1077,7 @@ __device__ __forceinline__ void fin_collect_pending(const DevCfg& c, const KArgs
 //                  and builds the observation record ob (all rows).  `g_*` = ring positions of the LAST completed step.
 // reset_env = both back to back (reset kernel; episode ends that were not foreseen).
 struct ResetDraw {
+    float gust_gain;
     float y[NY], wind[3];
     Derived d;
     float tgt[FWG_MAX_TARGETS], tprop[FWG_MAX_TARGETS][4];
@@ -1143,6 +1148,22 @@ __device__ __forceinline__ void draw_targets(const DevCfg& c, const DynCfg& dc, 
     R.d = D.d;
     fill_vars(R, T);
     sample_targets(c, dc, A, e, R, T, A.init_target);
+    D.gust_gain = 1.f;
+    if (c.sim_keys) {   // simulator.turbulence / turbulence_intensity (fixed_wing.py:560-569): one uniform per sampled key
+        const unsigned env_id = (unsigned)(A.env_base + e);
+        float on = dc.sk_base_gain, g = 1.f;
+        if (dc.sk_n_turb > 0) {
+            const float u = u01(philox4x32(env_id, episode_new, (unsigned)dc.sk_idx_turb, FWG_STREAM_SIM_KEY, A.seed_lo, A.seed_hi).x);
+            on = dc.sk_on_turb[dc.sk_n_turb - 1];
+            for (int i = dc.sk_n_turb - 2; i >= 0; --i) on = u < dc.sk_cum_turb[i] ? dc.sk_on_turb[i] : on;
+        }
+        if (dc.sk_n_int > 0) {
+            const float u = u01(philox4x32(env_id, episode_new, (unsigned)dc.sk_idx_int, FWG_STREAM_SIM_KEY, A.seed_lo, A.seed_hi).x);
+            g = dc.sk_gain_int[dc.sk_n_int - 1];
+            for (int i = dc.sk_n_int - 2; i >= 0; --i) g = u < dc.sk_cum_int[i] ? dc.sk_gain_int[i] : g;
+        }
+        D.gust_gain = on * g;
+    }
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
         D.tgt[k] = R.tgt[k];
@@ -1201,7 +1222,7 @@ __device__ __forceinline__ void draw_store_final(const DevCfg& c, float* __restr
         GROUP(S, N, g0 + 6, e) = make_float4(D.d.alpha, D.d.beta, 0.f, 0.f);
     } else if (part == 1) {
         GROUP(S, N, g0 + 6, e) = make_float4(D.d.alpha, D.d.beta, D.tgt[0], D.tgt[1]);
-        GROUP(S, N, g0 + 7, e) = make_float4(D.tgt[2], 0.f, 0.f, 0.f);
+        GROUP(S, N, g0 + 7, e) = make_float4(D.tgt[2], D.gust_gain, 0.f, 0.f);
         if (c.any_dynamic_target) {
 #pragma unroll
             for (int k = 0; k < FWG_MAX_TARGETS; ++k)
@@ -1222,7 +1243,7 @@ __device__ __forceinline__ void draw_load_final(const DevCfg& c, const float* __
     D.y[16] = 0.f; D.y[17] = 0.f;
     D.wind[0] = q[4].x; D.wind[1] = q[4].y; D.wind[2] = q[4].z;
     D.d.roll = q[5].x; D.d.pitch = q[5].y; D.d.yaw = q[5].z; D.d.Va = q[5].w;
-    D.d.alpha = q[6].x; D.d.beta = q[6].y; D.tgt[0] = q[6].z; D.tgt[1] = q[6].w; D.tgt[2] = q[7].x;
+    D.d.alpha = q[6].x; D.d.beta = q[6].y; D.tgt[0] = q[6].z; D.tgt[1] = q[6].w; D.tgt[2] = q[7].x; D.gust_gain = q[7].y;
     D.row_noise[0] = q[8].x; D.row_noise[1] = q[8].y; D.row_noise[2] = q[8].z; D.row_noise[3] = q[8].w;
     D.row_noise[4] = q[9].x; D.row_noise[5] = q[9].y; D.row_noise[6] = q[9].z; D.row_noise[7] = q[9].w;
 #pragma unroll
@@ -1374,6 +1395,7 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
     for (int i = 0; i < FWG_N_DRYDEN; ++i) E.dry[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) E.gust[i] = 0.f;
+    E.gust_gain = D.gust_gain;
     E.d = D.d;
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {

@@ -113,6 +113,9 @@ class Config(C.Structure):
         ("model_n", C.c_int32), ("model_dist", C.c_int32), ("model_idx", C.c_int32 * N_PARAMS), ("pad_model_", C.c_int32),
         ("model_var", C.c_double * N_PARAMS), ("model_clip_lo", C.c_double * N_PARAMS), ("model_clip_hi", C.c_double * N_PARAMS),
         ("randomize_scaling", C.c_int32), ("pad_rs_", C.c_int32),
+        ("sk_n_intensity", C.c_int32), ("sk_n_turbulence", C.c_int32), ("sk_index_intensity", C.c_int32), ("sk_index_turbulence", C.c_int32),
+        ("sk_cum_intensity", C.c_double * 4), ("sk_gain_intensity", C.c_double * 4),
+        ("sk_cum_turbulence", C.c_double * 2), ("sk_on_turbulence", C.c_double * 2), ("sk_base_gain", C.c_double),
         ("factor_scaling_low", C.c_double * MAX_FACTORS), ("factor_scaling_high", C.c_double * MAX_FACTORS),
     ]
 

@@ -256,13 +256,61 @@ class EnvConfig(object):
         self.set_curriculum_level(1)
 
     # ------------------------------------------------------------------------------------------------------------------
+    W20_KNOTS = {"light": 15.0, "moderate": 30.0, "severe": 45.0}
+
+    def _lower_sim_keys(self, c):
+        """simulator.turbulence / simulator.turbulence_intensity sampled at every reset (fixed_wing.py:560-569) -> the tables
+        of the per-env gust gain.  With either key sampled the kernels run with turbulence compiled in."""
+        keys = [k for k in self.cfg["simulator"] if k not in ("states", "model")]
+        c.sk_n_intensity = c.sk_n_turbulence = 0
+        c.sk_base_gain = 1.0
+        if not keys:
+            return
+        base = self.W20_KNOTS[self.turbulence_intensity]
+
+        def cum(value, n):
+            p = value.get("probabilities", None)
+            p = np.full(n, 1.0 / n) if p is None else np.asarray(p, dtype=np.float64)
+            return np.cumsum(p)
+
+        on_configured = 1.0 if self.turbulence else 0.0
+        if "turbulence_intensity" in keys:
+            v = self.cfg["simulator"]["turbulence_intensity"]
+            n = len(v["values"])
+            c.sk_n_intensity, c.sk_index_intensity = n, keys.index("turbulence_intensity")
+            for i, (name, cp) in enumerate(zip(v["values"], cum(v, n))):
+                c.sk_cum_intensity[i], c.sk_gain_intensity[i] = cp, self.W20_KNOTS[name] / base
+        if "turbulence" in keys:
+            v = self.cfg["simulator"]["turbulence"]
+            c.sk_index_turbulence = keys.index("turbulence")
+            if "values" in v:
+                n = len(v["values"])
+                c.sk_n_turbulence = n
+                for i, (val, cp) in enumerate(zip(v["values"], cum(v, n))):
+                    c.sk_cum_turbulence[i], c.sk_on_turbulence[i] = cp, 1.0 if val else 0.0
+            else:   # bool(uniform(low, high)): True unless the draw is exactly 0
+                c.sk_n_turbulence = 1
+                c.sk_cum_turbulence[0], c.sk_on_turbulence[0] = 1.0, 1.0 if (v["high"] or v["low"]) else 0.0
+        else:
+            c.sk_base_gain = on_configured
+        c.turbulence = 1
+
     def _check_supported(self):
         cfg = self.cfg
         if cfg.get("integration_window", 0):
             raise NotImplementedError("integration_window > 0 (integrator observations / int_error rewards)")
-        for key in cfg["simulator"]:
-            if key not in ("states", "model"):
-                raise NotImplementedError("simulator.{} sampling".format(key))
+        for key, value in cfg["simulator"].items():
+            if key in ("states", "model"):
+                continue
+            # fixed_wing.py:560-569 samples ANY attribute of the simulator object; here the two turbulence keys (the intensity
+            # is an output gain of the Dryden filters, so a per-env choice costs one multiplication)
+            if key not in ("turbulence", "turbulence_intensity"):
+                raise NotImplementedError("simulator.{} sampling (supported: turbulence, turbulence_intensity)".format(key))
+            if "values" in value:
+                if len(value["values"]) > (4 if key == "turbulence_intensity" else 2):
+                    raise NotImplementedError("simulator.{}: too many values".format(key))
+            elif not ("low" in value and "high" in value and key == "turbulence"):
+                raise ValueError("simulator.{} needs values[, probabilities] (or low/high for turbulence)".format(key))
         if "model" in cfg["simulator"]:
             m = cfg["simulator"]["model"]
             if m.get("distribution", "gaussian") not in ("gaussian", "uniform"):
@@ -327,6 +375,7 @@ class EnvConfig(object):
         c.n_substeps = int(integ.get("substeps", 1))
         c.actuator_microsteps = int(integ.get("actuator_microsteps", 16))
         c.turbulence = int(self.turbulence)
+        self._lower_sim_keys(c)
         c.turbulence_output = {"filter": nat.TURB_FILTER, "increment": nat.TURB_INCREMENT}[self.turbulence_output]
         for i, p in enumerate(nat.PARAMS):
             c.param[i] = float(self.params[p])

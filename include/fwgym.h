@@ -202,6 +202,14 @@ typedef struct fwg_config {
     /* ---- reward["randomize_scaling"] (fixed_wing.py:330-334): factors whose scaling is given as [low, high] get a
      * scaling drawn U(low, high) for every env at every reset; low == high: the fixed factor[i].scaling */
     int32_t randomize_scaling, pad_rs_;
+    /* ---- simulator.<key> sampling at every reset (fixed_wing.py:560-569) for the two turbulence keys.  Per env and episode the
+     * gust is scaled by on(turbulence) * W20(turbulence_intensity) / W20(the intensity dryden_C was built for): the intensity
+     * only enters the MIL-F-8785C filters as an output gain.  n = 0: the key is not sampled (the configuration's value holds). */
+    int32_t sk_n_intensity, sk_n_turbulence;
+    int32_t sk_index_intensity, sk_index_turbulence;   /* position among the sampled keys (RNG sub-stream) */
+    double sk_cum_intensity[4], sk_gain_intensity[4];  /* cumulative probabilities / gain of each listed value */
+    double sk_cum_turbulence[2], sk_on_turbulence[2];
+    double sk_base_gain;                               /* gain of the keys that are not sampled (0 when turbulence is configured off) */
     double factor_scaling_low[FWG_MAX_FACTORS], factor_scaling_high[FWG_MAX_FACTORS];
 } fwg_config;
 

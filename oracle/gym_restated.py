@@ -182,8 +182,8 @@ class FixedWingOracle:
         self.simulator = PyFly(**kw)
         sim = self.simulator
         self.steps_max = cfg["steps_max"]
-        if cfg.get("integration_window", 0):
-            raise NotImplementedError("integration_window > 0")
+        self.integration_window = cfg.get("integration_window", 0)   # fixed_wing.py:53
+        self.err_hist = None      # per target: the episode's error history (only kept for integrator entries / int_error)
         self._rew_factors_init = copy.deepcopy(cfg["reward"]["factors"])   # fixed_wing.py:62
         self.goal_achieved = False           # sticky for the env's lifetime (fixed_wing.py:51,381-382)
         self.steps_count = None
@@ -219,8 +219,6 @@ class FixedWingOracle:
                     ov["mean"] = hi - lo if bounded else 0
                 if ov.get("var", None) is None:
                     ov["var"] = (hi - lo) / (4 ** 2) if bounded else 1
-            if ov["type"] == "target" and ov["value"] == "integrator":
-                raise NotImplementedError("integrator observations")
         L = cfg["observation"]["length"]
         if L > 1:
             if cfg["observation"]["shape"] == "vector":
@@ -456,6 +454,10 @@ class FixedWingOracle:
         self.row_offsets = offs
         self.lag_rows = {}               # time index -> un-normalised row-0 vector (kept for the last max(offs) steps)
         err0 = {k: self._error(k) for k in names}
+        # integrator observations at reset (fixed_wing.py:317-321 builds the observation BEFORE it re-creates the histories, so
+        # :804-810 reads the PREVIOUS episode's error history, or the "history is None" branch on the very first reset)
+        self._err_hist_prev = self.err_hist
+        self.err_hist = {k: [err0[k]] for k in names}
         self.err_last = dict(err0)
         self.m = {k: {"e0": err0[k], "sum": err0[k], "sum_abs": abs(err0[k]), "min": err0[k], "max": err0[k],
                       "n": 1, "last50": [err0[k]], "rise_lo": math.nan, "rise_hi": math.nan} for k in names}
@@ -568,6 +570,7 @@ class FixedWingOracle:
                 m["sum_abs"] += abs(e)
                 m["min"], m["max"] = min(m["min"], e), max(m["max"], e)
                 m["n"] += 1
+                self.err_hist[k].append(e)
                 m["last50"].append(e)
                 if len(m["last50"]) > 50:
                     del m["last50"][0]
@@ -619,6 +622,11 @@ class FixedWingOracle:
                     val = self.simulator.state[f["name"]].value
                 elif t == "error":
                     val = self._error(f["name"])
+                elif t == "int_error":   # fixed_wing.py:708-711 (the history holds the errors up to the previous step here)
+                    W, h = self.integration_window, self.err_hist[f["name"]]
+                    val = float(np.sum(h[-W:])) if W > 0 else float(np.sum(h))
+                    if self.steps_count < W:
+                        val += (W - self.steps_count) * h[0]
                 else:
                     raise NotImplementedError("reward type {}".format(t))
             elif c == "success":
@@ -712,7 +720,7 @@ class FixedWingOracle:
         return res
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _row0(self):
+    def _row0(self, reset_quirk=False):
         """Un-normalised, noise-free newest observation row; action entries hold the diff-sum when available else
         None (filled at assembly time with the current actuator value)."""
         cfg = self.cfg
@@ -722,10 +730,30 @@ class FixedWingOracle:
             if ov["type"] == "state":
                 row.append(self.simulator.state[ov["name"]].value)
             elif ov["type"] == "target":
-                row.append(self._error(ov["name"]) if ov["value"] == "relative" else self.target[ov["name"]])
+                if ov["value"] == "integrator":
+                    row.append(self._integrator_obs(ov["name"], reset_quirk))
+                else:
+                    row.append(self._error(ov["name"]) if ov["value"] == "relative" else self.target[ov["name"]])
             else:
                 row.append(None)
         return row
+
+    def _integrator_obs(self, name, reset_quirk):
+        """fixed_wing.py:804-810 for the newest row (i = 1).  The windowed sum runs over history["error"][-W-1:-1], i.e. it
+        ends BEFORE the newest error, padded with the initial error while the episode is younger than the window.
+        reset_quirk: the value the reference returns in the reset observation (previous episode's history, see reset)."""
+        W, t = self.integration_window, self.steps_count
+        if reset_quirk:
+            old = self._err_hist_prev
+            if old is None:
+                return self._error(name) * W
+            h = old[name]
+            return float(np.sum(h[-W - 1:-1])) + (W + 1) * h[0]    # steps_count - i = -1 < W always
+        h = self.err_hist[name]                                    # t + 1 entries (the newest error included)
+        val = float(np.sum(h[-W - 1:-1]))
+        if t - 1 < W:
+            val += (W - (t - 1)) * h[0]
+        return val
 
     def _action_obs(self, ov, i):
         """Entry of type "action" for row offset i (fixed_wing.py:813-828)."""
@@ -756,6 +784,9 @@ class FixedWingOracle:
             self.lag_rows[newest] = self._row0()
             for old in [k for k in self.lag_rows if k < newest - max(self.row_offsets)]:
                 del self.lag_rows[old]
+        at_reset = ok and t == 0 and self.integration_window and any(
+            ov["type"] == "target" and ov["value"] == "integrator" for ov in cfg["observation"]["states"])
+        reset_row = self._row0(reset_quirk=True) if at_reset else None
         self.rng.begin_obs(t)
         obs = []
         n_idx = 0
@@ -766,6 +797,8 @@ class FixedWingOracle:
                 if L > 1:
                     init_noise = self.rng.init_noise(r) * self.simulator.dt
             src = self.lag_rows[max(newest - (i - 1), 0)]
+            if reset_row is not None:
+                src = reset_row
             if r == 0 and not ok:
                 # row 0 after a failed step: error against the (un-advanced) target with the last valid state
                 src = self._row0()

@@ -54,6 +54,14 @@ def reference_like(kind):
             pars[3]["var"] = 0.5
             cfg["simulator"]["model"] = {"var_type": "absolute", "var": 0.002, "distribution": "uniform", "parameters": pars}
         return cfg
+    if kind == "integrator":   # integration_window: integrator observations and an int_error reward factor
+        cfg["integration_window"] = 12
+        cfg["observation"]["states"][6]["value"] = "integrator"     # roll target: windowed error sum
+        cfg["observation"]["states"] = cfg["observation"]["states"][:9] + [
+            {"name": "Va", "type": "target", "value": "integrator", "low": -300, "high": 300}] + cfg["observation"]["states"][9:]
+        cfg["reward"]["factors"].append({"name": "pitch", "class": "state", "type": "int_error", "function_class": "linear",
+                                         "scaling": 40, "shaping": False, "sign": -1})
+        return cfg
     if kind == "sim_keys":   # simulator.<key> sampled at every reset (fixed_wing.py:560-569)
         cfg["simulator"]["turbulence_intensity"] = {"values": ["light", "moderate", "severe"], "probabilities": [0.5, 0.3, 0.2]}
         cfg["simulator"]["turbulence"] = {"values": [True, False], "probabilities": [0.75, 0.25]}
@@ -101,4 +109,12 @@ CASES = [
     ("sim_keys", "sim_keys", {"steps_max": 25}, {"turbulence": True, "turbulence_intensity": "moderate", "turbulence_output": "filter"}),
     ("model_gaussian", "model_gaussian", {"steps_max": 45}, None),
     ("model_uniform", "model_uniform", {"steps_max": 45}, {"turbulence": True, "turbulence_intensity": "light"}),
+]
+
+# restated in the ORACLE (and checked against the verbatim reference / golden vectors) but not built on the device yet:
+# integration_window (integrator observations, int_error reward factors; fixed_wing.py:708-711, 804-810 incl. the reset
+# observation that reads the previous episode's history, :317-321)
+ORACLE_ONLY_CASES = [
+    ("integrator", "integrator", {"steps_max": 40}, None),
+    ("integrator_matrix", "integrator", {"steps_max": 30, "observation": {"length": 3, "shape": "matrix", "step": 2}}, None),
 ]

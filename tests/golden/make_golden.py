@@ -89,7 +89,7 @@ SCENARIO_STATE = {"roll": 0.35, "pitch": -0.12, "yaw": 0.8, "omega_p": 0.1, "ome
                   "wind_n": 0.0, "wind_e": 0.0, "wind_d": 0.0}
 SCENARIO_TARGET = {"roll": -0.2, "pitch": 0.1, "Va": 22.0}
 
-G1_CASES = [c for c in configs.CASES if c[0] not in ("spec_c3", "cnn_step2_turb", "dev_noise")]
+G1_CASES = [c for c in configs.CASES if c[0] not in ("spec_c3", "cnn_step2_turb", "dev_noise")] + configs.ORACLE_ONLY_CASES
 
 
 def run_case(ref, case, steps=140, episodes=3):

@@ -24,7 +24,7 @@ def _cmp(a, b, path=""):
     return float(np.max(np.abs(np.where(np.isnan(a), 0, a - b)))) if a.size else 0.0
 
 
-CASES = [c for c in configs.CASES if c[0] not in ("spec_c3",)]
+CASES = [c for c in configs.CASES if c[0] not in ("spec_c3",)] + configs.ORACLE_ONLY_CASES
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
