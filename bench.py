@@ -461,6 +461,21 @@ def main():
         side_env("integrator_4x64", (cfg, ckw, hi), n_envs, log_rows, alg_b,
                  "the same workload with 4 RK4 sub-steps and 64 exact actuator micro-steps per env step: the first scheme clearly "
                  "more accurate than the reference's adaptive RK45 at rtol 1e-3 (profiles/r02_convergence.json)", stag=False)
+        from gym_fixed_wing import presets as _pr
+        try:   # every env flies its own aircraft (16 parameters re-sampled at every reset); gentle actions: random full-scale
+            # actions crash the randomised aircraft within a few dozen steps and the run then measures failure ends
+            S = Runner(_pr.preset("cnn_model16"), ckw, skw, n_envs, 0, log_rows)
+            S.pool = [p * 0.15 for p in S.pool]
+            S.enable_graphs()
+            S.run(sc, max(1, STEADY_STATE_STEPS // sc), 0)
+            ms = S.time_replays(sc, sreps)
+            sides["randomised_aircraft"] = side_entry(ms, n_envs, alg_b + 208 + 32, specialised_kernel=S.vec.spec_index >= 0,
+                note="the same workload with simulator.model: 16 aircraft parameters re-sampled per env at every reset (49 per-lane "
+                     "force/moment constants: +208 B/env-step read); actions 0.15 x U(-1,1); the next sets are drawn by a 4-wave "
+                     "launch working off the queue of the envs reset in the previous step")
+            S.vec.close()
+        except Exception as e:
+            sides["randomised_aircraft"] = {"error": str(e)[:300]}
     if side_ok and world > 1 and args.workload == "c3" and not args.envs and not args.total_envs:
         # multi-GPU side figures: BASELINE configs[3] (32 768 envs per GPU) and the north-star point (65 536 envs in total)
         ns_first, ns_n = fd.shard(65536, rank, world)

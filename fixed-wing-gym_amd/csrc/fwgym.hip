@@ -169,6 +169,12 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     Env E;
     if (PHYS) load_sim<TURB>(c, A.S, A.N, e, E);
     load_cold(c, A.S, A.N, e, E);
+    // per-lane force / moment constants (simulator.model; the generic kernel keeps ONE code path): requested with the
+    // simulator rows, so that the first right-hand side does not start by waiting for 13 more round trips
+    Aero la;
+    if (PHYS && (KT::generic || c.model_n > 0)) {
+        if (c.model_n > 0) load_aero(c, A.S, A.N, e, la); else aero_from_cfg(c, la);
+    }
     // k_step2, row-log mode, no attached observer: the PHYSICS wave owns the work that prepares the state the NEXT step starts
     // from, in its idle tail (after the integration, while the gym wave runs its post-barrier chain):
     //  * tail_rows   -- the padding rows of lanes in the first steps of an episode (record 0 + fresh per-row noise + the new
@@ -249,9 +255,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (SPLIT) fail = sim_step<TURB, PartnerActuators>(c, c, E.y, sp, E.wind, gust, E.d, PartnerActuators{acts});
         else
 #endif
-        if (KT::generic || c.model_n > 0) {   // per-lane force / moment constants (the generic kernel keeps ONE code path)
-            Aero la;
-            if (c.model_n > 0) load_aero(c, A.S, A.N, e, la); else aero_from_cfg(c, la);
+        if (KT::generic || c.model_n > 0) {
             fail = sim_step<TURB, NoExtActuators, Aero>(c, la, E.y, sp, E.wind, gust, E.d);
         } else {
             fail = sim_step<TURB>(c, c, E.y, sp, E.wind, gust, E.d);
@@ -827,16 +831,12 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
 // fwg_reset); lanes whose set is current leave at once.  Rare path: loops, the table in a lane-private LDS column.
 struct LaneColumn {
     const float* base;
-    __device__ __forceinline__ float operator[](int i) const { return base[i * FWG_WAVE]; }
+    int stride;
+    __device__ __forceinline__ float operator[](int i) const { return base[i * stride]; }
 };
-__global__ __launch_bounds__(FWG_WAVE) void k_model_draw(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [FWG_N_PARAMS][64]
-    float* tab = lds;
-    const DevCfg& c = *cp;
+// the next episode's parameter set of ONE env (tab: this thread's column of the LDS table [FWG_N_PARAMS][stride])
+__device__ __forceinline__ void model_draw_env(const DevCfg& c, const DynCfg* dp, const KArgs& A, long e, float* P, int stride) {
     const ModelCfg& m = dp->model;
-    const int lane = threadIdx.x;
-    const long e = (long)blockIdx.x * FWG_WAVE + lane;
-    if (e >= A.N) return;
     const unsigned episode_new = f2u(CGROUP(A.S, A.N, (c.L.cold >> 2), e).w) + 1u;
     const unsigned env_id = (unsigned)(A.env_base + e);
     if (c.randomize_scaling) {   // reward.randomize_scaling (fixed_wing.py:330-334): 1 / U(low, high) per listed factor
@@ -860,8 +860,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_model_draw(const DevCfg* __restric
     if (c.model_n <= 0) return;
     const float4 tag = CGROUP(A.S, A.N, (c.L.aero_next >> 2) + FWG_AERO_GROUPS - 1, e);
     if (f2u(tag.y) == episode_new && f2u(tag.z) == dp->generation) return;
-    float* P = tab + lane;
-    for (int i = 0; i < FWG_N_PARAMS; ++i) P[i * FWG_WAVE] = m.nominal[i];
+    for (int i = 0; i < FWG_N_PARAMS; ++i) P[i * stride] = m.nominal[i];
     for (int i = 0; i < m.n; ++i) {
         const u4 b = philox4x32(env_id, episode_new, (unsigned)i, FWG_STREAM_MODEL, A.seed_lo, A.seed_hi);
         const float nominal = m.nominal[m.idx[i]];
@@ -872,15 +871,15 @@ __global__ __launch_bounds__(FWG_WAVE) void k_model_draw(const DevCfg* __restric
         } else {
             x = (nominal - m.var[i]) + 2.f * m.var[i] * u01(b.x);
         }
-        P[m.idx[i] * FWG_WAVE] = x;
+        P[m.idx[i] * stride] = x;
     }
     for (int g = 0; 4 * g < m.n; ++g) {   // the sampled values themselves, in list order (get_simulator_parameters)
         float r[4];
-        for (int i = 0; i < 4; ++i) r[i] = 4 * g + i < m.n ? P[m.idx[4 * g + i] * FWG_WAVE] : 0.f;
+        for (int i = 0; i < 4; ++i) r[i] = 4 * g + i < m.n ? P[m.idx[4 * g + i] * stride] : 0.f;
         GROUP(A.S, A.N, (c.L.model_raw_next >> 2) + g, e) = make_float4(r[0], r[1], r[2], r[3]);
     }
     Aero a;
-    derive_aero<float>(LaneColumn{P}, m.rho, m.g, a);
+    derive_aero<float>(LaneColumn{P, stride}, m.rho, m.g, a);
     float v[4 * FWG_AERO_GROUPS];
     int k = 0;
 #define FWG_AERO_PUT(n) v[k++] = a.n;
@@ -890,6 +889,25 @@ __global__ __launch_bounds__(FWG_WAVE) void k_model_draw(const DevCfg* __restric
 #pragma unroll
     for (int g = 0; g < FWG_AERO_GROUPS; ++g)
         GROUP(A.S, A.N, (c.L.aero_next >> 2) + g, e) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+// every env (fwg_reset, and the first fwg_step after the configuration generation changed): one lane per env
+__global__ __launch_bounds__(FWG_WAVE) void k_model_draw(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [FWG_N_PARAMS][64]
+    const long e = (long)blockIdx.x * FWG_WAVE + threadIdx.x;
+    if (e >= A.N) return;
+    model_draw_env(*cp, dp, A, e, lds + threadIdx.x, FWG_WAVE);
+}
+// the envs that were reset by the previous launch: ONE workgroup works off their queue (count | env indices) and empties it
+// -- a step of a long run resets a few dozen envs, so this replaces a full-grid launch whose lanes almost all leave after
+// two loads (measured 5-8 us per step) by a launch of four waves
+#define FWG_MQ_THREADS 256
+__global__ __launch_bounds__(FWG_MQ_THREADS) void k_model_draw_q(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A,
+                                                                 unsigned* __restrict__ q) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [FWG_N_PARAMS][FWG_MQ_THREADS]
+    const unsigned n = q[0];
+    for (unsigned i = threadIdx.x; i < n; i += FWG_MQ_THREADS) model_draw_env(*cp, dp, A, (long)q[1u + i], lds + threadIdx.x, FWG_MQ_THREADS);
+    __syncthreads();
+    if (threadIdx.x == 0) q[0] = 0u;
 }
 
 __global__ void k_check_nan(const float* __restrict__ a, long n, int* flag) {
@@ -991,6 +1009,8 @@ struct fwg_handle {
     StepSlots* d_slots;
     size_t lds_bytes;
     float* last_metrics_out;      // metrics block of the last fwg_step (what fwg_reduce_success* collect into)
+    unsigned* d_mq;               // simulator.model / randomize_scaling: two reset queues [2][1 + N] (by the parity of the step count)
+    int model_all_stale;          // every env needs a new prepared set (start, fwg_update_config, fwg_seed): full-grid draw next
     struct fwg_actor* observer;   // attached rollout head (fwg_attach_observer) or null
     int split;                    // specialised configurations: the step runs as k_step2 (two waves per 64 envs)
 #ifdef FWG_TIMELINE
@@ -1270,6 +1290,12 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     HIP_TRY(hipMemcpy(h->d_cfg, &h->h, sizeof(DevCfg), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->d_reduce, 0, sizeof(unsigned long long) * FWG_N_REDUCE));
     HIP_TRY(hipMemset(h->d_flag, 0, sizeof(int)));
+    h->d_mq = nullptr;
+    h->model_all_stale = 1;
+    if (h->h.model_n > 0 || h->h.randomize_scaling) {
+        HIP_TRY(hipMalloc((void**)&h->d_mq, 2 * (size_t)(1 + n_envs) * sizeof(unsigned)));
+        HIP_TRY(hipMemset(h->d_mq, 0, 2 * (size_t)(1 + n_envs) * sizeof(unsigned)));
+    }
     *out = h;
     return FWG_OK;
 }
@@ -1277,7 +1303,7 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
 int fwg_destroy(fwg_handle* h) {
     if (!h) return FWG_OK;
     (void)hipSetDevice(h->device);
-    (void)hipFree(h->d_cfg); (void)hipFree(h->d_dyn); (void)hipFree(h->d_reduce); (void)hipFree(h->d_flag); (void)hipFree(h->d_slots);
+    (void)hipFree(h->d_cfg); (void)hipFree(h->d_dyn); (void)hipFree(h->d_reduce); (void)hipFree(h->d_flag); (void)hipFree(h->d_slots); if (h->d_mq) (void)hipFree(h->d_mq);
     delete h;
     return FWG_OK;
 }
@@ -1293,6 +1319,7 @@ int fwg_update_config(fwg_handle* h, const fwg_config* cfg) {
     if (memcmp(&d.L, &h->h.L, sizeof(fwg_layout)) != 0 || d.obs_dim != h->h.obs_dim)
         return fail_with(FWG_ERR_INVALID, "fwg_update_config must not change the state layout");
     dy.generation = h->hd.generation + 1u;   // ranges may have changed: prepared reset draws are stale
+    h->model_all_stale = 1;
     h->cfg = *cfg; h->h = d; h->hd = dy;
     h->spec = match_spec(h->h);
     HIP_TRY(hipSetDevice(h->device));
@@ -1305,6 +1332,7 @@ int fwg_seed(fwg_handle* h, uint64_t seed) {
     if (!h) return fail_with(FWG_ERR_INVALID, "null handle");
     if (seed != h->seed) {   // prepared reset draws belong to the old streams
         h->hd.generation += 1u;
+        h->model_all_stale = 1;
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipMemcpy(h->d_dyn, &h->hd, sizeof(DynCfg), hipMemcpyHostToDevice));
     }
@@ -1333,9 +1361,15 @@ static void base_args(const fwg_handle* h, KArgs* A) {
 
 static void observer_args(fwg_handle* h, KArgs* A);   // defined with the rollout head below
 // simulator.model: before any launch that may reset an env, every env has the parameter set of its next episode prepared
-static void launch_model_draw(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
+static void launch_model_draw(fwg_handle* h, const KArgs& A, hipStream_t stream, bool all) {
     if (h->h.model_n <= 0 && !h->h.randomize_scaling) return;
-    hipLaunchKernelGGL(k_model_draw, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), FWG_N_PARAMS * FWG_WAVE * sizeof(float), stream, h->d_cfg, h->d_dyn, A);
+    if (all || h->model_all_stale) {
+        hipLaunchKernelGGL(k_model_draw, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), FWG_N_PARAMS * FWG_WAVE * sizeof(float), stream, h->d_cfg, h->d_dyn, A);
+        h->model_all_stale = 0;
+    } else {   // the envs reset by the previous launch (queue of the other parity)
+        hipLaunchKernelGGL(k_model_draw_q, dim3(1), dim3(FWG_MQ_THREADS), FWG_N_PARAMS * FWG_MQ_THREADS * sizeof(float), stream, h->d_cfg, h->d_dyn, A,
+                           h->d_mq + (size_t)((h->gstep - 1) & 1) * (size_t)(1 + h->n_envs));
+    }
 }
 
 int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const float* init_target, float* obs_out, void* stream) {
@@ -1345,7 +1379,8 @@ int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const
     A.mask = mask; A.init_state = init_state; A.init_target = init_target; A.obs = obs_out;
     fill_slots(h, h->gstep - 1, &A);  // initial records take the ring position of the last completed step
     if (h->graph_mode) { A.slots_in = h->d_slots + (h->gstep & 1); A.reset_launch = 1; }
-    launch_model_draw(h, A, (hipStream_t)stream);
+    if (h->d_mq != nullptr) A.mq = h->d_mq + (size_t)((h->gstep - 1) & 1) * (size_t)(1 + h->n_envs);   // as if part of the last step
+    launch_model_draw(h, A, (hipStream_t)stream, true);
     launch<false>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return FWG_OK;
@@ -1365,7 +1400,8 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
 #ifdef FWG_TIMELINE
     A.trace = h->trace;
 #endif
-    launch_model_draw(h, A, (hipStream_t)stream);
+    launch_model_draw(h, A, (hipStream_t)stream, false);
+    if (h->d_mq != nullptr) A.mq = h->d_mq + (size_t)(h->gstep & 1) * (size_t)(1 + h->n_envs);
     launch<true>(h, A, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     h->gstep += 1;

@@ -23,6 +23,7 @@ struct KArgs {
     const float* init_state;  // reset: nullable [FWG_N_RESET_VARS][N]
     const float* init_target; // reset: nullable [n_targets][N]
     unsigned seed_lo, seed_hi;
+    unsigned* mq;             // nullable: queue of the envs reset in this launch (count | env indices), consumed by k_model_draw_q
     int slot_act, slot_end, slot_lag, bit_goal;  // ring positions of the CURRENT global step
     int lag_slots[FWG_MAX_ROWS];                 // ring slot holding the row pushed r*obs_step steps ago
     // graph mode (fwg_set_graph_mode): the ring positions live on the device (StepSlots below), double-buffered -- a step
@@ -1382,6 +1383,8 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
         for (int g = 0; g < FWG_MAX_FACTORS / 4; ++g)
             GROUP(A.S, A.N, (c.L.fscale >> 2) + g, e) = CGROUP(A.S, A.N, (c.L.fscale_next >> 2) + g, e);
     }
+    // the set of the episode AFTER this one is now due: the env goes on the queue the next launch's k_model_draw_q works off
+    if ((c.model_n > 0 || c.randomize_scaling) && A.mq != nullptr) A.mq[1u + atomicAdd(A.mq, 1u)] = (unsigned)e;
     E.episode = D.episode;
     E.steps = 0u;
     E.sft = 0u;

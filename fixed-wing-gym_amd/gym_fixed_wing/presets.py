@@ -14,6 +14,10 @@ def default():
 
 
 def preset(kind):
+    if kind == "cnn_model16":   # the cnn variant with randomised aircraft (simulator["model"])
+        cfg = preset("cnn")
+        cfg["simulator"]["model"] = copy.deepcopy(MODEL_16)
+        return cfg
     cfg = default()
     if kind == "default":
         return cfg
@@ -84,6 +88,10 @@ def preset(kind):
 # (name, preset kind, config_kw, sim_config_kw): configurations whose kernels are frozen at build time
 TURB_MODERATE = {"turbulence": True, "turbulence_intensity": "moderate"}
 INTEGRATOR_4X64 = {"method": "rk4", "substeps": 4, "actuator_microsteps": 64}
+# simulator["model"] (fixed_wing.py:532-559): every env flies its own aircraft, 16 parameters re-sampled at every reset
+MODEL_16 = {"var_type": "relative", "var": 0.1, "clip": 0.2, "distribution": "gaussian",
+            "parameters": [{"name": n} for n in ("mass", "Jx", "Jz", "C_L_alpha", "C_L_0", "C_D_p", "C_m_alpha", "C_m_q", "C_m_delta_e",
+                                                 "C_Y_beta", "C_l_p", "C_l_delta_a", "C_n_beta", "C_n_r", "k_motor", "S_prop")]}
 SPECIALISED = [
     ("c2_default", "default", None, None),                                   # BASELINE configs[1]
     ("c3_cnn_step2_dryden", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),  # BASELINE configs[2]/[3]
@@ -97,6 +105,8 @@ SPECIALISED = [
     ("c3_cnn_step2_dryden_log", "cnn", {"observation": {"step": 2}}, TURB_MODERATE),
     # the c3 workload with 4 RK4 sub-steps and 64 actuator micro-steps per env step (bench.py side figure `integrator_4x64`)
     ("c3_hi_lean_log", "cnn", {"observation": {"step": 2}}, dict(TURB_MODERATE, integrator=INTEGRATOR_4X64)),
+    # the c3 workload with randomised aircraft (bench.py side figure `randomised_aircraft`)
+    ("c3_model16_lean_log", "cnn_model16", {"observation": {"step": 2}}, TURB_MODERATE),
 ]
 OBS_LOG_ROWS = 32
 

@@ -113,6 +113,7 @@ static inline float __shfl_xor(float v, int mask, int) {
 static std::mutex emu_atomic_mutex;
 static inline float atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); float o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); unsigned long long o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); unsigned o = *p; *p = o + v; return o; }
 static inline int atomicOr(int* p, int v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); int o = *p; *p = o | v; return o; }
 
 // ---- intrinsics ----------------------------------------------------------------------------------------------------
