@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--rollout", default="auto", choices=["auto", "none", "fused"],
                     help="c5 only: 'fused' (default for c5) = env step + HIP rollout head (VecNormalize + MlpPolicy + "
                          "sampling); 'none' = env step on stored actions")
+    ap.add_argument("--head-precision", default="split", choices=["split", "bf16"],
+                    help="c5: the rollout head's matrix products: 'split' (default) = every fp32 operand as bf16 hi + lo, three MFMA "
+                         "products per tile (~1e-5 of a torch fp32 forward); 'bf16' = one plain bf16 product (~1e-2)")
     ap.add_argument("--eager", action="store_true", help="launch every step from the host instead of replaying hipGraphs")
     ap.add_argument("--lib", default=None, help="measurement builds (tools/ablate.py): path of an alternative libfwgym.so")
     ap.add_argument("--stagger", type=int, default=0,
@@ -352,7 +355,7 @@ def main():
         if args.steps % 2 or args.warmup % 2:
             raise SystemExit("--workload c5: --steps and --warmup must be even (hipGraph chunks)")
         torch.manual_seed(0)
-        actor = DeviceActor.for_env(vec, seed=7, env_id_base=first)
+        actor = DeviceActor.for_env(vec, seed=7, env_id_base=first, precise=args.head_precision == "split")
         actor.load_policy(MlpPolicy(vec.obs_dim))
         rollouts = {}
 
@@ -528,8 +531,9 @@ def main():
                                       "(FixedWingVecEnv default for lagged observations)".format(vec.obs_log_rows)) if layout_log else "dense batch",
                        "launch": ("hipGraph replay: {} x {} steps + {} single".format(replays, chunk, singles)) if graphs else "one host launch per step",
                        "steady_state_steps_before_warmup": extra, "staggered_episode_ages": args.stagger,
-                       "rollout_head": ("HIP VecNormalize + 64-64 MlpPolicy (bf16 MFMA, split operands) + sampling, "
-                                        "hipGraph chunks of {} steps".format(chunk)) if fused else None,
+                       "rollout_head": ("HIP VecNormalize + 64-64 MlpPolicy (bf16 MFMA, {}) + sampling, hipGraph chunks of {} steps".format(
+                                            "split operands: three products per tile" if args.head_precision == "split" else "ONE plain bf16 product per tile",
+                                            chunk)) if fused else None,
                        "success_allgather_every": chunk if graphs and chunk else args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

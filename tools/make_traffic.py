@@ -20,14 +20,17 @@ def parse(path, kernel):
 
 
 out = {}
-for key, fn, kernel in (("c3_log", "r02_c3_rocprofv3_summary_v10.txt", "k_step2<true, 6>"),
-                        ("c3", "r02_c3_dense_rocprofv3_summary_v10.txt", "k_step2<true, 4>")):
+TAG = sys.argv[1] if len(sys.argv) > 1 else "v13"
+for key, fn, kernel in (("c3_log", "r03_c3_rocprofv3_summary_{}.txt".format(TAG), "k_step2<true, 6>"),
+                        ("c3", "r03_c3_dense_rocprofv3_summary_{}.txt".format(TAG), "k_step2<true, 4>")):
     p = os.path.join(ROOT, "profiles", fn)
+    if not os.path.exists(p):
+        continue
     v = parse(p, kernel)
     b = int(v["FETCH_SIZE"] * 1024 * 2 + v["WRITE_SIZE"] * 1024)
     out[key] = {"bytes_per_launch": b, "source_hash": bench.source_hash(),
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/{}): mean per {} dispatch FETCH_SIZE {:.1f} KB "
-                          "x 1024 x 2 (gfx950 counter correction) + WRITE_SIZE {:.1f} KB x 1024; 65536 envs; algorithmic 61.4 MB".format(
+                          "x 1024 x 2 (gfx950 counter correction) + WRITE_SIZE {:.1f} KB x 1024; 65536 envs; algorithmic 61.4 MB (937 B per env-step)".format(
                               fn, kernel, v["FETCH_SIZE"], v["WRITE_SIZE"])}
 with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
     json.dump(out, f, indent=2)
