@@ -185,7 +185,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // have to be waited for at the kernel entry or be kept from the scheduler's hoisting: both measured slower).
     // (steps that fail or end an episode otherwise are completed by the gym wave as before)
     const bool tail_rows = SPLIT && c.obs_log > 0 && c.obs_length > 1 && A.acc == nullptr;
-    const bool pre_install = SPLIT && c.auto_reset && c.obs_log > 0 && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 && A.acc == nullptr;
+    const bool pre_install = SPLIT && c.auto_reset && c.obs_log > 0 && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 && A.acc == nullptr &&
+                             !c.has_int_obs;   // (integrator entries of a reset observation depend on how the old episode ends)
 
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
     // LDS copy once the streamed window has landed, i.e. after the integration)
@@ -257,6 +258,27 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #endif
         if (KT::generic || c.model_n > 0) {
             fail = sim_step<TURB, NoExtActuators, Aero>(c, la, E.y, sp, E.wind, gust, E.d);
+        } else if (SPLIT) {
+            // a HINT only (the word may not be written yet, or hold another workgroup's leftovers): one 4-byte load per group
+            // of the prepared draw, results never used -- the real loads follow after the barrier, when the flag is final
+            float pf[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* flagp = acts + 1;
+            auto hook = [&](int st) {
+                if (pre_install && st == 1) {
+                    const bool want = valid && f2u(*flagp) == 0x5EEDu;
+                    if (__ballot(want) != 0ull) {
+                        if (want) {
+#pragma unroll
+                            for (int g = 0; g < 10; ++g) pf[g] = A.S[((unsigned)((L.draw >> 2) + g) * (unsigned)A.N + (unsigned)e) * 4u];
+                        }
+                    }
+                }
+            };
+            fail = sim_step<TURB, NoExtActuators, DevCfg, decltype(hook)>(c, c, E.y, sp, E.wind, gust, E.d, NoExtActuators(), hook);
+#ifndef FWG_EMU
+#pragma unroll
+            for (int g = 0; g < 10; ++g) asm volatile("" :: "v"(pf[g]));   // (keeps the hint loads from being dropped)
+#endif
         } else {
             fail = sim_step<TURB>(c, c, E.y, sp, E.wind, gust, E.d);
         }
@@ -291,6 +313,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // round trips run while the physics wave integrates
     bool pre_end = false, pre_draw = false, pre_rows = false;
     float4 pre_tag = make_float4(0.f, 0.f, 0.f, 0.f), pre_old = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 int_old = make_float4(0.f, 0.f, 0.f, 0.f);   // integration_window: cumulative error sums W + 1 records back
     ResetDraw RD;
     // lanes in the first steps of an episode: the padding rows of their observation, up to the "action" entries
     bool pre_early = false;
@@ -323,6 +346,10 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
         }
         E.steps += 1u;
+        if (c.int_window) {   // S_(t-1-W): the record W + 1 positions before this step's in the cumulative error ring
+            int slot = A.slot_end - (c.int_window + 1); slot += (slot < 0) ? FWG_END_RING : 0;
+            int_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+        }
         // lanes in the first steps of an episode (row-log mode): their record 0 is requested now, the padding rows follow at
         // the end of this block
         const bool early_now = c.obs_log > 0 && c.obs_length > 1 && valid && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
@@ -335,6 +362,9 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // an episode that ends at steps_max is known here: everything its episode-end branch reads from memory is requested
         // now -- the prepared draw, the end-error record, the lagged rows of the terminal observation --, so that the round
         // trips run under the rest of this block and the partner's integration
+        // (k_step2) the partner looks at this word half-way through its integration and, for a foreseen end, starts pulling
+        // the prepared draw's cold lines into the cache, so that its tail work does not begin with their round trip
+        if (pre_install) acts[1] = u2f((valid && done && draw_stage_of(E.flags) == FWG_DRAW_READY) ? 0x5EEDu : 0u);
         if (c.auto_reset && c.steps_max > 0 && __ballot(valid && done) != 0ull) {
             if (valid && done) {
                 pre_end = true;
@@ -521,6 +551,31 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (k < c.n_targets) err[k] = target_error(c.target[k], E.tgt[k], T.get(c.target[k].var));
     float reward = 0.f;
     const unsigned rec = E.steps;  // index of the record this step appends to the episode histories
+    // integration_window (fixed_wing.py:708-711, 804-810): the sum of the W errors BEFORE the newest one, from the episode's
+    // cumulative sums: S_(t-1) (E.esum has not taken this step's error yet) - S_(t-1-W), padded with the initial error while
+    // the episode is younger than the window.  After a failed step the histories are one record shorter: S_(t-2) - S_(t-2-W)
+    float wsum[3] = {0.f, 0.f, 0.f};
+    if (c.int_window) {
+        const int t = (int)E.steps, W = c.int_window;
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wsum[k] = E.esum[k] - ((t - 1 - W >= 0) ? (k == 0 ? int_old.x : (k == 1 ? int_old.y : int_old.z)) : 0.f);
+        } else {
+            float4 o2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t - 2 - W >= 0) {
+                int slot = A.slot_end - (W + 2); slot += (slot < 0) ? FWG_END_RING : 0;
+                o2 = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+            }
+            wsum[0] = E.esum[0] - E.perr[0] - o2.x; wsum[1] = E.esum[1] - E.perr[1] - o2.y; wsum[2] = E.esum[2] - E.perr[2] - o2.z;
+        }
+#pragma unroll
+        for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+            if (k < c.n_targets) {
+                T.put(FWG_TAB_INT + k, wsum[k] + (float)max(0, W - (t - 1)) * E.e0[k]);
+                E.int_reset[k] = wsum[k] + (float)(W + 1) * E.e0[k];   // what a reset after THIS step would show
+            }
+        }
+    }
     if (ok) {
         bool achieved_now = false, resample = false;
         unsigned g = 0u;
@@ -544,7 +599,10 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             if (F.cls == FWG_RC_ACTION) {
                 val = fval_action[f];
             } else if (F.cls == FWG_RC_STATE) {
-                val = (F.type == FWG_RT_VALUE) ? T.get(F.src) : (F.src == 0 ? err[0] : (F.src == 1 ? err[1] : err[2]));
+                if (F.type == FWG_RT_INT_ERROR)
+                    val = (F.src == 0 ? wsum[0] : (F.src == 1 ? wsum[1] : wsum[2])) + (float)max(0, c.int_window - (int)E.steps) * E.e0[F.src < 3 ? F.src : 0];
+                else
+                    val = (F.type == FWG_RT_VALUE) ? T.get(F.src) : (F.src == 0 ? err[0] : (F.src == 1 ? err[1] : err[2]));
             } else if (F.cls == FWG_RC_SUCCESS) {
                 val = achieved_now ? (F.value_is_timesteps ? (float)(c.steps_max - (int)E.steps) : F.value) : 0.f;
             } else if (F.cls == FWG_RC_STEP) {
@@ -622,6 +680,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         }
     } else {
         done = true;
+        if (c.int_window) E.flags |= FWG_FLAG_LAST_FAILED;
         reward = c.step_fail_timesteps ? (float)((int)E.steps - c.steps_max) : c.step_fail_value;
         term = FWG_TERM_VAR0 + (unsigned)(fail - 1);
     }
@@ -803,6 +862,23 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     {   // only what survives a reset is needed: the sticky goal flag and the episode counter
         const float4 w = CGROUP(A.S, A.N, (c.L.cold >> 2), e), f = CGROUP(A.S, A.N, (c.L.gym >> 2) + 1, e);
         E.episode = f2u(w.w); E.flags = f2u(f.x);
+    }
+    if (c.int_window && sel) {   // integrator entries of the reset observation: the old episode's sums (see reset_finish)
+        const int g0 = c.L.gym >> 2;
+        const float4 q0 = CGROUP(A.S, A.N, g0 + 0, e), q2 = CGROUP(A.S, A.N, g0 + 2, e), q3 = CGROUP(A.S, A.N, g0 + 3, e),
+                     q4 = CGROUP(A.S, A.N, g0 + 4, e), q7 = CGROUP(A.S, A.N, g0 + 7, e);
+        const bool last_failed = (E.flags & FWG_FLAG_LAST_FAILED) != 0u;
+        const int steps = (int)(f2u(q0.w) & 0xFFFFu), W = c.int_window;
+        const int n = last_failed ? steps : steps + 1;                  // records in the old histories
+        const float esum[3] = {q2.x, q2.y, q2.z}, perr[3] = {q2.w, q3.w, q4.y}, e0[3] = {q7.y, q7.z, q7.w};
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n - W - 2 >= 0) {   // S_(n-W-2): W + 1 records before the last one (which sits one slot earlier after a failed step)
+            int slot = A.slot_end - (last_failed ? 1 : 0) - (W + 1); slot += (slot < 0) ? FWG_END_RING : 0; slot += (slot < 0) ? FWG_END_RING : 0;
+            o = CGROUP(A.S, A.N, (c.L.end_ring >> 2) + slot, e);
+        }
+        E.int_reset[0] = esum[0] - perr[0] - o.x + (float)(W + 1) * e0[0];
+        E.int_reset[1] = esum[1] - perr[1] - o.y + (float)(W + 1) * e0[1];
+        E.int_reset[2] = esum[2] - perr[2] - o.z + (float)(W + 1) * e0[2];
     }
     if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane * 4, A.slot_end, A.slot_lag, A.bit_goal);
     if (c.obs_log == 0) {
@@ -1139,6 +1215,12 @@ static int lower_config(const fwg_config& c, DevCfg* d, DynCfg* dy, std::string*
     }
     d->randomize_scaling = c.randomize_scaling ? 1 : 0;
     if (c.sk_n_intensity < 0 || c.sk_n_intensity > 4 || c.sk_n_turbulence < 0 || c.sk_n_turbulence > 2) { *why = "sk_n_* out of range"; return -1; }
+    if (c.integration_window < 0 || c.integration_window > FWG_END_WINDOW - 1) { *why = "integration_window out of range"; return -1; }
+    d->int_window = c.integration_window;
+    d->has_int_obs = 0;
+    for (int j = 0; j < c.n_obs; ++j) d->has_int_obs |= c.obs[j].type == FWG_OBS_TARGET_INTEGRATOR ? 1 : 0;
+    if ((d->has_int_obs || d->int_window) && !c.metrics) { *why = "integration_window needs the metric accumulators (metrics = 1)"; return -1; }
+    if (d->has_int_obs && d->int_window == 0) { *why = "integrator observations need integration_window > 0"; return -1; }
     d->sim_keys = (c.sk_n_intensity > 0 || c.sk_n_turbulence > 0) ? 1 : 0;
     if (d->sim_keys && !c.turbulence) { *why = "sampled turbulence keys need the turbulence kernels (turbulence = 1)"; return -1; }
     dy->sk_n_int = c.sk_n_intensity; dy->sk_n_turb = c.sk_n_turbulence; dy->sk_idx_int = c.sk_index_intensity; dy->sk_idx_turb = c.sk_index_turbulence;

@@ -11,6 +11,7 @@
 #define FWG_FLAG_GOAL_ACHIEVED 1u        // sticky for the env's lifetime (fixed_wing.py:51,381-382)
 #define FWG_FLAG_PREV_VALID_SHIFT 1      // bits 1..3: prev_shaping[fclass] is not None (fixed_wing.py:327-328,756,765)
 #define FWG_FLAG_FIN_PENDING (1u << 7)    // the env's finished-episode record (L.fin) has not been collected yet (k_finish)
+#define FWG_FLAG_LAST_FAILED (1u << 31)   // the episode's last step failed: its histories are one record shorter (integration_window)
 #define FWG_FLAG_RESAMPLE_SHIFT 8        // bits 8..31: target resample counter inside the episode (RNG sub-stream)
 
 // Philox stream ids (shared with oracle/physics.py)
@@ -120,6 +121,8 @@ struct DevCfg {
     float dryA[FWG_N_DRYDEN * FWG_N_DRYDEN], dryB[FWG_N_DRYDEN * 4], dryC[6 * FWG_N_DRYDEN];
     int turb_increment;   // the gust sample is the first difference of the filter outputs (kept in the simulator rows)
     int sim_keys;         // simulator.turbulence / turbulence_intensity are sampled per env at every reset: per-env gust gain
+    int int_window;       // integration_window when integrator observations / int_error factors use it, else 0
+    int has_int_obs;      // an observation entry of value "integrator" exists (its reset value depends on the PREVIOUS episode)
     // ---- gym side
     int steps_max, obs_length, obs_step, n_obs, obs_dim, obs_noise;
     float obs_noise_mean, obs_noise_std;

@@ -265,7 +265,8 @@ __device__ __forceinline__ void log_wrap(const DevCfg& c, float* log, long N, lo
 struct LdsMap { int aring, cring, lag, stage, tab, obs, total; };
 #define FWG_TAB_TGT FWG_N_VARS               // table rows: simulator variables | targets | target errors
 #define FWG_TAB_ERR (FWG_N_VARS + FWG_MAX_TARGETS)
-#define FWG_TAB_ROWS (FWG_N_VARS + 2 * FWG_MAX_TARGETS)
+#define FWG_TAB_INT (FWG_N_VARS + 2 * FWG_MAX_TARGETS)   // ... | windowed error sums (integrator observations)
+#define FWG_TAB_ROWS (FWG_N_VARS + 3 * FWG_MAX_TARGETS)
 // row stride (words) of the output staging: records of 4q words with q odd are written/read with conflict-free 16-byte
 // LDS accesses; any other size falls back to an odd stride and 4-byte accesses
 __host__ __device__ inline bool obs_vec4(int obs_dim) { return (obs_dim % 4 == 0) && ((obs_dim / 4) % 2 == 1); }
@@ -312,6 +313,7 @@ struct Env {
     float dry[FWG_N_DRYDEN];
     float gust[6];       // increment turbulence: this step's gust sample (computed when the filter advanced one step ago)
     float gust_gain;     // simulator.turbulence / turbulence_intensity sampled per env and episode: gain on the gust (cold row)
+    float int_reset[3];  // integration_window: what the integrator entries of the NEXT reset observation show (fixed_wing.py:317-321)
     Derived d;
     float tgt[FWG_MAX_TARGETS];
     float tprop[FWG_MAX_TARGETS][4];  // slope|amplitude, period, phase, bias
@@ -586,7 +588,7 @@ template <class TAB>
 __device__ __forceinline__ void sample_targets(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, Env& E,
                                                const TAB& T, const float* given) {
     const unsigned env_id = (unsigned)(A.env_base + e);
-    const unsigned resample = E.flags >> FWG_FLAG_RESAMPLE_SHIFT;
+    const unsigned resample = (E.flags & ~FWG_FLAG_LAST_FAILED) >> FWG_FLAG_RESAMPLE_SHIFT;
     E.sft = 0;
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
@@ -695,22 +697,29 @@ __device__ __forceinline__ float action_obs(const DevCfg& c, const float* ring, 
 }
 
 // newest observation row (un-noised, normalised) into ob[0, n_obs) and, when `push`, into the lag ring (AoS record)
+// int_pad (reset only, integration_window): the integrator entries of the PUSHED record -- the source of later padding rows,
+// (W + 1) e0 -- differ from those of the reset observation itself (which show the previous episode's sums, see reset_finish)
 template <class TAB, class OB>
 __device__ __forceinline__ void build_row0(const DevCfg& c, const KArgs& A, long e, const Env& E, const TAB& T, OB& ob,
                                            const float* ring, int ring_slot, bool push, int act_slot,
-                                           const float* pre_action = nullptr) {
+                                           const float* pre_action = nullptr, const float* int_pad = nullptr) {
+    float padv[FWG_MAX_OBS];
 #pragma unroll
     for (int j = 0; j < FWG_MAX_OBS; ++j) {
+        padv[j] = 0.f;
         if (j < c.n_obs) {
             const DevObs& o = c.obs[j];
             float v;
             if (o.type == FWG_OBS_STATE) v = T.get(o.src);
             else if (o.type == FWG_OBS_TARGET_RELATIVE) v = T.get(FWG_TAB_ERR + o.src);
             else if (o.type == FWG_OBS_TARGET_ABSOLUTE) v = T.get(FWG_TAB_TGT + o.src);
+            else if (o.type == FWG_OBS_TARGET_INTEGRATOR) v = T.get(FWG_TAB_INT + o.src);
             else v = pre_action != nullptr ? pre_action[j]   // already summed while the integration ran (step kernel)
                                            : action_obs(c, ring, o.src, o.window, E.steps, act_slot, T.get(FWG_V_ELEVATOR + o.src));
-            if (o.norm) v = (v - o.mean) * o.inv_var;
+            float vp = (int_pad != nullptr && o.type == FWG_OBS_TARGET_INTEGRATOR) ? int_pad[o.src] : v;
+            if (o.norm) { v = (v - o.mean) * o.inv_var; vp = (vp - o.mean) * o.inv_var; }
             ob.put(j, v);
+            padv[j] = vp;
         }
     }
     if (push && c.obs_length > 1) {  // the record enters the lag ring as ceil(n_obs/4) 16-byte groups
@@ -719,8 +728,8 @@ __device__ __forceinline__ void build_row0(const DevCfg& c, const KArgs& A, long
         for (int g = 0; g < FWG_MAX_OBS / 4; ++g)
             if (g < ng)
                 store_group_once(A.S, A.N, (c.L.lag_ring >> 2) + ring_slot * ng + g, e,
-                                 make_float4(ob.get(4 * g), 4 * g + 1 < c.n_obs ? ob.get(4 * g + 1) : 0.f,
-                                             4 * g + 2 < c.n_obs ? ob.get(4 * g + 2) : 0.f, 4 * g + 3 < c.n_obs ? ob.get(4 * g + 3) : 0.f));
+                                 make_float4(padv[4 * g], 4 * g + 1 < c.n_obs ? padv[4 * g + 1] : 0.f,
+                                             4 * g + 2 < c.n_obs ? padv[4 * g + 2] : 0.f, 4 * g + 3 < c.n_obs ? padv[4 * g + 3] : 0.f));
     }
 }
 
@@ -1435,7 +1444,21 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
     if (rows_done) return;   // (k_step2, foreseen end: the partner wave wrote the cold and simulator rows as well)
     store_cold(c, A.S, A.N, e, E);
     // ---- observation: every row is the initial record (+ per-row init noise when length > 1)
-    build_row0(c, A, e, E, T, ob, ring, g_lag, true, 0);
+    float int_pad[3] = {0.f, 0.f, 0.f};
+    if (c.int_window) {
+        // integrator entries (fixed_wing.py:804-810).  The reference builds the reset observation BEFORE it re-creates its
+        // histories (:317-321): the entries show the PREVIOUS episode's windowed sum + (W + 1) times its initial error
+        // (E.int_reset, set by the caller from the old episode), W e0 on the env's very first reset ("history is None");
+        // rows that later pad the window use (W + 1) e0 of the NEW episode
+#pragma unroll
+        for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+            if (k < c.n_targets) {
+                T.put(FWG_TAB_INT + k, D.episode == 1u ? (float)c.int_window * err[k] : E.int_reset[k]);
+                int_pad[k] = (float)(c.int_window + 1) * err[k];
+            }
+        }
+    }
+    build_row0(c, A, e, E, T, ob, ring, g_lag, true, 0, nullptr, c.int_window ? int_pad : nullptr);
     if (c.obs_length > 1) {
 #pragma unroll
         for (int r = FWG_MAX_ROWS - 1; r >= 0; --r) {

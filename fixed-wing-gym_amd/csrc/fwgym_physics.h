@@ -235,9 +235,12 @@ struct NoExtActuators {
     static constexpr bool enabled = false;
     __device__ __forceinline__ void fetch(float (&)[5], float (&)[5]) const {}
 };
-template <bool TURB, class EXT = NoExtActuators, class AP = DevCfg>
+// `hook(st)` runs after stage st of the first sub-step: a place for work that only needs to be STARTED while the integration
+// runs (k_step2: cache prefetches for the tail work, decided from a word its partner wave has written by then)
+struct NoStageHook { __device__ __forceinline__ void operator()(int) const {} };
+template <bool TURB, class EXT = NoExtActuators, class AP = DevCfg, class HOOK = NoStageHook>
 __device__ __forceinline__ int sim_step(const DevCfg& c, const AP& aero, float (&y)[NY], const float (&sp)[3], const float (&wind)[3],
-                                        const float (&gust)[6], Derived& d, const EXT& ext = EXT()) {
+                                        const float (&gust)[6], Derived& d, const EXT& ext = EXT(), const HOOK& hook = HOOK()) {
     const bool use_ext = EXT::enabled && c.nsub == 1;
     float yb[NB], a[5];
 #pragma unroll
@@ -280,6 +283,7 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, const AP& aero, float (
             for (int i = 0; i < 3; ++i) act[i] = (st == 0) ? a[i] : ((st == 3) ? a_full[i] : a_half[i]);
             rhs<TURB>(c, aero, ys, act, wind, gust, k, fail);
             if (use_ext && st == 0) ext.fetch(a_half, a_full);   // needed from the second stage on
+            if (s == 0) hook(st);
             const float bw = (st == 0 || st == 3) ? c.h_sixth : 2.f * c.h_sixth;
             const float aw = (st == 2) ? c.h : c.half_h;
 #pragma unroll

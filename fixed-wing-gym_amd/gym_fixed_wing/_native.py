@@ -30,10 +30,10 @@ PARAMS = ["mass", "Jx", "Jy", "Jz", "Jxz", "S_wing", "b", "c", "S_prop", "C_prop
 assert len(PARAMS) == N_PARAMS and len(VARS) == N_VARS
 
 TERM_NONE, TERM_STEPS, TERM_SUCCESS, TERM_VAR0, TERM_NAN = 0, 1, 2, 16, 255
-OBS_STATE, OBS_TARGET_RELATIVE, OBS_TARGET_ABSOLUTE, OBS_ACTION = 0, 1, 2, 3
+OBS_STATE, OBS_TARGET_RELATIVE, OBS_TARGET_ABSOLUTE, OBS_ACTION, OBS_TARGET_INTEGRATOR = 0, 1, 2, 3, 4
 TGT_CONSTANT, TGT_COMPENSATE, TGT_LINEAR, TGT_SINUSOIDAL = 0, 1, 2, 3
 RC_STATE, RC_ACTION, RC_SUCCESS, RC_STEP, RC_GOAL = 0, 1, 2, 3, 4
-RT_VALUE, RT_ERROR, RT_DELTA, RT_BOUND, RT_PER_STATE, RT_ALL = 0, 1, 2, 3, 4, 5
+RT_VALUE, RT_ERROR, RT_DELTA, RT_BOUND, RT_PER_STATE, RT_ALL, RT_INT_ERROR = 0, 1, 2, 3, 4, 5, 6
 FC_LINEAR, FC_QUADRATIC, FC_EXPONENTIAL = 0, 1, 2
 ON_SUCCESS = {"none": 0, "done": 1, "new": 2}
 TURB_FILTER, TURB_INCREMENT = 0, 1
@@ -112,7 +112,7 @@ class Config(C.Structure):
         ("rise_low", C.c_double), ("rise_high", C.c_double),
         ("model_n", C.c_int32), ("model_dist", C.c_int32), ("model_idx", C.c_int32 * N_PARAMS), ("pad_model_", C.c_int32),
         ("model_var", C.c_double * N_PARAMS), ("model_clip_lo", C.c_double * N_PARAMS), ("model_clip_hi", C.c_double * N_PARAMS),
-        ("randomize_scaling", C.c_int32), ("pad_rs_", C.c_int32),
+        ("randomize_scaling", C.c_int32), ("integration_window", C.c_int32),
         ("sk_n_intensity", C.c_int32), ("sk_n_turbulence", C.c_int32), ("sk_index_intensity", C.c_int32), ("sk_index_turbulence", C.c_int32),
         ("sk_cum_intensity", C.c_double * 4), ("sk_gain_intensity", C.c_double * 4),
         ("sk_cum_turbulence", C.c_double * 2), ("sk_on_turbulence", C.c_double * 2), ("sk_base_gain", C.c_double),

@@ -297,8 +297,8 @@ class EnvConfig(object):
 
     def _check_supported(self):
         cfg = self.cfg
-        if cfg.get("integration_window", 0):
-            raise NotImplementedError("integration_window > 0 (integrator observations / int_error rewards)")
+        if cfg.get("integration_window", 0) > 49:   # the windowed sums are differences over the 51-slot cumulative error ring
+            raise NotImplementedError("integration_window > 49")
         for key, value in cfg["simulator"].items():
             if key in ("states", "model"):
                 continue
@@ -322,10 +322,10 @@ class EnvConfig(object):
             if t.get("class", "constant") not in ("constant", "compensate", "linear", "sinusoidal"):
                 raise NotImplementedError("target class {}".format(t.get("class")))
         for ov in cfg["observation"]["states"]:
-            if ov["type"] == "target" and ov["value"] not in ("relative", "absolute"):
+            if ov["type"] == "target" and ov["value"] not in ("relative", "absolute", "integrator"):
                 raise NotImplementedError("observation value {}".format(ov["value"]))
         for f in cfg["reward"]["factors"]:
-            if f["class"] == "state" and f["type"] not in ("value", "error"):
+            if f["class"] == "state" and f["type"] not in ("value", "error", "int_error"):
                 raise NotImplementedError("reward type {}".format(f["type"]))
 
     def set_curriculum_level(self, level):
@@ -428,7 +428,8 @@ class EnvConfig(object):
             if ov["type"] == "state":
                 d.type, d.src = nat.OBS_STATE, nat.VAR_ID[ov["name"]]
             elif ov["type"] == "target":
-                d.type = nat.OBS_TARGET_RELATIVE if ov["value"] == "relative" else nat.OBS_TARGET_ABSOLUTE
+                d.type = {"relative": nat.OBS_TARGET_RELATIVE, "absolute": nat.OBS_TARGET_ABSOLUTE,
+                          "integrator": nat.OBS_TARGET_INTEGRATOR}[ov["value"]]
                 d.src = self.target_names.index(ov["name"])
             elif ov["type"] == "action":
                 d.type, d.src = nat.OBS_ACTION, anames.index(ov["name"])
@@ -506,7 +507,8 @@ class EnvConfig(object):
                 if typ == "value":
                     d.type, d.src = nat.RT_VALUE, nat.VAR_ID[f["name"]]
                 else:
-                    d.type, d.src = nat.RT_ERROR, self.target_names.index(f["name"])
+                    d.type = nat.RT_INT_ERROR if typ == "int_error" else nat.RT_ERROR
+                    d.src = self.target_names.index(f["name"])
             elif cls == "success":
                 d.cls = nat.RC_SUCCESS
                 d.value_is_timesteps = int(f["value"] == "timesteps")
@@ -540,7 +542,13 @@ class EnvConfig(object):
             d.max = float(f["max"]) if d.has_max else 0.0
 
         metrics = cfg.get("metrics", [])
-        c.metrics = int(len(metrics) > 0)
+        c.integration_window = int(cfg.get("integration_window", 0) or 0)
+        uses_window = any(ov["type"] == "target" and ov["value"] == "integrator" for ov in cfg["observation"]["states"]) or \
+            any(f["class"] == "state" and f["type"] == "int_error" for f in cfg["reward"]["factors"])
+        if not uses_window:
+            c.integration_window = 0
+        # (the windowed sums live on the episode's cumulative error sums, which the metric accumulators maintain)
+        c.metrics = int(len(metrics) > 0 or c.integration_window > 0)
         c.rise_low, c.rise_high = 0.1, 0.9
         for m in metrics:
             if m["name"] == "rise_time":

@@ -80,7 +80,8 @@ enum {
 };
 
 /* observation.states[i] (fixed_wing.py:796-838) */
-enum { FWG_OBS_STATE = 0, FWG_OBS_TARGET_RELATIVE = 1, FWG_OBS_TARGET_ABSOLUTE = 2, FWG_OBS_ACTION = 3 };
+enum { FWG_OBS_STATE = 0, FWG_OBS_TARGET_RELATIVE = 1, FWG_OBS_TARGET_ABSOLUTE = 2, FWG_OBS_ACTION = 3,
+       FWG_OBS_TARGET_INTEGRATOR = 4 /* windowed error sum over integration_window steps (fixed_wing.py:804-810) */ };
 typedef struct fwg_obs_desc {
     int32_t type;      /* FWG_OBS_* */
     int32_t src;       /* STATE: fwg_var; TARGET_*: index into target.states; ACTION: index into action.states */
@@ -109,7 +110,8 @@ typedef struct fwg_target_desc {
 
 /* reward.factors[i] (fixed_wing.py:683-751) */
 enum { FWG_RC_STATE = 0, FWG_RC_ACTION = 1, FWG_RC_SUCCESS = 2, FWG_RC_STEP = 3, FWG_RC_GOAL = 4 };
-enum { FWG_RT_VALUE = 0, FWG_RT_ERROR = 1, FWG_RT_DELTA = 2, FWG_RT_BOUND = 3, FWG_RT_PER_STATE = 4, FWG_RT_ALL = 5 };
+enum { FWG_RT_VALUE = 0, FWG_RT_ERROR = 1, FWG_RT_DELTA = 2, FWG_RT_BOUND = 3, FWG_RT_PER_STATE = 4, FWG_RT_ALL = 5,
+       FWG_RT_INT_ERROR = 6 /* fixed_wing.py:708-711 */ };
 enum { FWG_FC_LINEAR = 0, FWG_FC_QUADRATIC = 1, FWG_FC_EXPONENTIAL = 2 };
 typedef struct fwg_factor_desc {
     int32_t cls;       /* FWG_RC_* */
@@ -201,7 +203,8 @@ typedef struct fwg_config {
 
     /* ---- reward["randomize_scaling"] (fixed_wing.py:330-334): factors whose scaling is given as [low, high] get a
      * scaling drawn U(low, high) for every env at every reset; low == high: the fixed factor[i].scaling */
-    int32_t randomize_scaling, pad_rs_;
+    int32_t randomize_scaling;
+    int32_t integration_window;  /* fixed_wing.py:53: window of the integrator observations / int_error factors (0: none; <= FWG_END_WINDOW - 1) */
     /* ---- simulator.<key> sampling at every reset (fixed_wing.py:560-569) for the two turbulence keys.  Per env and episode the
      * gust is scaled by on(turbulence) * W20(turbulence_intensity) / W20(the intensity dryden_C was built for): the intensity
      * only enters the MIL-F-8785C filters as an output gain.  n = 0: the key is not sampled (the configuration's value holds). */

@@ -111,10 +111,11 @@ CASES = [
     ("model_uniform", "model_uniform", {"steps_max": 45}, {"turbulence": True, "turbulence_intensity": "light"}),
 ]
 
-# restated in the ORACLE (and checked against the verbatim reference / golden vectors) but not built on the device yet:
-# integration_window (integrator observations, int_error reward factors; fixed_wing.py:708-711, 804-810 incl. the reset
-# observation that reads the previous episode's history, :317-321)
-ORACLE_ONLY_CASES = [
+# integration_window: integrator observations + an int_error reward factor (fixed_wing.py:708-711, 804-810 incl. the reset
+# observation that reads the previous episode's history, :317-321): vector and matrix observations
+CASES += [
     ("integrator", "integrator", {"steps_max": 40}, None),
     ("integrator_matrix", "integrator", {"steps_max": 30, "observation": {"length": 3, "shape": "matrix", "step": 2}}, None),
+    ("integrator_fail_prone", "integrator", {"simulator": {"states": {6: {"constraint_min": -40, "constraint_max": 40}}}}, None),
 ]
+ORACLE_ONLY_CASES = []

@@ -102,7 +102,7 @@ def run_case(ref, case, steps=140, episodes=3):
     env.seed(7)
     env.np_random = ScriptedRNG()
     rec = {"case": name, "config": cfg, "config_kw": ckw, "sim_config_kw": skw, "episodes": []}
-    acts = actions_for(3, steps, 1.8 if name == "fail_prone" else 1.3)
+    acts = actions_for(3, steps, 1.8 if "fail_prone" in name else 1.3)
     t = 0
     for ep in range(episodes):
         st = dict(SCENARIO_STATE)

@@ -35,7 +35,7 @@ def test_emulated_kernel_matches_oracle(emu_lib, case):
                           _backend=HostBackend(), _lib_path=emu_lib)
     assert (vec.spec_index >= 0) == (name in configs.SPECIALISED_CASES), (name, vec.spec_index)
     orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
-    acts = _actions(5, steps, n, scale=1.8 if name == "fail_prone" else 1.3)
+    acts = _actions(5, steps, n, scale=1.8 if "fail_prone" in name else 1.3)
     tol = 5e-2 if name == "dev_noise" else 4e-3
     res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=tol, atol=tol)
     assert res["episodes"] >= (1 if (ckw and "steps_max" in ckw) or name in ("success_done", "fail_prone") else 0)

@@ -147,3 +147,34 @@ def test_goal_env_reproduces_the_reference_goal_env(backend, form):
         got = env.compute_reward(np.array(rl["achieved"]), np.array(rl["desired"]), rl["info"])
         assert got == pytest.approx(rl["reward"], abs=2e-4), (rl["info"]["step"], got, rl["reward"])
     env.close()
+
+
+@pytest.mark.parametrize("fail_prone", [False, True], ids=["time_limit", "failure"])
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_integrator_observations_across_explicit_resets(backend, fail_prone):
+    """integration_window through the single-env class (auto-reset off: fwg_reset between episodes): the integrator entries
+    of a reset observation show the PREVIOUS episode's windowed error sum (fixed_wing.py:317-321 builds the observation before
+    the histories are re-created), one record shorter after an episode that ended in a failed step."""
+    cfg = configs.reference_like("integrator")
+    ckw = {"steps_max": 30}
+    if fail_prone:
+        ckw["simulator"] = {"states": {6: {"constraint_min": -40, "constraint_max": 40}}}
+    env = FixedWingAircraft(cfg, config_kw=ckw, **_kw(backend))
+    orc = parity.make_oracles(cfg, 1, 0, config_kw=ckw)[0]
+    env.seed(0)
+    rng = np.random.default_rng(5)
+    ends = []
+    for ep in range(4):
+        st = dict(STATE, roll=0.3 + 0.2 * ep)
+        obs, want = env.reset(state=st, target=TARGET), orc.reset(state=st, target=TARGET)
+        np.testing.assert_allclose(obs, want, atol=2e-3, rtol=2e-3, err_msg="reset observation of episode {}".format(ep))
+        done = False
+        while not done:
+            a = rng.uniform(-1.8, 1.8, 3) if fail_prone else rng.uniform(-1, 1, 3)
+            obs, rew, done, info = env.step(a)
+            o2, r2, d2, i2 = orc.step(a)
+            np.testing.assert_allclose(obs, o2, atol=2e-3, rtol=2e-3)
+            assert rew == pytest.approx(r2, abs=2e-3) and done == d2
+        ends.append(info["termination"])
+    assert (set(ends) != {"steps"}) == fail_prone, ends
+    env.close()

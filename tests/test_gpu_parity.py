@@ -50,7 +50,7 @@ def test_gym_rollout_matches_oracle(case):
     vec = _vec(cfg, n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True)
     assert (vec.spec_index >= 0) == (name in configs.SPECIALISED_CASES), (name, vec.spec_index)
     orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
-    acts = _actions(5, steps, n, scale=1.8 if name == "fail_prone" else 1.3)
+    acts = _actions(5, steps, n, scale=1.8 if "fail_prone" in name else 1.3)
     tol = 5e-2 if name == "dev_noise" else 4e-3
     res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=tol, atol=tol)
     print(name, res)
@@ -72,7 +72,7 @@ def test_two_wave_kernel_matches_oracle_through_episode_ends(case):
     vec = _vec(cfg, n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True, specialize=True)
     assert vec.spec_index >= 0
     orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
-    acts = _actions(5, steps, n, scale=1.8 if name == "fail_prone" else 1.3)
+    acts = _actions(5, steps, n, scale=1.8 if "fail_prone" in name else 1.3)
     res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3)
     if ckw and "steps_max" in ckw:
         assert res["episodes"] >= n
