@@ -258,27 +258,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #endif
         if (KT::generic || c.model_n > 0) {
             fail = sim_step<TURB, NoExtActuators, Aero>(c, la, E.y, sp, E.wind, gust, E.d);
-        } else if (SPLIT) {
-            // a HINT only (the word may not be written yet, or hold another workgroup's leftovers): one 4-byte load per group
-            // of the prepared draw, results never used -- the real loads follow after the barrier, when the flag is final
-            float pf[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float* flagp = acts + 1;
-            auto hook = [&](int st) {
-                if (pre_install && st == 1) {
-                    const bool want = valid && f2u(*flagp) == 0x5EEDu;
-                    if (__ballot(want) != 0ull) {
-                        if (want) {
-#pragma unroll
-                            for (int g = 0; g < 10; ++g) pf[g] = A.S[((unsigned)((L.draw >> 2) + g) * (unsigned)A.N + (unsigned)e) * 4u];
-                        }
-                    }
-                }
-            };
-            fail = sim_step<TURB, NoExtActuators, DevCfg, decltype(hook)>(c, c, E.y, sp, E.wind, gust, E.d, NoExtActuators(), hook);
-#ifndef FWG_EMU
-#pragma unroll
-            for (int g = 0; g < 10; ++g) asm volatile("" :: "v"(pf[g]));   // (keeps the hint loads from being dropped)
-#endif
         } else {
             fail = sim_step<TURB>(c, c, E.y, sp, E.wind, gust, E.d);
         }
@@ -362,9 +341,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // an episode that ends at steps_max is known here: everything its episode-end branch reads from memory is requested
         // now -- the prepared draw, the end-error record, the lagged rows of the terminal observation --, so that the round
         // trips run under the rest of this block and the partner's integration
-        // (k_step2) the partner looks at this word half-way through its integration and, for a foreseen end, starts pulling
-        // the prepared draw's cold lines into the cache, so that its tail work does not begin with their round trip
-        if (pre_install) acts[1] = u2f((valid && done && draw_stage_of(E.flags) == FWG_DRAW_READY) ? 0x5EEDu : 0u);
         if (c.auto_reset && c.steps_max > 0 && __ballot(valid && done) != 0ull) {
             if (valid && done) {
                 pre_end = true;
@@ -911,7 +887,7 @@ struct LaneColumn {
     __device__ __forceinline__ float operator[](int i) const { return base[i * stride]; }
 };
 // the next episode's parameter set of ONE env (tab: this thread's column of the LDS table [FWG_N_PARAMS][stride])
-__device__ __forceinline__ void model_draw_env(const DevCfg& c, const DynCfg* dp, const KArgs& A, long e, float* P, int stride) {
+__device__ __forceinline__ void model_draw_env(const DevCfg& c, const DynCfg* dp, const KArgs& A, long e, float* P, int stride, bool model_part = true) {
     const ModelCfg& m = dp->model;
     const unsigned episode_new = f2u(CGROUP(A.S, A.N, (c.L.cold >> 2), e).w) + 1u;
     const unsigned env_id = (unsigned)(A.env_base + e);
@@ -933,7 +909,7 @@ __device__ __forceinline__ void model_draw_env(const DevCfg& c, const DynCfg* dp
             GROUP(A.S, A.N, (c.L.fscale_next >> 2) + FWG_MAX_FACTORS / 4, e) = make_float4(u2f(episode_new), u2f(dp->generation), 0.f, 0.f);
         }
     }
-    if (c.model_n <= 0) return;
+    if (c.model_n <= 0 || !model_part) return;
     const float4 tag = CGROUP(A.S, A.N, (c.L.aero_next >> 2) + FWG_AERO_GROUPS - 1, e);
     if (f2u(tag.y) == episode_new && f2u(tag.z) == dp->generation) return;
     for (int i = 0; i < FWG_N_PARAMS; ++i) P[i * stride] = m.nominal[i];
@@ -973,17 +949,66 @@ __global__ __launch_bounds__(FWG_WAVE) void k_model_draw(const DevCfg* __restric
     if (e >= A.N) return;
     model_draw_env(*cp, dp, A, e, lds + threadIdx.x, FWG_WAVE);
 }
-// the envs that were reset by the previous launch: ONE workgroup works off their queue (count | env indices) and empties it
-// -- a step of a long run resets a few dozen envs, so this replaces a full-grid launch whose lanes almost all leave after
-// two loads (measured 5-8 us per step) by a launch of four waves
-#define FWG_MQ_THREADS 256
-__global__ __launch_bounds__(FWG_MQ_THREADS) void k_model_draw_q(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A,
-                                                                 unsigned* __restrict__ q) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [FWG_N_PARAMS][FWG_MQ_THREADS]
+// the envs that were reset by the previous launch: a few workgroups work off their queue (count | env indices), ONE WAVE per
+// env -- the listed parameters are sampled by as many lanes side by side (a lane per parameter: one Philox block each), the 49
+// constants derived by one lane from the wave's LDS table, the 13 groups stored by 13 lanes -- so that a step of a long run
+// (a few dozen resets) pays ~350 dependent instructions instead of the ~2 500 of a lane that does it all by itself, and
+// neither pays the full-grid launch whose 65 536 lanes almost all leave after two loads (5-8 us per step).  The queue it
+// consumed is emptied by the NEXT launch's instance (which consumes the other one): no grid-wide hand-shake needed.
+#define FWG_MQ_WAVES 4
+#define FWG_MQ_BLOCKS 32
+__global__ __launch_bounds__(64 * FWG_MQ_WAVES) void k_model_draw_q(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A,
+                                                                     const unsigned* __restrict__ q, unsigned* __restrict__ q_other) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [FWG_MQ_WAVES][FWG_N_PARAMS + 4 FWG_AERO_GROUPS]
+    const DevCfg& c = *cp;
+    const ModelCfg& m = dp->model;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) q_other[0] = 0u;   // the queue this launch's step kernel appends to
+    float* P = lds + wv * (FWG_N_PARAMS + 4 * FWG_AERO_GROUPS);
+    float* V = P + FWG_N_PARAMS;
     const unsigned n = q[0];
-    for (unsigned i = threadIdx.x; i < n; i += FWG_MQ_THREADS) model_draw_env(*cp, dp, A, (long)q[1u + i], lds + threadIdx.x, FWG_MQ_THREADS);
-    __syncthreads();
-    if (threadIdx.x == 0) q[0] = 0u;
+    for (unsigned i = blockIdx.x * FWG_MQ_WAVES + wv; i < n; i += FWG_MQ_BLOCKS * FWG_MQ_WAVES) {
+        const long e = (long)q[1u + i];
+        if (c.randomize_scaling && lane == 0) model_draw_env(c, dp, A, e, P, 1, false);   // (a handful of draws, one lane)
+        if (c.model_n <= 0) continue;
+        const unsigned episode_new = f2u(CGROUP(A.S, A.N, (c.L.cold >> 2), e).w) + 1u;
+        const unsigned env_id = (unsigned)(A.env_base + e);
+        const float4 tag = CGROUP(A.S, A.N, (c.L.aero_next >> 2) + FWG_AERO_GROUPS - 1, e);
+        if (f2u(tag.y) == episode_new && f2u(tag.z) == dp->generation) continue;   // (wave-uniform)
+        FWG_WAVE_SYNC();
+        if (lane < FWG_N_PARAMS) P[lane] = m.nominal[lane];
+        FWG_WAVE_SYNC();
+        if (lane < m.n) {
+            const u4 b = philox4x32(env_id, episode_new, (unsigned)lane, FWG_STREAM_MODEL, A.seed_lo, A.seed_hi);
+            const float nominal = m.nominal[m.idx[lane]];
+            float x;
+            if (m.dist == 0) {
+                const float z = sqrtf(-2.f * logf(u01(b.x))) * cosf(6.2831853071795865f * u01(b.y));
+                x = fminf(fmaxf(nominal + m.var[lane] * z, m.lo[lane]), m.hi[lane]);
+            } else {
+                x = (nominal - m.var[lane]) + 2.f * m.var[lane] * u01(b.x);
+            }
+            P[m.idx[lane]] = x;
+        }
+        FWG_WAVE_SYNC();
+        if (4 * lane < m.n) {   // the sampled values themselves, in list order (get_simulator_parameters)
+            float r[4];
+            for (int k = 0; k < 4; ++k) r[k] = 4 * lane + k < m.n ? P[m.idx[4 * lane + k]] : 0.f;
+            GROUP(A.S, A.N, (c.L.model_raw_next >> 2) + lane, e) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+        if (lane == 0) {
+            Aero a;
+            derive_aero<float>(LaneColumn{P, 1}, m.rho, m.g, a);
+            int k = 0;
+#define FWG_AERO_PUT(nm) V[k++] = a.nm;
+            FWG_AERO_LIST(FWG_AERO_PUT)
+#undef FWG_AERO_PUT
+            V[FWG_N_AERO] = u2f(episode_new); V[FWG_N_AERO + 1] = u2f(dp->generation); V[FWG_N_AERO + 2] = 0.f;
+        }
+        FWG_WAVE_SYNC();
+        if (lane < FWG_AERO_GROUPS)
+            GROUP(A.S, A.N, (c.L.aero_next >> 2) + lane, e) = make_float4(V[4 * lane], V[4 * lane + 1], V[4 * lane + 2], V[4 * lane + 3]);
+    }
 }
 
 __global__ void k_check_nan(const float* __restrict__ a, long n, int* flag) {
@@ -1447,10 +1472,13 @@ static void launch_model_draw(fwg_handle* h, const KArgs& A, hipStream_t stream,
     if (h->h.model_n <= 0 && !h->h.randomize_scaling) return;
     if (all || h->model_all_stale) {
         hipLaunchKernelGGL(k_model_draw, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), FWG_N_PARAMS * FWG_WAVE * sizeof(float), stream, h->d_cfg, h->d_dyn, A);
+        // (the queues hold nothing this draw has not covered; the one the coming kernel appends to starts empty)
+        (void)hipMemsetAsync(h->d_mq, 0, sizeof(unsigned), stream);
+        (void)hipMemsetAsync(h->d_mq + (size_t)(1 + h->n_envs), 0, sizeof(unsigned), stream);
         h->model_all_stale = 0;
     } else {   // the envs reset by the previous launch (queue of the other parity)
-        hipLaunchKernelGGL(k_model_draw_q, dim3(1), dim3(FWG_MQ_THREADS), FWG_N_PARAMS * FWG_MQ_THREADS * sizeof(float), stream, h->d_cfg, h->d_dyn, A,
-                           h->d_mq + (size_t)((h->gstep - 1) & 1) * (size_t)(1 + h->n_envs));
+        hipLaunchKernelGGL(k_model_draw_q, dim3(FWG_MQ_BLOCKS), dim3(64 * FWG_MQ_WAVES), FWG_MQ_WAVES * (FWG_N_PARAMS + 4 * FWG_AERO_GROUPS) * sizeof(float), stream, h->d_cfg, h->d_dyn, A,
+                           h->d_mq + (size_t)((h->gstep - 1) & 1) * (size_t)(1 + h->n_envs), h->d_mq + (size_t)(h->gstep & 1) * (size_t)(1 + h->n_envs));
     }
 }
 
