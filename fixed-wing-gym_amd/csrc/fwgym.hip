@@ -881,10 +881,15 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
 // the force / moment constants derived from the table by the formulas of lower_config -- into L.aero_next, tagged with
 // the episode it is for and the configuration generation.  Launched before every kernel that may reset an env (fwg_step,
 // fwg_reset); lanes whose set is current leave at once.  Rare path: loops, the table in a lane-private LDS column.
+// (the inertia entries read from the nominal table: PyFly builds its inertia matrix and the gammas once, from the parameter
+// file -- the reference's write of a sampled Jx into simulator.params is reported by get_simulator_parameters and moves nothing)
 struct LaneColumn {
     const float* base;
     int stride;
-    __device__ __forceinline__ float operator[](int i) const { return base[i * stride]; }
+    const float* nominal;
+    __device__ __forceinline__ float operator[](int i) const {
+        return (i == FWG_P_JX || i == FWG_P_JY || i == FWG_P_JZ || i == FWG_P_JXZ) ? nominal[i] : base[i * stride];
+    }
 };
 // the next episode's parameter set of ONE env (tab: this thread's column of the LDS table [FWG_N_PARAMS][stride])
 __device__ __forceinline__ void model_draw_env(const DevCfg& c, const DynCfg* dp, const KArgs& A, long e, float* P, int stride, bool model_part = true) {
@@ -931,7 +936,7 @@ __device__ __forceinline__ void model_draw_env(const DevCfg& c, const DynCfg* dp
         GROUP(A.S, A.N, (c.L.model_raw_next >> 2) + g, e) = make_float4(r[0], r[1], r[2], r[3]);
     }
     Aero a;
-    derive_aero<float>(LaneColumn{P, stride}, m.rho, m.g, a);
+    derive_aero<float>(LaneColumn{P, stride, m.nominal}, m.rho, m.g, a);
     float v[4 * FWG_AERO_GROUPS];
     int k = 0;
 #define FWG_AERO_PUT(n) v[k++] = a.n;
@@ -998,7 +1003,7 @@ __global__ __launch_bounds__(64 * FWG_MQ_WAVES) void k_model_draw_q(const DevCfg
         }
         if (lane == 0) {
             Aero a;
-            derive_aero<float>(LaneColumn{P, 1}, m.rho, m.g, a);
+            derive_aero<float>(LaneColumn{P, 1, m.nominal}, m.rho, m.g, a);
             int k = 0;
 #define FWG_AERO_PUT(nm) V[k++] = a.nm;
             FWG_AERO_LIST(FWG_AERO_PUT)

@@ -43,10 +43,14 @@ AERO_KEYS = ["mass", "Jx", "Jy", "Jz", "Jxz", "S_wing", "b", "c", "S_prop", "C_p
 class SimSpec:
     """Constants of one simulator instance (float64)."""
 
-    def __init__(self, sim_cfg, params, dryden_span=None):
+    def __init__(self, sim_cfg, params, dryden_span=None, inertia=None):
         # dryden_span: wingspan the turbulence filters are built with (the parameter FILE's value when simulator.model
         # re-samples the table: the filters are set up once, csrc lower_config / config.dryden_matrices)
+        # inertia: (Jx, Jy, Jz, Jxz) the inertia matrix and its gammas are built with -- PyFly 0.1.2 builds self.I and
+        # self.gammas once in __init__ from the parameter FILE, so a later write of Jx.. into simulator.params
+        # (fixed_wing.py:532-559) changes what get_simulator_parameters returns but not the rotational dynamics
         self.dryden_span = None if dryden_span is None else float(dryden_span)
+        self.inertia = None if inertia is None else tuple(float(x) for x in inertia)
         self.dt = float(sim_cfg["dt"])
         self.rho = float(sim_cfg["rho"])
         self.g = float(sim_cfg["g"])
@@ -96,9 +100,12 @@ class SimSpec:
         self._dryden = None
 
     # -- derived constants ------------------------------------------------------------------------------------------
-    def gammas(self):
+    def inertia_values(self):
         p = self.params
-        Jx, Jy, Jz, Jxz = p["Jx"], p["Jy"], p["Jz"], p["Jxz"]
+        return self.inertia if self.inertia is not None else (p["Jx"], p["Jy"], p["Jz"], p["Jxz"])
+
+    def gammas(self):
+        Jx, Jy, Jz, Jxz = self.inertia_values()
         G = Jx * Jz - Jxz ** 2
         return (Jxz * (Jx - Jy + Jz) / G, (Jz * (Jz - Jy) + Jxz ** 2) / G, Jz / G, Jxz / G, (Jz - Jx) / Jy, Jxz / Jy,
                 ((Jx - Jy) * Jx + Jxz ** 2) / G, Jx / G)
@@ -300,7 +307,7 @@ def rhs(spec, yb, act, wind_ned, gust, fail):
     dy[:, 3] = 0.5 * (r * e0 + q * e1 - p * e2)
     G1, G2, G3, G4, G5, G6, G7, G8 = spec.gammas()
     dy[:, 4] = G1 * p * q - G2 * q * r + G3 * l_ + G4 * n_
-    dy[:, 5] = G5 * p * r - G6 * (p * p - r * r) + m_ / P["Jy"]
+    dy[:, 5] = G5 * p * r - G6 * (p * p - r * r) + m_ / spec.inertia_values()[1]
     dy[:, 6] = G7 * p * q - G1 * q * r + G4 * l_ + G8 * n_
     r00, r01, r02, r10, r11, r12, r20, r21, r22 = rot_body_to_ned(q4)
     dy[:, 7] = r00 * u + r01 * v + r02 * w

@@ -69,6 +69,7 @@ class PyFly:
         with open(parameter_path) as f:
             self.params = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
         self._file_span = self.params["b"]
+        self._file_inertia = tuple(self.params[k] for k in ("Jx", "Jy", "Jz", "Jxz"))   # self.I / self.gammas: built once
         self.dt = self.cfg["dt"]
         self.rho = self.cfg["rho"]
         self.g = self.cfg["g"]
@@ -105,7 +106,7 @@ class PyFly:
         cfg = dict(self.cfg)
         cfg["turbulence"] = bool(self.turbulence)
         cfg["turbulence_intensity"] = self.turbulence_intensity
-        spec = ph.SimSpec(cfg, self.params, dryden_span=self._file_span)
+        spec = ph.SimSpec(cfg, self.params, dryden_span=self._file_span, inertia=self._file_inertia)
         # the gym layer mutates Variable attributes (curriculum, fixed_wing.py:245): they are authoritative
         for name, var in self.state.items():
             i = ph.VAR_ID[name]

@@ -184,8 +184,9 @@ AERO_NAMES = ("half_rho_S mg inv_mass inv_Jy G1 G2 G3 G4 G5 G6 G7 G8 M Ma0 CL0 C
               "Cm0 Cma cmq Cmde Cmfp chord span CY0 CYb cYp cYr CYda Cl0 Clb clp clr Clda Cn0 Cnb cnp cnr Cnda kprop kmotor ktp").split()
 
 
-def aero_from_params(P, rho, g):
-    Jx, Jy, Jz, Jxz = P["Jx"], P["Jy"], P["Jz"], P["Jxz"]
+def aero_from_params(P, rho, g, inertia=None):
+    # inertia: the parameter FILE's (Jx, Jy, Jz, Jxz) -- PyFly's inertia matrix and gammas are built once (oracle/physics.py SimSpec)
+    Jx, Jy, Jz, Jxz = inertia if inertia is not None else (P["Jx"], P["Jy"], P["Jz"], P["Jxz"])
     G = Jx * Jz - Jxz * Jxz
     b, c = P["b"], P["c"]
     v = {"half_rho_S": 0.5 * rho * P["S_wing"], "mg": P["mass"] * g, "inv_mass": 1 / P["mass"], "inv_Jy": 1 / Jy,
@@ -237,7 +238,7 @@ def check_model_randomisation(vec, oracles, steps, action_fn):
         o.reset()
     rho, g = oracles[0].simulator.rho, oracles[0].simulator.g
     first = device_aero(vec)
-    want = np.stack([aero_from_params(o.simulator.params, rho, g) for o in oracles])
+    want = np.stack([aero_from_params(o.simulator.params, rho, g, o.simulator._file_inertia) for o in oracles])
     close(first, want, 1e-5, 1e-7, "per-env constants after reset")
     check_parameter_api(vec, oracles, "after reset")
     assert np.abs(first[0] - first[1]).max() > 0, "two envs drew the same aircraft"
@@ -253,7 +254,7 @@ def check_model_randomisation(vec, oracles, steps, action_fn):
                 o.reset()
         if done.any():
             now = device_aero(vec)
-            want = np.stack([aero_from_params(o.simulator.params, rho, g) for o in oracles])
+            want = np.stack([aero_from_params(o.simulator.params, rho, g, o.simulator._file_inertia) for o in oracles])
             close(now, want, 1e-5, 1e-7, "per-env constants after the auto-reset at step {}".format(t))
             check_parameter_api(vec, oracles, "after the auto-reset at step {}".format(t))
             changed += int((np.abs(now - first).max(axis=1) > 0)[done].sum())
