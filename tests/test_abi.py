@@ -57,7 +57,11 @@ def test_missing_library_fails_loudly(tmp_path):
 def test_unsupported_configurations_raise():
     from gym_fixed_wing import presets
     cfg = presets.default()
-    cfg["integration_window"] = 10
+    cfg["integration_window"] = 10   # (built since round 3: lowers -- to 0 while nothing reads the windowed sums)
+    assert EnvConfig(cfg).compile().integration_window == 0
+    cfg["observation"]["states"].append({"type": "target", "name": "roll", "value": "integrator"})
+    assert EnvConfig(cfg).compile().integration_window == 10
+    cfg["integration_window"] = 50
     with pytest.raises(NotImplementedError):
         EnvConfig(cfg)
     cfg = presets.default()

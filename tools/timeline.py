@@ -113,6 +113,23 @@ def run():
                                                         "max": float(life_b[m].max())}
                 print("   {:34s} blocks {:4d}  lifetime median {:.0f}  p90 {:.0f}  max {:.0f}".format(name, int(m.sum()), np.median(life_b[m]),
                                                                                                        np.percentile(life_b[m], 90), life_b[m].max()))
+        # dispatch ramp: the counter is per XCD (block b runs on XCD b % 8), so starts and ends are compared within an XCD only
+        Tl = T[-1]
+        st_b, en_b = np.nanmin(Tl[:, :, 0], axis=1), np.nanmax(Tl, axis=(1, 2))
+        ramp, span, last_is = [], [], []
+        for x in range(8):
+            idx = np.arange(x, Tl.shape[0], 8)
+            z = np.nanmin(st_b[idx])
+            ramp.append(np.nanmax(st_b[idx]) - z)
+            span.append(np.nanmax(en_b[idx]) - z)
+            j = idx[int(np.nanargmax(en_b[idx]))]
+            last_is.append((int(j), float(st_b[j] - z), float(life_b[j]), bool(done_b[j])))
+        res[key]["xcd_start_ramp_ticks"] = [float(r) for r in ramp]
+        res[key]["xcd_span_ticks"] = [float(r) for r in span]
+        print("   per XCD: first-to-last block start {}  | first start to last end {}".format(
+            " ".join("{:.0f}".format(r) for r in ramp), " ".join("{:.0f}".format(r) for r in span)))
+        print("   last block to finish per XCD (block, started at, lifetime, hosted an end): " +
+              "  ".join("{}:{:.0f}+{:.0f}{}".format(j, a, l, "E" if d else "") for j, a, l, d in last_is))
         for worst in [int(order[0]), int(order[8]), int(order[40]), int(order[200])]:
             print("   block {} of the last launch (lifetime {:.0f}, done lanes in the wave: {}{}):".format(
                 worst, np.nanmax(last[worst]), int(vec._done[worst * 64:(worst + 1) * 64].sum().item()),
