@@ -435,9 +435,18 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         FWG_DMA_DRAIN();   // this wave's own streamed windows have landed (no other wave reads them)
         FWG_WAVE_SYNC();
         gym_prework();
-        // (a foreseen end whose new window the partner writes after the barrier: the terminal observation's lagged rows,
-        // requested above from the planes it will overwrite, must have landed)
-        if (pre_install && __ballot(pre_rows) != 0ull) FWG_DMA_DRAIN();
+        // a foreseen end's operands, requested above, are pinned in registers here (see FWG_TOUCH: the episode-end branch then
+        // runs without a wait); the terminal observation's lagged rows MUST have landed before the barrier -- the partner
+        // writes the new window over their planes after it.  (Not a drain: that would sit through the acknowledgement of
+        // the stores issued since, e.g. a neighbour lane's draw piece)
+        if (__ballot(pre_end) != 0ull) {
+            touch4(pre_tag); touch4(pre_old); touch_draw(c, RD);
+            if (c.obs_log > 0) {
+#pragma unroll
+                for (int i = 0; i < FWG_MAX_OBS * FWG_MAX_ROWS; ++i)
+                    if (i >= c.n_obs && i < c.obs_dim) { const float v = ob.get(i); FWG_TOUCH(v); }
+            }
+        }
         FWG_TL(A, 2);
     }
     if (SPLIT) FWG_BLOCK_SYNC_LDS();     // barrier A
@@ -453,14 +462,20 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     if (SPLIT && PHYS && (tail_rows || pre_install)) {
         const float4 w = *reinterpret_cast<const float4*>(acts);
         steps_p = f2u(w.x);
-        early_p = tail_rows && valid && fail == 0 && steps_p != 0u;
         end_p = pre_install && valid && f2u(w.y) != 0u;
+        early_p = tail_rows && valid && fail == 0 && steps_p != 0u && !end_p;   // (an ending lane's rows are the partner's)
         if (__ballot(early_p) != 0ull) {
             if (early_p) early_rows_request(c, A, e, rec0_p);
         }
         if (__ballot(end_p) != 0ull) {
             if (end_p) draw_load_final(c, A.S, A.N, e, RDp);   // (just read by the partner: served from the cache)
         }
+    }
+    // hand-shake B, first mark: this wave's hand-off areas are read (LDS executes a wave's accesses in order), the partner may
+    // re-use them as the output staging area
+    if (SPLIT && PHYS) {
+        FWG_EMU_WAVE_SYNC();
+        if (lane == 0) FWG_FLAG_RAISE(hand + FWG_HAND_WORDS - 1, 1);   // (asm with a memory clobber: the reads above stay above)
     }
     if (SPLIT && GYM) {
         const float4* h4 = reinterpret_cast<const float4*>(hand);
@@ -479,9 +494,25 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             dryden_advance(c, E.dry, n);
             if (c.turb_increment) dryden_next_gust(c, x_old, E.dry, E.gust);
         }
-        if (SPLIT && pre_install && __ballot(end_p) != 0ull) {
-            // foreseen episode end: the NEXT episode goes into the simulator / cold rows and the row log (the old episode's final
-            // state went to the partner through LDS above)
+#ifndef FWG_ABL_NO_SIMSTORE
+        // (foreseen episode end: the old episode's final state went to the partner through LDS; the NEXT episode's rows follow below)
+        if (valid && !end_p) store_sim<TURB>(c, A.S, A.N, e, E);
+#endif
+        FWG_TL(A, 3);
+        if (SPLIT && tail_rows && __ballot(early_p) != 0ull) {
+            if (early_p) {   // (fail == 0: a failed step's rows are the gym wave's)
+                float rn[FWG_MAX_ROWS];
+                early_row_noise(c, A, e, steps_p, E.episode, rn);
+                const float actuator[3] = {0.5f * (E.y[13] + E.y[14]), 0.5f * (E.y[14] - E.y[13]), E.y[15]};
+                early_rows_to_log(c, A, e, steps_p, rec0_p, rn, actuator, A.log_win);
+            }
+        }
+    }
+    if (SPLIT && PHYS) {
+        // foreseen episode end: the NEXT episode goes into the simulator / cold rows and the row log (the old episode's final
+        // state went to the partner through LDS; its terminal observation was requested before barrier A; the lanes are
+        // disjoint from the ones the partner re-initialises itself)
+        if (pre_install && __ballot(end_p) != 0ull) {
             if (end_p) {   // (the partner checked the draw's tag)
                 reset_rows_to_log(c, A, e, RDp, aring, A.slot_lag, A.log_win);
 #pragma unroll
@@ -495,24 +526,15 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 for (int i = 0; i < 6; ++i) E.gust[i] = 0.f;
                 E.gust_gain = RDp.gust_gain;
                 store_cold(c, A.S, A.N, e, E);
+                store_sim<TURB>(c, A.S, A.N, e, E);
             }
         }
-#ifndef FWG_ABL_NO_SIMSTORE
-        if (valid) store_sim<TURB>(c, A.S, A.N, e, E);
-#endif
-        FWG_TL(A, 3);
-        if (SPLIT && tail_rows && __ballot(early_p) != 0ull) {
-            if (early_p) {   // (fail == 0: a failed step's rows are the gym wave's)
-                float rn[FWG_MAX_ROWS];
-                early_row_noise(c, A, e, steps_p, E.episode, rn);
-                const float actuator[3] = {0.5f * (E.y[13] + E.y[14]), 0.5f * (E.y[14] - E.y[13]), E.y[15]};
-                early_rows_to_log(c, A, e, steps_p, rec0_p, rn, actuator, A.log_win);
-            }
-        }
-    }
-    if (SPLIT && PHYS) {   // barrier B: the simulator rows are written before the gym wave may overwrite them (auto-reset)
+        // hand-shake B, second mark, one way: everything above is in memory.  The gym wave waits for it only in a wave that
+        // re-initialises an env itself (an episode that ended unforeseen: it overwrites this launch's simulator rows, and an
+        // early lane's padding rows); this wave waits for nobody
         FWG_DMA_DRAIN();   // s_waitcnt vmcnt(0): covers stores as well
-        FWG_BLOCK_SYNC_LDS();
+        FWG_WAVE_SYNC();
+        if (lane == 0) FWG_FLAG_RAISE(hand + FWG_HAND_WORDS - 1, 2);
         return;
     }
     // everything streamed HBM -> LDS at kernel start is needed from here on; the integration above hid its latency
@@ -712,7 +734,13 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // waves in which no episode ends have their final observation records here: the moments for an attached rollout head
     // go out before the remaining stores, whose issue then hides the round trip of the atomics
     if (A.acc != nullptr && done_mask == 0ull) step_moments(c, A, ob, reward, done, valid, lane, e);
-    if (SPLIT) FWG_BLOCK_SYNC_LDS();   // barrier B (the physics wave arrived long ago: its rows are in memory)
+    // hand-shake B: the output staging area aliases the hand-off areas (first mark, raised right after barrier A), and an env
+    // that is re-initialised HERE has rows the physics wave wrote in this launch (second mark: they are in memory).  A
+    // foreseen end whose new episode the partner installs needs neither acknowledgement
+    if (SPLIT) {
+        const bool overwrites = __ballot(done && valid && !pre_rows) != 0ull;
+        if (overwrites || c.obs_log == 0 || done_mask != 0ull) FWG_FLAG_WAIT(lds + M.stage + FWG_HAND_WORDS - 1, overwrites ? 2 : 1);
+    }
     if (done_mask != 0ull) {
         if (done && valid) {
             if (c.metrics) {
@@ -729,13 +757,14 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 }
                 R.settle[0] = E.settle[0]; R.settle[1] = E.settle[1]; R.gcnt[0] = E.gcnt[0]; R.gcnt[1] = E.gcnt[1]; R.sdcmd = E.sdcmd;
                 if (R.n_rec > (unsigned)FWG_END_WINDOW) {
-                    float4 r = pre_old;   // requested before the integration for foreseen ends
-                    if (!(pre_end && ok)) {
+                    if (pre_end && ok) {   // requested before the integration (two separate paths: no wait on this one)
+                        R.end_sum[0] -= pre_old.x; R.end_sum[1] -= pre_old.y; R.end_sum[2] -= pre_old.z;
+                    } else {
                         int slot = ok ? A.slot_end + 1 : A.slot_end;
                         slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
-                        r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                        const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                        R.end_sum[0] -= r.x; R.end_sum[1] -= r.y; R.end_sum[2] -= r.z;
                     }
-                    R.end_sum[0] -= r.x; R.end_sum[1] -= r.y; R.end_sum[2] -= r.z;
                 }
                 if (E.flags & FWG_FLAG_FIN_PENDING) fin_collect_pending(c, A, e);   // (rare) never collected: fold it now
                 fin_store(c, A.S, A.N, e, R);
@@ -762,13 +791,20 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         FWG_TL(A, 13);
         if (c.auto_reset && done && valid) {
             bool ready = draw_stage_of(E.flags) == FWG_DRAW_READY;
-            if (ready) {   // prepared in the steps after the previous reset; valid for this configuration generation / episode?
-                const float4 tag = pre_draw ? pre_tag : draw_tag(A.S, A.N, e, c);
+            // prepared in the steps after the previous reset; valid for this configuration generation / episode?  Two separate
+            // paths: one that merges prefetched words with words loaded here makes the foreseen end wait (vmcnt(0)) at the merge
+            if (ready && pre_draw) {
+                ready = f2u(pre_tag.x) == dc.generation && f2u(pre_tag.y) == E.episode + 1u;
+                RD.flags = f2u(pre_tag.z);
+            } else if (ready) {
+                const float4 tag = draw_tag(A.S, A.N, e, c);
                 ready = f2u(tag.x) == dc.generation && f2u(tag.y) == E.episode + 1u;
-                RD.flags = f2u(tag.z); RD.episode = E.episode + 1u;
+                RD.flags = f2u(tag.z);
+                FWG_TOUCH(tag.z);
+                if (ready) { draw_load_final(c, A.S, A.N, e, RD); touch_draw(c, RD); }
             }
-            if (ready) { if (!pre_draw) draw_load_final(c, A.S, A.N, e, RD); }
-            else reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);   // episode ended before its successor's draw was complete
+            RD.episode = E.episode + 1u;
+            if (!ready) reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);   // episode ended before its successor's draw was complete
             reset_finish<TURB>(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_end, A.slot_lag, A.bit_goal, RD, true, pre_rows);
             if (!pre_rows) store_sim<TURB>(c, A.S, A.N, e, E);   // (pre_rows: the partner wrote the new simulator rows)
             store_gym(c, A.S, A.N, e, E, A.bit_goal, true, true);

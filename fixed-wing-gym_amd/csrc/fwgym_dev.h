@@ -270,6 +270,27 @@ __device__ __forceinline__ void dma_group_once(const float4* src_lane_ptr, float
 #else
 #define FWG_BLOCK_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
+// one-way hand-shake through an LDS word (k_step2: the physics wave raises it to 1 when it has read its hand-off areas and to
+// 2 when its rows are in memory; the gym wave waits only where it is about to re-use the former or overwrite the latter --
+// an s_barrier would make the physics wave wait as well, and the gym wave wait for store acknowledgements it does not need)
+// (a volatile access through a generic pointer would be a FLAT instruction followed by s_waitcnt vmcnt(0) -- the wave would sit
+// through the acknowledgement of every store it has in flight; ds_read / ds_write on the LDS offset (the low half of the
+// generic address) touch the LDS queue only)
+#ifdef FWG_EMU
+#define FWG_FLAG_WAIT(p, level) do { while (*reinterpret_cast<volatile const unsigned*>(p) < (unsigned)(level)) emu_yield(); } while (0)
+#define FWG_FLAG_RAISE(p, level) do { *reinterpret_cast<volatile unsigned*>(p) = (unsigned)(level); } while (0)
+#else
+__device__ __forceinline__ unsigned fwg_lds_peek(const void* p) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+    return v;
+}
+#define FWG_FLAG_WAIT(p, level)                                                            \
+    do {                                                                                   \
+        while (fwg_lds_peek(p) < (unsigned)(level)) __builtin_amdgcn_s_sleep(1);           \
+    } while (0)
+#define FWG_FLAG_RAISE(p, level) asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(size_t)(p)), "v"((unsigned)(level)) : "memory")
+#endif
 // ordering of LDS traffic between the lanes of ONE wave (k_step2: the other wave of the workgroup is not involved)
 #ifdef FWG_EMU
 #define FWG_WAVE_SYNC() emu_wave_sync()
@@ -280,6 +301,12 @@ __device__ __forceinline__ void dma_group_once(const float4* src_lane_ptr, float
         __builtin_amdgcn_wave_barrier();                         \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
     } while (0)
+#endif
+// (the lanes of a wave run in lock step on the device; the emulation's lane fibers need the rendezvous spelled out)
+#ifdef FWG_EMU
+#define FWG_EMU_WAVE_SYNC() emu_wave_sync()
+#else
+#define FWG_EMU_WAVE_SYNC() do {} while (0)
 #endif
 __device__ __forceinline__ void dma_wait() {
     FWG_DMA_DRAIN();

@@ -1263,6 +1263,31 @@ __device__ __forceinline__ void draw_load_final(const DevCfg& c, const float* __
         D.tprop[k][0] = t.x; D.tprop[k][1] = t.y; D.tprop[k][2] = t.z; D.tprop[k][3] = t.w;
     }
 }
+// Values requested long before their use (a foreseen episode end's prefetches) are "touched" where they have surely landed:
+// the compiler places its s_waitcnt at the touch, where nothing younger is in flight, instead of at the first use -- there,
+// after divergent code that issued a number of stores it cannot count, it falls back to vmcnt(0) and the wave sits through
+// the acknowledgement of every store it has just issued (2-3k ticks on the episode-end path, tools/timeline.py)
+#ifdef FWG_EMU
+#define FWG_TOUCH(x) ((void)(x))
+#else
+#define FWG_TOUCH(x) asm volatile("" ::"v"(x))
+#endif
+__device__ __forceinline__ void touch4(const float4& q) { FWG_TOUCH(q.x); FWG_TOUCH(q.y); FWG_TOUCH(q.z); FWG_TOUCH(q.w); }
+__device__ __forceinline__ void touch_draw(const DevCfg& c, const ResetDraw& D) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) FWG_TOUCH(D.y[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) FWG_TOUCH(D.wind[i]);
+    FWG_TOUCH(D.d.roll); FWG_TOUCH(D.d.pitch); FWG_TOUCH(D.d.yaw); FWG_TOUCH(D.d.Va); FWG_TOUCH(D.d.alpha); FWG_TOUCH(D.d.beta);
+    FWG_TOUCH(D.gust_gain);
+#pragma unroll
+    for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
+        FWG_TOUCH(D.tgt[k]);
+        if (c.any_dynamic_target) { FWG_TOUCH(D.tprop[k][0]); FWG_TOUCH(D.tprop[k][1]); FWG_TOUCH(D.tprop[k][2]); FWG_TOUCH(D.tprop[k][3]); }
+    }
+#pragma unroll
+    for (int r = 0; r < FWG_MAX_ROWS; ++r) FWG_TOUCH(D.row_noise[r]);
+}
 // generation | episode the draw is for | flags after sample_targets
 __device__ __forceinline__ float4 draw_tag(const float* __restrict__ S, long N, long e, const DevCfg& c) { return CGROUP(S, N, (c.L.draw >> 2) + 10, e); }
 // one piece of the next episode's draw (called for lanes whose stage is below FWG_DRAW_READY); returns the new stage.

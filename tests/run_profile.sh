@@ -17,7 +17,9 @@ $T rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS
 $T rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS --output-format csv -d $OUT/pmc2 -o pmc -- python3 $B > $OUT/bench_pmc2.log 2>&1
 $T rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -o pmc -- python3 $B > $OUT/bench_pmc3.log 2>&1
 $T rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -o pmc -- python3 $B > $OUT/bench_pmc4.log 2>&1
+# instruction cache: the episode-end path is cold code (steady state: --stagger)
+timeout 280 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH --output-format csv -d $OUT/pmc5 -o pmc -- python3 $B --stagger 2000 > $OUT/bench_pmc5.log 2>&1
 python3 $GRAFT_REPO_ROOT/tests/summarize_prof.py $OUT > /dev/null
 # keep only the summary (the raw traces are large)
-rm -rf $OUT/trace $OUT/trace_steady $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
+rm -rf $OUT/trace $OUT/trace_steady $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 $OUT/pmc5
 ls -la $OUT

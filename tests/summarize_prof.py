@@ -27,7 +27,7 @@ for tdir in ("trace", "trace_steady"):
             gaps = [(w[i + 1][0] - w[i][1]) / 1e3 for i in range(len(w) - 1)]
             lines.append("{:<62s} n={} mean {:.2f} us  median {:.2f}  min {:.2f}  p90 {:.2f}  max {:.2f} | mean gap to the next launch {:.2f} us".format(
                 kn, len(w), sum(dur) / len(dur), dur[len(dur) // 2], dur[0], dur[int(0.9 * len(dur))], dur[-1], sum(gaps) / max(len(gaps), 1)))
-for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
+for d in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5"):
     for f in sorted(glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True)):
         acc = collections.defaultdict(lambda: [0.0, 0])
         with open(f) as fh:
