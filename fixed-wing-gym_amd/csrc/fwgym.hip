@@ -135,7 +135,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #ifdef FWG_ABL_EMPTY  // FWG_ABL_*: measurement-only switches (tools/ablate.py), never defined in the product build
     return;
 #endif
-    const DynCfg& dc = *dp;
+    DynCfgK& dc = *(DynCfgK*)dp;
     FWG_TL(A, 0);
     const int lane = threadIdx.x & (FWG_WAVE - 1);
     const long env0 = (long)blockIdx.x * FWG_WAVE;
@@ -691,6 +691,33 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     }
 
     FWG_TL(A, 5);
+    // An episode end that was NOT foreseen (failure, success; or a foreseen one whose last step failed) is known here: what its
+    // end branch reads from memory is requested and waited for NOW, before the bookkeeping stores go out -- vmcnt counts in
+    // issue order, so a load issued after them would sit through the acknowledgement of every one of them (2-3k ticks)
+    // where this wait costs one round trip.  The same registers as the foreseen end's prefetches: one end branch for both
+    const bool late_end = done && valid && !(pre_end && ok);
+    const bool reload = c.obs_log > 0 && (done || !ok) && valid && !pre_end;   // (overwrites what early_rows_pre prepared)
+    if (__ballot(late_end || reload) != 0ull) {
+        if (late_end || reload) {
+            if (c.metrics && late_end) {
+                int slot = ok ? A.slot_end + 1 : A.slot_end;
+                slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
+                pre_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+            }
+            if (c.auto_reset && late_end && !pre_end && draw_stage_of(E.flags) == FWG_DRAW_READY) {
+                pre_draw = true;
+                pre_tag = draw_tag(A.S, A.N, e, c);
+                draw_load_final(c, A.S, A.N, e, RD);   // used only if the tag checks out
+            }
+            if (reload) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
+            touch4(pre_tag); touch4(pre_old); touch_draw(c, RD);
+            if (c.obs_log > 0) {
+#pragma unroll
+                for (int i = 0; i < FWG_MAX_OBS * FWG_MAX_ROWS; ++i)
+                    if (i >= c.n_obs && i < c.obs_dim) { const float v = ob.get(i); FWG_TOUCH(v); }
+            }
+        }
+    }
 #ifndef FWG_ABL_NO_GYMSTORE
     store_gym(c, A.S, A.N, e, E, A.bit_goal, valid, false);
 #endif
@@ -719,10 +746,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     const bool early = c.obs_length > 1 && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
     const unsigned log_pad_t = E.steps;   // rows with lag >= this are padding (valid for lanes that do not finish)
     const long long log_win = A.log_win;   // wave-uniform
-    const bool reload = c.obs_log > 0 && (done || !ok) && valid && !pre_end;   // (overwrites what early_rows_pre prepared)
-    if (__ballot(reload) != 0ull) {
-        if (reload) log_load_rows(c, A.obs, A.N, e, log_win, ob);
-    }
     // (tail_rows: the partner writes the padding rows of lanes that neither fail nor finish; the others build them here)
     if (c.obs_length > 1 && (!ok || (early && (!tail_rows || done)))) fix_lagged_rows(c, A, e, E, T, ob, ok, pre_early && !reload, early_noise);
     FWG_TL(A, 15);
@@ -757,14 +780,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 }
                 R.settle[0] = E.settle[0]; R.settle[1] = E.settle[1]; R.gcnt[0] = E.gcnt[0]; R.gcnt[1] = E.gcnt[1]; R.sdcmd = E.sdcmd;
                 if (R.n_rec > (unsigned)FWG_END_WINDOW) {
-                    if (pre_end && ok) {   // requested before the integration (two separate paths: no wait on this one)
-                        R.end_sum[0] -= pre_old.x; R.end_sum[1] -= pre_old.y; R.end_sum[2] -= pre_old.z;
-                    } else {
-                        int slot = ok ? A.slot_end + 1 : A.slot_end;
-                        slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
-                        const float4 r = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
-                        R.end_sum[0] -= r.x; R.end_sum[1] -= r.y; R.end_sum[2] -= r.z;
-                    }
+                    // (requested before the integration for a foreseen end, before the bookkeeping stores otherwise)
+                    R.end_sum[0] -= pre_old.x; R.end_sum[1] -= pre_old.y; R.end_sum[2] -= pre_old.z;
                 }
                 if (E.flags & FWG_FLAG_FIN_PENDING) fin_collect_pending(c, A, e);   // (rare) never collected: fold it now
                 fin_store(c, A.S, A.N, e, R);
@@ -791,17 +808,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         FWG_TL(A, 13);
         if (c.auto_reset && done && valid) {
             bool ready = draw_stage_of(E.flags) == FWG_DRAW_READY;
-            // prepared in the steps after the previous reset; valid for this configuration generation / episode?  Two separate
-            // paths: one that merges prefetched words with words loaded here makes the foreseen end wait (vmcnt(0)) at the merge
-            if (ready && pre_draw) {
-                ready = f2u(pre_tag.x) == dc.generation && f2u(pre_tag.y) == E.episode + 1u;
+            // prepared in the steps after the previous reset; valid for this configuration generation / episode?  (tag and draw
+            // are in registers either way: requested before the integration or before the bookkeeping stores)
+            if (ready) {
+                ready = pre_draw && f2u(pre_tag.x) == dc.generation && f2u(pre_tag.y) == E.episode + 1u;
                 RD.flags = f2u(pre_tag.z);
-            } else if (ready) {
-                const float4 tag = draw_tag(A.S, A.N, e, c);
-                ready = f2u(tag.x) == dc.generation && f2u(tag.y) == E.episode + 1u;
-                RD.flags = f2u(tag.z);
-                FWG_TOUCH(tag.z);
-                if (ready) { draw_load_final(c, A.S, A.N, e, RD); touch_draw(c, RD); }
             }
             RD.episode = E.episode + 1u;
             if (!ready) reset_sample(c, dc, A, e, E.episode, E.flags, T, RD);   // episode ended before its successor's draw was complete
@@ -859,7 +870,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
     typedef KernelTypes<SPEC> KT;
     const DevCfg& c = SpecCfg<SPEC>::get(cp);
     const KArgs A = resolve_slots(c, A0);
-    const DynCfg& dc = *dp;
+    DynCfgK& dc = *(DynCfgK*)dp;
     const int lane = threadIdx.x;
     const long env0 = (long)blockIdx.x * FWG_WAVE;
     const bool valid = env0 + lane < A.N;

@@ -47,6 +47,16 @@ struct DynCfg {
     int sk_n_int, sk_n_turb, sk_idx_int, sk_idx_turb;
     float sk_cum_int[4], sk_gain_int[4], sk_cum_turb[2], sk_on_turb[2], sk_base_gain;
 };
+// How the kernels see it: in the CONSTANT address space.  The run-time configuration does not change during a launch, but a
+// kernel that also stores to global memory cannot prove that: through a plain pointer every `dc.x` after the first store is
+// a vector-memory load with a round trip of its own (the reset draw read its ranges in 4-5 SERIAL round trips per piece);
+// through address space 4 they are scalar loads, batched and cached in the scalar cache
+#if defined(FWG_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+typedef const DynCfg DynCfgK;
+#else
+typedef const __attribute__((address_space(4))) DynCfg DynCfgK;
+#endif
+
 // The constants of the force / moment model, pre-combined from the parameter table (same names and order as the block at
 // the head of DevCfg).  One set for all envs (DevCfg) unless simulator.model re-samples the table per env and episode: then
 // every lane carries its own (arena section L.aero), derived on the device by the same formulas (derive_aero).

@@ -585,7 +585,7 @@ __device__ __forceinline__ void goal_push(const DevCfg& c, Env& E, unsigned g, i
 
 // sample_target (fixed_wing.py:461-521); `given` (nullable) holds explicit targets for reset(target=...)
 template <class TAB>
-__device__ __forceinline__ void sample_targets(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, Env& E,
+__device__ __forceinline__ void sample_targets(const DevCfg& c, DynCfgK& dc, const KArgs& A, long e, Env& E,
                                                const TAB& T, const float* given) {
     const unsigned env_id = (unsigned)(A.env_base + e);
     const unsigned resample = (E.flags & ~FWG_FLAG_LAST_FAILED) >> FWG_FLAG_RESAMPLE_SHIFT;
@@ -1099,7 +1099,7 @@ struct ResetDraw {
 // step, off the critical path (draw_stage_step below).  Identical arithmetic either way.
 // (1) sampled initial values of the variables [4 BLK0, 4 (BLK0 + NBLK)): given values or U(init_min, init_max)
 template <int BLK0, int NBLK>
-__device__ __forceinline__ void draw_state_values(const DynCfg& dc, const KArgs& A, long e, unsigned episode_new,
+__device__ __forceinline__ void draw_state_values(DynCfgK& dc, const KArgs& A, long e, unsigned episode_new,
                                                   float (&v0)[FWG_N_RESET_VARS + 3]) {
     const unsigned env_id = (unsigned)(A.env_base + e);
 #pragma unroll
@@ -1146,7 +1146,7 @@ __device__ __forceinline__ void draw_state(const DevCfg& c, const float (&v0)[FW
 }
 // (2b) the sampled targets for that state (D.y, D.wind, D.d set)
 template <class TAB>
-__device__ __forceinline__ void draw_targets(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_new, TAB& T, ResetDraw& D) {
+__device__ __forceinline__ void draw_targets(const DevCfg& c, DynCfgK& dc, const KArgs& A, long e, unsigned episode_new, TAB& T, ResetDraw& D) {
     Env R;   // scratch: only the fields sample_targets / fill_vars touch
     R.episode = episode_new;
     R.steps = 0u;
@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void draw_targets(const DevCfg& c, const DynCfg& dc, 
     D.flags = R.flags; D.episode = R.episode;
 }
 template <class TAB>
-__device__ __forceinline__ void draw_state_and_targets(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_new,
+__device__ __forceinline__ void draw_state_and_targets(const DevCfg& c, DynCfgK& dc, const KArgs& A, long e, unsigned episode_new,
                                                        const float (&v0)[FWG_N_RESET_VARS + 3], TAB& T, ResetDraw& D) {
     draw_state(c, v0, D);
     draw_targets(c, dc, A, e, episode_new, T, D);
@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void draw_row_noise(const DevCfg& c, const KArgs& A, 
 }
 
 template <class TAB>
-__device__ __forceinline__ void reset_sample(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_old,
+__device__ __forceinline__ void reset_sample(const DevCfg& c, DynCfgK& dc, const KArgs& A, long e, unsigned episode_old,
                                              unsigned flags_old, TAB& T, ResetDraw& D) {
     (void)flags_old;
     float v0[FWG_N_RESET_VARS + 3];
@@ -1294,7 +1294,7 @@ __device__ __forceinline__ float4 draw_tag(const float* __restrict__ S, long N, 
 // Six pieces of at most two or three Philox blocks each, so that a piece fits into the gym wave's wait for its partner:
 // 0-2 the sampled initial values (two blocks each) | 3 state vector and derived angles | 4 targets | 5 per-row noise
 template <class TAB>
-__device__ __forceinline__ unsigned draw_stage_step(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, unsigned episode_now,
+__device__ __forceinline__ unsigned draw_stage_step(const DevCfg& c, DynCfgK& dc, const KArgs& A, long e, unsigned episode_now,
                                                     unsigned stage, TAB& T) {
     const int g0 = c.L.draw >> 2;
     const unsigned episode_new = episode_now + 1u;
@@ -1498,7 +1498,7 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
 }
 
 template <bool TURB, class TAB, class OB>
-__device__ __forceinline__ void reset_env(const DevCfg& c, const DynCfg& dc, const KArgs& A, long e, Env& E, TAB& T, OB& ob,
+__device__ __forceinline__ void reset_env(const DevCfg& c, DynCfgK& dc, const KArgs& A, long e, Env& E, TAB& T, OB& ob,
                                           const float* ring, int g_end, int g_lag, int g_bit) {
     ResetDraw D;
     reset_sample(c, dc, A, e, E.episode, E.flags, T, D);

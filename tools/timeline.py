@@ -113,6 +113,16 @@ def run():
                                                         "max": float(life_b[m].max())}
                 print("   {:34s} blocks {:4d}  lifetime median {:.0f}  p90 {:.0f}  max {:.0f}".format(name, int(m.sum()), np.median(life_b[m]),
                                                                                                        np.percentile(life_b[m], 90), life_b[m].max()))
+        # which piece of the draw costs what: lifetime and the gym wave's arrival at barrier A (stamp 2) by the stage reached
+        g2 = last[:, 1, 2]
+        for st in range(1, 7):
+            m = ((stage == st).sum(axis=1) > 0) & ~done_b
+            if m.sum():
+                print("   draw stage now {}: blocks {:4d}  lifetime median {:.0f} p90 {:.0f} | gym wave at barrier A median {:.0f} p90 {:.0f}".format(
+                    st, int(m.sum()), np.median(life_b[m]), np.percentile(life_b[m], 90), np.nanmedian(g2[m]), np.nanpercentile(g2[m], 90)))
+        m = ~done_b & ~early_b & ~draw_b
+        print("   plain: gym wave at barrier A median {:.0f} p90 {:.0f}; physics wave median {:.0f} p90 {:.0f}".format(
+            np.nanmedian(g2[m]), np.nanpercentile(g2[m], 90), np.nanmedian(last[m, 0, 2]), np.nanpercentile(last[m, 0, 2], 90)))
         # dispatch ramp: the counter is per XCD (block b runs on XCD b % 8), so starts and ends are compared within an XCD only
         Tl = T[-1]
         st_b, en_b = np.nanmin(Tl[:, :, 0], axis=1), np.nanmax(Tl, axis=(1, 2))
