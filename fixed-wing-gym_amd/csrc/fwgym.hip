@@ -80,15 +80,19 @@ __device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, co
     if (valid) {
         const float r = A.acc_ret[e] * A.acc_gamma + reward;
         A.acc_ret[e] = done ? 0.f : r;
-        dr = r - *A.acc_ret_mean;
+        dr = r - *(FWG_KCONST(float)*)A.acc_ret_mean;
     }
+    // the running means the deviations are taken from: written by the head's previous launch, constant during this one.
+    // Read through a plain pointer (after this kernel's stores) every one of them was a vector load with a wait of its own --
+    // 2 D serial round trips, most of what the attached moments cost (§5); as scalar loads they arrive in a few batches
+    FWG_KCONST(float)* mean_k = (FWG_KCONST(float)*)A.acc_mean;
 #define FWG_OBS_AT(k) ob.get(k)
 #pragma unroll
     for (int chunk = 0; chunk < (2 * FWG_MAX_OBS * FWG_MAX_ROWS + 4 + 31) / 32; ++chunk) {
         if (32 * chunk < 2 * D + 4) {
             float v[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) v[i] = FWG_ACC_COLUMN(32 * chunk + i, D, valid, FWG_OBS_AT, A.acc_mean, dr, true, true);
+            for (int i = 0; i < 32; ++i) v[i] = FWG_ACC_COLUMN(32 * chunk + i, D, valid, FWG_OBS_AT, mean_k, dr, true, true);
 #ifdef FWG_ABL_NO_TOTALS
             acc_flush(A.acc, A.acc_cols, blockIdx.x & (FWG_ACC_SHARDS - 1), chunk, lane, v[0] + v[7] + v[13] + v[27]);
 #else

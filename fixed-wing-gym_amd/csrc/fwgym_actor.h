@@ -309,6 +309,15 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
             for (int i = 0; i < 4; ++i) raw_x[kk][4 * q + i] = v[i];
         }
     }
+    // what the sampling / output phase reads is requested here as well, BEFORE this kernel's first store: a load issued after
+    // the normalised-observation stores waits for their acknowledgement (vmcnt counts in issue order), and a uniform load
+    // after a store is no longer a scalar load
+    const unsigned act_ctr = A.stats[A.parity].act_counter;
+    float ls_in[FWG_ACT_MAX_ACT];
+#pragma unroll
+    for (int i = 0; i < FWG_ACT_MAX_ACT; ++i) ls_in[i] = i < A.act_dim ? A.log_std[i] : 0.f;
+    const float rew_in = (A.rew != nullptr && valid) ? A.rew[e] : 0.f;
+    const uint8_t done_in = (A.done != nullptr && valid) ? A.done[e] : (uint8_t)0;
     FWG_ATL(A, 1);
     {   // add the accumulator shards (integers: exact, order-free) and fold the batch into the running statistics (the
         // parallel-variance update of VecNormalize's RunningMeanStd).  Every block computes the same values; block 0
@@ -324,7 +333,9 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
             for (int sh = 0; sh < FWG_ACC_SHARDS; ++sh) sum += (long long)acc[(long)sh * A.acc_cols + tid];
             tot[tid] = (tid == 2 || tid == 3) ? (float)sum : (float)sum * (1.f / FWG_ACC_SCALE);
         }
-        __syncthreads();
+        // (LDS-only barriers here: __syncthreads() drains vmcnt, i.e. it would wait for the whole weight staging above --
+        // the fold and the normalisation below are meant to run UNDER it; dma_wait() before the first MFMA is the drain)
+        FWG_BLOCK_SYNC_LDS();
         const float n_obs = A.training ? tot[2] : 0.f, n_ret = A.training ? tot[3] : 0.f;
         if (tid < FWG_ACT_MAX_OBS) {
             const int f = tid;
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
             for (int i = tid; i < FWG_ACC_SHARDS * A.acc_cols; i += 64 * FWG_ACT_WAVES) nxt[i] = 0ull;
         }
     }
-    __syncthreads();
+    FWG_BLOCK_SYNC_LDS();
     FWG_ATL(A, 2);
 
     frag_t bx_hi[NK1], bx_lo[NK1];
@@ -409,15 +420,14 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     if (half == 0 && valid) {
         float n[4] = {0.f, 0.f, 0.f, 0.f};
         if (!A.deterministic) {
-            const u4 b = philox4x32((unsigned)(A.env_base + e), A.stats[A.parity].act_counter, 0u, FWG_STREAM_POLICY,
-                                    A.seed_lo, A.seed_hi);
+            const u4 b = philox4x32((unsigned)(A.env_base + e), act_ctr, 0u, FWG_STREAM_POLICY, A.seed_lo, A.seed_hi);
             box_muller(b, n);
         }
         float lp = 0.f;
 #pragma unroll
         for (int i = 0; i < FWG_ACT_MAX_ACT; ++i) {
             if (i < A.act_dim) {
-                const float ls = A.log_std[i];
+                const float ls = ls_in[i];
                 if (A.action != nullptr) A.action[e * A.act_dim + i] = res[0][i] + expf(ls) * n[i];
                 lp += -0.5f * n[i] * n[i] - ls - 0.9189385332046727f;
             }
@@ -425,8 +435,8 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
         if (A.logp != nullptr) A.logp[e] = lp;
         if (A.value != nullptr) A.value[e] = res[1][0];
         if (A.norm_rew != nullptr && A.rew != nullptr)
-            A.norm_rew[e] = fminf(fmaxf(A.rew[e] * misc[0], -A.clip_rew), A.clip_rew);
-        if (A.done_out != nullptr && A.done != nullptr) A.done_out[e] = A.done[e];
+            A.norm_rew[e] = fminf(fmaxf(rew_in * misc[0], -A.clip_rew), A.clip_rew);
+        if (A.done_out != nullptr && A.done != nullptr) A.done_out[e] = done_in;
     }
     FWG_ATL(A, 6);
 }

@@ -53,8 +53,10 @@ struct DynCfg {
 // through address space 4 they are scalar loads, batched and cached in the scalar cache
 #if defined(FWG_EMU) || !defined(__HIP_DEVICE_COMPILE__)
 typedef const DynCfg DynCfgK;
+#define FWG_KCONST(T) const T
 #else
 typedef const __attribute__((address_space(4))) DynCfg DynCfgK;
+#define FWG_KCONST(T) const __attribute__((address_space(4))) T   /* launch-constant data behind a plain kernel argument */
 #endif
 
 // The constants of the force / moment model, pre-combined from the parameter table (same names and order as the block at
