@@ -114,8 +114,9 @@ __device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, co
 //   role 2 ("gym"):     bookkeeping rows, action windows, the turbulence noise (Philox + Box-Muller, handed to the
 //                       physics wave through LDS) while the integration runs; then goal / reward / targets / observation
 //                       / metrics / auto-reset on the state it receives.
-// Workgroup barriers: A = state and noise handed over; B = the physics wave's simulator rows are written (the gym wave's
-// auto-reset then overwrites them for lanes that end an episode).
+// Synchronisation: workgroup barrier A = state and noise handed over; then a ONE-WAY mark in LDS that only the physics wave
+// raises (1 = its hand-off areas are read, 2 = its rows are in memory) and the gym wave waits for only where it re-uses the
+// former (output staging) or overwrites the latter (an env it re-initialises itself) -- see FWG_FLAG_RAISE / FWG_FLAG_WAIT.
 // k_step2, physics wave: the partner's actuator states, after workgroup barrier A0
 struct PartnerActuators {
     static constexpr bool enabled = true;

@@ -272,7 +272,8 @@ struct LdsMap { int aring, cring, lag, stage, tab, obs, total; };
 __host__ __device__ inline bool obs_vec4(int obs_dim) { return (obs_dim % 4 == 0) && ((obs_dim / 4) % 2 == 1); }
 __host__ __device__ inline int obs_stage_stride(int obs_dim) { return obs_vec4(obs_dim) ? obs_dim : (obs_dim | 1); }
 // k_step2 hand-off areas (per lane): new state, noise, actuator states.  They ALIAS the output staging area: every use of
-// the staging area comes after workgroup barrier B, every hand-off access before it.  Workgroup residency is bounded by
+// the staging area comes after the physics wave's first hand-shake mark (FWG_FLAG_WAIT level 1: its hand-off areas are read),
+// every hand-off access before it; the pad word of lane 0's hand-off area IS that mark.  Workgroup residency is bounded by
 // LDS (4 workgroups per CU need <= 40 KiB each; a fifth area would cost a fourth of the chip).
 #define FWG_HAND_WORDS 20   /* y[4..15] | roll pitch yaw Va alpha beta | failure code | pad: five 16-byte LDS accesses per lane */
 #define FWG_ACT_WORDS 12    /* actuator states at t + h/2 and t + h (2 x 5) | pad: three 16-byte LDS accesses per lane (FWG_EXT_ACTUATORS) */
