@@ -445,11 +445,14 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // writes the new window over their planes after it.  (Not a drain: that would sit through the acknowledgement of
         // the stores issued since, e.g. a neighbour lane's draw piece)
         if (__ballot(pre_end) != 0ull) {
-            touch4(pre_tag); touch4(pre_old); touch_draw(c, RD);
-            if (c.obs_log > 0) {
+            if (pre_end) {   // (only the lanes that requested them: the others' copies are indeterminate)
+                touch4(pre_tag); touch4(pre_old);
+                if (pre_draw) touch_draw(c, RD);
+                if (c.obs_log > 0) {
 #pragma unroll
-                for (int i = 0; i < FWG_MAX_OBS * FWG_MAX_ROWS; ++i)
-                    if (i >= c.n_obs && i < c.obs_dim) { const float v = ob.get(i); FWG_TOUCH(v); }
+                    for (int i = 0; i < FWG_MAX_OBS * FWG_MAX_ROWS; ++i)
+                        if (i >= c.n_obs && i < c.obs_dim) { const float v = ob.get(i); FWG_TOUCH(v); }
+                }
             }
         }
         FWG_TL(A, 2);
@@ -715,8 +718,9 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 draw_load_final(c, A.S, A.N, e, RD);   // used only if the tag checks out
             }
             if (reload) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
-            touch4(pre_tag); touch4(pre_old); touch_draw(c, RD);
-            if (c.obs_log > 0) {
+            touch4(pre_tag); touch4(pre_old);
+            if (pre_draw) touch_draw(c, RD);
+            if (c.obs_log > 0 && (reload || pre_end)) {
 #pragma unroll
                 for (int i = 0; i < FWG_MAX_OBS * FWG_MAX_ROWS; ++i)
                     if (i >= c.n_obs && i < c.obs_dim) { const float v = ob.get(i); FWG_TOUCH(v); }
