@@ -94,14 +94,33 @@ def cpu_baseline(wl, seconds, max_procs=0):
         cores = max(1, min(cores, int(psutil.virtual_memory().available // (512 << 20))))
     except Exception:
         pass
-    ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(wl, seconds, 100 + i) for i in range(cores)])
+    # one process per core means ONE thread per process: NumPy / SciPy would otherwise start a BLAS / OpenMP pool of
+    # `present` threads in every worker (256 x 256 threads fighting over 256 cores: 26 env-steps/s per process in round 3
+    # against 300 for a process by itself).  Spawned workers inherit the parent's environment, so it is pinned here,
+    # before the pool exists
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = "1"
+    try:
+        ctx = mp.get_context("spawn")
+        with ctx.Pool(1) as pool:   # the single-process rate next to it: shows whether the all-core figure is oversubscribed
+            n1, dt1 = pool.map(_cpu_worker, [(wl, min(seconds, 4.0), 99)])[0]
+        with ctx.Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(wl, seconds, 100 + i) for i in range(cores)])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     total = sum(n / dt for n, dt in res)
     out = {"value": total, "unit": "env-steps/s", "cores": cores, "cores_present": present, "kind": "port",
-           "sample": "{} oracle processes (one per host core; float64 NumPy restatement, 1 env each, same workload config) x {:.0f} s, "
-                     "{} env-steps in total".format(cores, seconds, sum(n for n, _ in res))}
-    try:   # second CPU number: the scalar C++ loop of oracle/cpu_step.cpp over OpenMP threads, when built
+           "per_process": total / cores, "single_process": n1 / dt1, "threads_per_process": 1,
+           "sample": "{} oracle processes (one per host core, one thread each; float64 NumPy restatement, 1 env each, same workload "
+                     "config) x {:.0f} s, {} env-steps in total; a process by itself: {:.0f} env-steps/s".format(
+                         cores, seconds, sum(n for n, _ in res), n1 / dt1)}
+    try:   # second CPU number: the product kernel source compiled for the host (tests/emu, lock-step lane
+        # emulation, OpenMP over workgroups) through oracle/cpu_native.py, when built
         from oracle import cpu_native
         nat = cpu_native.measure(wl, min(seconds, 8.0))
         if nat is not None:
@@ -481,6 +500,42 @@ def main():
             S.vec.close()
         except Exception as e:
             sides["randomised_aircraft"] = {"error": str(e)[:300]}
+    if side_ok and world == 1 and args.workload == "c3" and not args.stagger and not args.envs and not args.total_envs:
+        # BASELINE configs[4]: the PPO rollout loop (VecNormalize + 64-64 MlpPolicy + sampling + env step, end to end), 128-step
+        # rollouts replayed as hipGraphs; head and env step in ONE launch per step where fwg_rollout_step applies
+        def side_c5(name, precise):
+            try:
+                from gym_fixed_wing.actor import DeviceActor
+                from gym_fixed_wing.rollout import FusedRollout, MlpPolicy
+                c5 = workload("c5")
+                S = Runner(c5[0], c5[1], c5[2], c5[3], 0, 0)
+                torch.manual_seed(0)
+                act = DeviceActor.for_env(S.vec, seed=7, env_id_base=0, precise=precise)
+                act.load_policy(MlpPolicy(S.vec.obs_dim))
+                ro = FusedRollout(S.vec, act, sc, graph=True)
+                for _ in range(3):
+                    ro.run()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(sreps):
+                    ro.run()
+                    S.reduce_step(False)
+                torch.cuda.synchronize(dev)
+                ms = (time.perf_counter() - t1) / (sreps * sc) * 1e3
+                sides[name] = side_entry(ms, c5[3], ALG_BYTES["c5"], specialised_kernel=S.vec.spec_index >= 0,
+                    launches_per_step=1 if ro.fused else 2,
+                    note=c5[4] + " (BASELINE configs[4]): rollout head (VecNormalize statistics + 64-64 MlpPolicy on bf16 MFMA, " +
+                         ("operands split hi + lo: three products per tile, ~1e-5 of a torch fp32 forward" if precise else
+                          "ONE plain bf16 product per tile, ~1e-2") + " + sampling) and env step, " +
+                         ("ONE launch per rollout step (fwg_rollout_step)" if ro.fused else "two launches per rollout step") +
+                         ", rollout buffers written in place, {}-step rollouts replayed as hipGraphs".format(sc))
+                act.close()
+                S.vec.close()
+            except Exception as e:
+                sides[name] = {"error": str(e)[:300]}
+
+        side_c5("c5", True)
+        side_c5("c5_bf16", False)
     if side_ok and world > 1 and args.workload == "c3" and not args.envs and not args.total_envs:
         # multi-GPU side figures: BASELINE configs[3] (32 768 envs per GPU) and the north-star point (65 536 envs in total)
         ns_first, ns_n = fd.shard(65536, rank, world)
@@ -526,6 +581,8 @@ def main():
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.emulate else "synthetic (HOST EMULATION: not a measurement)",
+            # ranks that took part in the success-vector all-gather (RCCL; gloo under --emulate); null = no process group
+            "rccl_ranks": (dist.get_world_size() if use_dist else None),
             "config": {"workload": desc, "envs_per_gpu": n_envs, "total_envs": total_envs, "ranks": seen["ranks"],
                        "rk4_substeps": int(vec._c.n_substeps), "actuator_microsteps": int(vec._c.actuator_microsteps),
                        "specialised_kernel": vec.spec_index >= 0, "derived_views": False,
@@ -544,7 +601,8 @@ def main():
                          "measured_GBs": (traffic * args.steps / wall / 1e9) if traffic else None,
                          "achieved_real": (traffic * args.steps / wall / 1e9) if traffic else None,   # (the same figure under the review's name)
                          "frac_measured": (traffic * args.steps / wall / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "kernel": ("k_step2" if vec.spec_index >= 0 and os.environ.get("FWGYM_SPLIT", "1") != "0" else "k_step") + (" + k_actor_act" if fused else ""),
+                         "kernel": ("k_rollout (head + env step in one launch)" if fused and getattr(get_rollout(chunk or 2), "fused", False) else
+                                    ("k_step2" if vec.spec_index >= 0 and os.environ.get("FWGYM_SPLIT", "1") != "0" else "k_step") + (" + k_actor_act" if fused else "")),
                          "kernel_ms": wall / args.steps * 1e3, "kernel_ms_hip_events": event_ms,
                          "clock": "wall clock of the timed region (the same interval as `value`)",
                          "algorithmic_bytes_per_env_step": ALG_BYTES[args.workload], "source_hash": source_hash()},

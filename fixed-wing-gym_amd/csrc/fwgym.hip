@@ -15,7 +15,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <vector>
 #include "fwgym_env.h"
+#include "fwgym_actor.h"   // the rollout head (k_rollout below runs it in the same launch as the env step)
 
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum64(v); }
 
@@ -40,10 +42,15 @@ static_assert(sizeof(SpecWords) == sizeof(DevCfg), "DevCfg must be made of 32-bi
 #define FWG_DEFINE_SPEC(i) static constexpr DevCfg kSpec##i = __builtin_bit_cast(DevCfg, kSpecWords##i);
 FWG_SPEC_LIST(FWG_DEFINE_SPEC)
 template <int SPEC> struct SpecCfg {
+    static constexpr int obs_dim = 16;   // (generic kernels never instantiate the fused rollout launch)
+    static constexpr bool rollout_ok = false;
     static __device__ __forceinline__ const DevCfg& get(const DevCfg* cp) { return *cp; }
 };
 #define FWG_SPEC_GETTER(i)                                                                                \
     template <> struct SpecCfg<i> {                                                                       \
+        static constexpr int obs_dim = kSpec##i.obs_dim;                                                  \
+        /* the fused head + step launch (k_rollout): dense observation batch within the head's 64 entries */ \
+        static constexpr bool rollout_ok = kSpec##i.obs_log == 0 && kSpec##i.obs_dim <= 64;               \
         static __device__ __forceinline__ const DevCfg& get(const DevCfg*) { return kSpec##i; }           \
     };
 FWG_SPEC_LIST(FWG_SPEC_GETTER)
@@ -70,9 +77,14 @@ FWG_SPEC_LIST(FWG_SPEC_TYPES)
 
 // Attached rollout head (fwg_attach_observer): this wave's batch moments of the observation records and discounted
 // returns it produced, added to the head's accumulators (fwgym_env.h "batch-moment accumulators").  Called by all lanes.
-template <class OB>
+// HS (k_rollout: head and env step in one launch): the running means and the act counter are the ones the head phase of
+// THIS launch computed -- `hs_mean` / `hs_ret_mean` in LDS, `hs_ctr` -- not the published copies in memory (which the first
+// block of this same launch is writing).
+struct NoHeadStats { static constexpr bool enabled = false; const float* mean = nullptr; float ret_mean = 0.f; unsigned ctr = 0u; };
+struct HeadStats { static constexpr bool enabled = true; const float* mean; float ret_mean; unsigned ctr; };
+template <class OB, class HS = NoHeadStats>
 __device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, const OB& ob, float reward, bool done, bool valid,
-                                             int lane, long e) {
+                                             int lane, long e, int sub, const HS& hs = HS()) {
 #ifndef FWG_ABL_NO_ACC
     const int D = c.obs_dim;
     // VecNormalize.step_wait: ret = ret * gamma + r; ret_rms.update(ret); ret[done] = 0
@@ -80,23 +92,30 @@ __device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, co
     if (valid) {
         const float r = A.acc_ret[e] * A.acc_gamma + reward;
         A.acc_ret[e] = done ? 0.f : r;
-        dr = r - *(FWG_KCONST(float)*)A.acc_ret_mean;
+        dr = r - (HS::enabled ? hs.ret_mean : *(FWG_KCONST(float)*)A.acc_ret_mean);
     }
+    // the accumulator set of this launch: the head's act counter mod 3 (fwgym_actor.h)
+    const unsigned ctr = HS::enabled ? hs.ctr : *(FWG_KCONST(unsigned)*)A.acc_ctr;
+    unsigned long long* acc = A.acc + (size_t)(ctr % FWG_ACC_SETS) * FWG_ACC_SHARDS * A.acc_cols;
     // the running means the deviations are taken from: written by the head's previous launch, constant during this one.
     // Read through a plain pointer (after this kernel's stores) every one of them was a vector load with a wait of its own --
     // 2 D serial round trips, most of what the attached moments cost (§5); as scalar loads they arrive in a few batches
     FWG_KCONST(float)* mean_k = (FWG_KCONST(float)*)A.acc_mean;
 #define FWG_OBS_AT(k) ob.get(k)
+    struct MeanRef {
+        const float* head; FWG_KCONST(float)* k;
+        __device__ __forceinline__ float operator[](int i) const { return HS::enabled ? head[i] : k[i]; }
+    } const mean_at{hs.mean, mean_k};
 #pragma unroll
     for (int chunk = 0; chunk < (2 * FWG_MAX_OBS * FWG_MAX_ROWS + 4 + 31) / 32; ++chunk) {
         if (32 * chunk < 2 * D + 4) {
             float v[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) v[i] = FWG_ACC_COLUMN(32 * chunk + i, D, valid, FWG_OBS_AT, mean_k, dr, true, true);
+            for (int i = 0; i < 32; ++i) v[i] = FWG_ACC_COLUMN(32 * chunk + i, D, valid, FWG_OBS_AT, mean_at, dr, true, true);
 #ifdef FWG_ABL_NO_TOTALS
-            acc_flush(A.acc, A.acc_cols, blockIdx.x & (FWG_ACC_SHARDS - 1), chunk, lane, v[0] + v[7] + v[13] + v[27]);
+            acc_flush(acc, A.acc_cols, sub & (FWG_ACC_SHARDS - 1), chunk, lane, v[0] + v[7] + v[13] + v[27]);
 #else
-            acc_flush(A.acc, A.acc_cols, blockIdx.x & (FWG_ACC_SHARDS - 1), chunk, lane, wave_totals32(v, lane));
+            acc_flush(acc, A.acc_cols, sub & (FWG_ACC_SHARDS - 1), chunk, lane, wave_totals32(v, lane));
 #endif
         }
     }
@@ -129,13 +148,17 @@ struct PartnerActuators {
     }
 };
 
-template <bool TURB, int SPEC, int ROLE>
-__device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs& A0, float* lds) {
+// `sub` = index of the 64-environment group this wave (pair of waves) steps: the workgroup index in k_step / k_step2, four
+// groups per workgroup in k_rollout, whose head phase leaves the actions in LDS (`act_lds`: this group's [64][4] floats) and
+// its updated running statistics in `hs`.
+template <bool TURB, int SPEC, int ROLE, class HS = NoHeadStats>
+__device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs& A0, float* lds, int sub,
+                                          const float* act_lds = nullptr, const HS& hs = HS()) {
     typedef KernelTypes<SPEC> KT;
     constexpr bool PHYS = ROLE != 2, GYM = ROLE != 1, SPLIT = ROLE != 0;
     const DevCfg& c = SpecCfg<SPEC>::get(cp);
     const KArgs A = resolve_slots(c, A0);
-    if (PHYS && A0.slots_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    if (PHYS && A0.slots_out != nullptr && sub == 0 && (threadIdx.x & (FWG_WAVE - 1)) == 0)
         *A0.slots_out = next_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, *A0.slots_in);
 #ifdef FWG_ABL_EMPTY  // FWG_ABL_*: measurement-only switches (tools/ablate.py), never defined in the product build
     return;
@@ -143,7 +166,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     DynCfgK& dc = *(DynCfgK*)dp;
     FWG_TL(A, 0);
     const int lane = threadIdx.x & (FWG_WAVE - 1);
-    const long env0 = (long)blockIdx.x * FWG_WAVE;
+    const long env0 = (long)sub * FWG_WAVE;
     const bool valid = env0 + lane < A.N;
     const long e = valid ? env0 + lane : A.N - 1;
     const LdsMap M = lds_map(c.obs_dim, c.n_obs, c.L.window, c.use_cmd_ring, KT::generic, c.obs_log, SPLIT);
@@ -157,6 +180,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     float* hand = lds + M.stage + lane * FWG_HAND_WORDS;                       // physics -> gym
     float* noise = lds + M.stage + FWG_WAVE * FWG_HAND_WORDS + lane * 4;       // gym -> physics
     float* acts = lds + M.stage + FWG_WAVE * (FWG_HAND_WORDS + 4) + lane * FWG_ACT_WORDS;   // gym -> physics
+    float* mark = lds + M.flag;   // the one-way hand-shake mark: cleared by the physics wave before barrier A, raised by it after
     // FWG_EXT_ACTUATORS (experiment, off): the gym wave advances the actuators for the physics wave, which picks them up
     // after its first stage.  Measured SLOWER by 1.0-1.2 us per step at 65 536 envs (the extra barrier inside the stage
     // loop and the two VALU-heavy streams contending on every SIMD cost more than the 16 micro-steps save).
@@ -170,7 +194,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // are addressed by the run-time ring slot); everything else goes to registers.
     float raw[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) raw[i] = A.actions[e * 3 + i];   // [N][3]: a wave reads 768 contiguous bytes
+    for (int i = 0; i < 3; ++i) raw[i] = HS::enabled ? act_lds[lane * 4 + i] : A.actions[e * 3 + i];   // [N][3]: a wave reads 768 contiguous bytes
     Env E;
     if (PHYS) load_sim<TURB>(c, A.S, A.N, e, E);
     load_cold(c, A.S, A.N, e, E);
@@ -277,6 +301,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         h4[2] = make_float4(E.y[12], E.y[13], E.y[14], E.y[15]);
         h4[3] = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
         h4[4] = make_float4(E.d.alpha, E.d.beta, u2f((unsigned)fail), 0.f);
+        if (lane == 0) FWG_FLAG_RAISE(mark, 0);   // (LDS executes a wave's accesses in order: cleared before barrier A releases the partner)
     }
     float n[4] = {0.f, 0.f, 0.f, 0.f};   // the step's four standard normals for the Dryden filter
     if (TURB && GYM) {   // (counters: the step and episode indices BEFORE this step; independent of the integration)
@@ -483,7 +508,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // re-use them as the output staging area
     if (SPLIT && PHYS) {
         FWG_EMU_WAVE_SYNC();
-        if (lane == 0) FWG_FLAG_RAISE(hand + FWG_HAND_WORDS - 1, 1);   // (asm with a memory clobber: the reads above stay above)
+        if (lane == 0) FWG_FLAG_RAISE(mark, 1);   // (asm with a memory clobber: the reads above stay above)
     }
     if (SPLIT && GYM) {
         const float4* h4 = reinterpret_cast<const float4*>(hand);
@@ -533,6 +558,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #pragma unroll
                 for (int i = 0; i < 6; ++i) E.gust[i] = 0.f;
                 E.gust_gain = RDp.gust_gain;
+                E.d = RDp.d;   // (store_sim writes the derived host views with store_derived)
                 store_cold(c, A.S, A.N, e, E);
                 store_sim<TURB>(c, A.S, A.N, e, E);
             }
@@ -542,7 +568,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // early lane's padding rows); this wave waits for nobody
         FWG_DMA_DRAIN();   // s_waitcnt vmcnt(0): covers stores as well
         FWG_WAVE_SYNC();
-        if (lane == 0) FWG_FLAG_RAISE(hand + FWG_HAND_WORDS - 1, 2);
+        if (lane == 0) FWG_FLAG_RAISE(mark, 2);
         return;
     }
     // everything streamed HBM -> LDS at kernel start is needed from here on; the integration above hid its latency
@@ -765,13 +791,13 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     const unsigned long long done_mask = __ballot(done && valid);
     // waves in which no episode ends have their final observation records here: the moments for an attached rollout head
     // go out before the remaining stores, whose issue then hides the round trip of the atomics
-    if (A.acc != nullptr && done_mask == 0ull) step_moments(c, A, ob, reward, done, valid, lane, e);
+    if (A.acc != nullptr && done_mask == 0ull) step_moments(c, A, ob, reward, done, valid, lane, e, sub, hs);
     // hand-shake B: the output staging area aliases the hand-off areas (first mark, raised right after barrier A), and an env
     // that is re-initialised HERE has rows the physics wave wrote in this launch (second mark: they are in memory).  A
     // foreseen end whose new episode the partner installs needs neither acknowledgement
     if (SPLIT) {
         const bool overwrites = __ballot(done && valid && !pre_rows) != 0ull;
-        if (overwrites || c.obs_log == 0 || done_mask != 0ull) FWG_FLAG_WAIT(lds + M.stage + FWG_HAND_WORDS - 1, overwrites ? 2 : 1);
+        if (overwrites || c.obs_log == 0 || done_mask != 0ull) FWG_FLAG_WAIT(mark, overwrites ? 2 : 1);
     }
     if (done_mask != 0ull) {
         if (done && valid) {
@@ -831,12 +857,12 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         }
     }
 
-    if (A.acc != nullptr && done_mask != 0ull) step_moments(c, A, ob, reward, done, valid, lane, e);
+    if (A.acc != nullptr && done_mask != 0ull) step_moments(c, A, ob, reward, done, valid, lane, e, sub, hs);
     FWG_TL(A, 8);
     // ---- phase F: outputs and the state write-back
 #ifndef FWG_ABL_NO_OBSWRITE
     if (c.obs_log == 0) {
-        write_obs<ROLE>(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull);
+        write_obs<ROLE>(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull, A.acc != nullptr);
     } else {
         if (valid && !pre_rows) log_store_row(c, A.obs, A.N, e, log_win, 0, ob);   // the new record: 64 consecutive rows per wave
         if (__ballot((done || (early && !tail_rows)) && valid && !pre_rows) != 0ull) {
@@ -858,7 +884,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 template <bool TURB, int SPEC>
 __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    step_wave<TURB, SPEC, 0>(cp, dp, A0, lds);
+    step_wave<TURB, SPEC, 0>(cp, dp, A0, lds, (int)blockIdx.x);
 }
 
 // the same step on two waves per 64 environments (specialised configurations only: the generic kernel keeps its tables
@@ -866,8 +892,54 @@ __global__ __launch_bounds__(FWG_WAVE, 1) void k_step(const DevCfg* __restrict__
 template <bool TURB, int SPEC>
 __global__ __launch_bounds__(2 * FWG_WAVE, 2) void k_step2(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (threadIdx.x < FWG_WAVE) step_wave<TURB, SPEC, 1>(cp, dp, A0, lds);
-    else step_wave<TURB, SPEC, 2>(cp, dp, A0, lds);
+    if (threadIdx.x < FWG_WAVE) step_wave<TURB, SPEC, 1>(cp, dp, A0, lds, (int)blockIdx.x);
+    else step_wave<TURB, SPEC, 2>(cp, dp, A0, lds, (int)blockIdx.x);
+}
+
+// One rollout step in ONE launch (fwg_rollout_step): the head (VecNormalize statistics + MlpPolicy + sampling, actor_block of
+// fwgym_actor.h) for the 256 environments of the workgroup, then the env step of those same environments under the actions
+// just sampled -- examples/train_rl_controller.py:223-231 (VecNormalize(SubprocVecEnv).step inside PPO2's runner) without the
+// launch boundary between policy and env.  The only grid-wide dependency of a rollout step -- the batch moments every
+// env step contributes to VecNormalize's running statistics -- falls on the boundary BETWEEN launches: a launch's head phase
+// folds the moments its predecessor's step phase left (accumulator set c % 3), its step phase adds into set (c + 1) % 3.
+// Workgroup = 8 waves: all of them run the head (one 32-environment tile each), then waves 0..3 are the physics waves and
+// waves 4..7 the gym waves of four two-wave steps (k_step2's roles; a workgroup's waves are dealt to the four SIMDs in turn,
+// so every SIMD hosts one wave of each kind).  LDS: the packed weights during the head phase, the four groups' step areas
+// afterwards (aliased), then what outlives the head: updated statistics, the sampled actions.
+#define FWG_RO_GROUPS 4
+#define FWG_RO_ENVS (FWG_RO_GROUPS * FWG_WAVE)
+__host__ __device__ inline int rollout_shared_floats(const DevCfg& c, int hsplit) {
+    const int w = actor_weight_floats((c.obs_dim + 15) / 16, hsplit > 1 ? 2 : 1);
+    const int st = FWG_RO_GROUPS * lds_map(c.obs_dim, c.n_obs, c.L.window, c.use_cmd_ring, false, c.obs_log, true).total;
+    return w > st ? w : st;
+}
+__host__ __device__ inline int rollout_lds_floats(const DevCfg& c, int hsplit) {
+    return rollout_shared_floats(c, hsplit) + actor_scratch_floats() + FWG_RO_ENVS * 4;
+}
+// (configurations the fused launch exists for: SpecCfg<SPEC>::rollout_ok -- dense observation batch of at most 64 entries, the
+// head's limit -- and everything within 160 KiB of LDS, checked by the launcher)
+template <bool TURB, int SPEC, int HSPLIT>
+__global__ __launch_bounds__(2 * FWG_RO_ENVS, 2) void k_rollout(const DevCfg* __restrict__ cp, const DynCfg* __restrict__ dp, const KArgs A0,
+                                                                 const ActorArgs AA) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const DevCfg& c = SpecCfg<SPEC>::get(cp);
+    constexpr int NK1 = (SpecCfg<SPEC>::obs_dim + 15) / 16;
+    const int shared = rollout_shared_floats(c, HSPLIT);
+    ActorLds Z;
+    Z.F = reinterpret_cast<frag_t*>(lds);
+    Z.mean_s = lds + shared;
+    Z.rstd_s = Z.mean_s + FWG_ACT_MAX_OBS;
+    Z.misc = Z.rstd_s + FWG_ACT_MAX_OBS;
+    Z.act_out = lds + shared + actor_scratch_floats();
+    const unsigned act_ctr = actor_block<HSPLIT, NK1>(AA, Z, (long)blockIdx.x * FWG_RO_ENVS);
+    __syncthreads();   // actions and statistics are in LDS; the weights are dead: their area becomes the step areas
+    const int wave = threadIdx.x >> 6, group = wave & (FWG_RO_GROUPS - 1);
+    const int sub = (int)blockIdx.x * FWG_RO_GROUPS + group;
+    const HeadStats hs{Z.mean_s, Z.misc[1], act_ctr + 1u};
+    float* area = lds + group * lds_map(c.obs_dim, c.n_obs, c.L.window, c.use_cmd_ring, false, c.obs_log, true).total;
+    const float* acts = Z.act_out + group * (FWG_WAVE * 4);
+    if (wave < FWG_RO_GROUPS) step_wave<TURB, SPEC, 1, HeadStats>(cp, dp, A0, area, sub, acts, hs);
+    else step_wave<TURB, SPEC, 2, HeadStats>(cp, dp, A0, area, sub, acts, hs);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1168,6 +1240,7 @@ struct fwg_handle {
     int64_t gstep;  // number of env steps taken so far (drives the ring slots)
     int graph_mode; // the ring positions live on the device (d_slots[2], double-buffered by the parity of the host count)
     int64_t gstep_at_capture;
+    unsigned generation_at_capture;   // configuration generation the captured launch sequences belong to
     StepSlots* d_slots;
     size_t lds_bytes;
     float* last_metrics_out;      // metrics block of the last fwg_step (what fwg_reduce_success* collect into)
@@ -1684,7 +1757,14 @@ int fwg_set_graph_mode(fwg_handle* h, int enable, void* stream) {
 
 int fwg_capture_begin(fwg_handle* h) {
     if (!h || !h->graph_mode) return fail_with(FWG_ERR_INVALID, "fwg_capture_begin needs graph mode");
+    // simulator.model / randomize_scaling: whether a step launches the full-grid draw (every prepared set stale) or the queue
+    // kernel is decided on the HOST when the launch is issued -- a sequence captured while the sets are stale would replay
+    // the full-grid draw for ever, and one captured before a generation bump would never run it (fwg_replay_check)
+    if (h->d_mq != nullptr && h->model_all_stale)
+        return fail_with(FWG_ERR_INVALID, "fwg_capture_begin: the per-env parameter sets are stale (start, fwg_update_config, fwg_seed): "
+                                          "issue fwg_reset or an even number of direct fwg_step calls before capturing");
     h->gstep_at_capture = h->gstep;
+    h->generation_at_capture = h->hd.generation;
     return FWG_OK;
 }
 int fwg_capture_end(fwg_handle* h) {   // the captured calls did not execute: take the host count back
@@ -1704,6 +1784,9 @@ int fwg_note_replayed_steps(fwg_handle* h, int64_t n_steps) {
 int fwg_capture_parity(const fwg_handle* h) { return h ? (int)(h->gstep_at_capture & 1) : 0; }
 int fwg_replay_check(const fwg_handle* h, int capture_parity) {
     if (!h || !h->graph_mode) return fail_with(FWG_ERR_INVALID, "fwg_replay_check needs graph mode");
+    if (h->d_mq != nullptr && (h->hd.generation != h->generation_at_capture || h->model_all_stale))
+        return fail_with(FWG_ERR_INVALID, "hipGraph captured before fwg_update_config / fwg_seed: its launches would keep using per-env "
+                                          "parameter sets drawn under the old ranges (issue two direct fwg_step calls, then capture again)");
     if ((int)(h->gstep & 1) != (capture_parity & 1))
         return fail_with(FWG_ERR_INVALID, "hipGraph captured at the other step parity: its launches would read the stale copy of the ring "
                                           "positions (run an even number of direct steps between capture and replay, or capture again)");
@@ -1762,8 +1845,6 @@ static void launch(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
 // =====================================================================================================================
 // rollout head (include/fwgym.h "Rollout head"): VecNormalize statistics + MlpPolicy on the matrix cores
 // =====================================================================================================================
-#include <vector>
-#include "fwgym_actor.h"
 
 struct fwg_actor {
     int device;
@@ -1773,7 +1854,7 @@ struct fwg_actor {
     int training, precise, parity;
     uint64_t seed;
     ActorStats* d_stats;   // [2]
-    unsigned long long* d_acc;   // [parity 2][FWG_ACC_SHARDS][acc_cols] fixed-point batch moments
+    unsigned long long* d_acc;   // [FWG_ACC_SETS][FWG_ACC_SHARDS][acc_cols] fixed-point batch moments (rotation: fwgym_actor.h)
     int acc_cols;
     frag_t* d_frags;
     float* d_log_std;
@@ -1814,7 +1895,8 @@ static ActorArgs actor_args(const fwg_actor* a) {
 static void observer_args(fwg_handle* h, KArgs* A) {
     fwg_actor* a = h->observer;
     if (!a) return;
-    A->acc = a->d_acc + (size_t)a->parity * FWG_ACC_SHARDS * a->acc_cols;
+    A->acc = a->d_acc;   // three sets; the step adds into set (act counter of the current statistics copy) % 3
+    A->acc_ctr = &a->d_stats[a->parity].act_counter;
     A->acc_mean = a->d_stats[a->parity].mean; A->acc_ret_mean = &a->d_stats[a->parity].ret_mean;
     A->acc_ret = a->d_ret; A->acc_gamma = a->gamma; A->acc_cols = a->acc_cols;
 }
@@ -1860,7 +1942,7 @@ int fwg_actor_create(int device, int64_t n_envs, int obs_dim, int act_dim, float
     const size_t nfrag = (size_t)2 * 2 * actor_frags(a->nk1) * 64;
     HIP_TRY(hipMalloc((void**)&a->d_stats, 2 * sizeof(ActorStats)));
     a->acc_cols = acc_cols_for(obs_dim);
-    const size_t acc_bytes = (size_t)2 * FWG_ACC_SHARDS * a->acc_cols * sizeof(unsigned long long);
+    const size_t acc_bytes = (size_t)FWG_ACC_SETS * FWG_ACC_SHARDS * a->acc_cols * sizeof(unsigned long long);
     HIP_TRY(hipMalloc((void**)&a->d_acc, acc_bytes));
     HIP_TRY(hipMemset(a->d_acc, 0, acc_bytes));
     HIP_TRY(hipMalloc((void**)&a->d_frags, nfrag * sizeof(frag_t)));
@@ -1993,6 +2075,81 @@ int fwg_actor_act(fwg_actor* a, const float* obs, const float* reward, const uin
 #undef FWG_ACT_LAUNCH
     HIP_TRY(hipGetLastError());
     a->parity ^= 1;
+    return FWG_OK;
+}
+
+}  // extern "C"
+// ---- the head and the env step in one launch
+template <bool TURB, int SPEC>
+static int launch_rollout_one(fwg_handle* h, fwg_actor* a, const KArgs& A, const ActorArgs& AA, hipStream_t stream) {
+    if constexpr (SPEC >= 0) {
+        if constexpr (SpecCfg<SPEC>::rollout_ok) {
+            const int hsplit = a->precise ? 3 : 1;
+            const size_t bytes = (size_t)rollout_lds_floats(h->h, hsplit) * sizeof(float);
+            if (bytes > 160 * 1024) return 1;
+            const dim3 grid((unsigned)((h->n_envs + FWG_RO_ENVS - 1) / FWG_RO_ENVS)), block(2 * FWG_RO_ENVS);
+            const void* fn = a->precise ? (const void*)k_rollout<TURB, SPEC, 3> : (const void*)k_rollout<TURB, SPEC, 1>;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
+            if (a->precise) hipLaunchKernelGGL((k_rollout<TURB, SPEC, 3>), grid, block, bytes, stream, h->d_cfg, h->d_dyn, A, AA);
+            else hipLaunchKernelGGL((k_rollout<TURB, SPEC, 1>), grid, block, bytes, stream, h->d_cfg, h->d_dyn, A, AA);
+            return 0;
+        }
+    }
+    return 1;
+}
+static int launch_rollout(fwg_handle* h, fwg_actor* a, const KArgs& A, const ActorArgs& AA, hipStream_t stream, bool probe) {
+    switch (h->spec) {
+#define FWG_SPEC_RO(i) \
+    case i: if (probe) return (SpecCfg<i>::rollout_ok && (size_t)rollout_lds_floats(kSpec##i, 3) * sizeof(float) <= 160 * 1024) ? 0 : 1; \
+            return launch_rollout_one<(kSpec##i.turbulence != 0), i>(h, a, A, AA, stream);
+        FWG_SPEC_LIST(FWG_SPEC_RO)
+#undef FWG_SPEC_RO
+        default: break;
+    }
+    return 1;
+}
+
+extern "C" {
+
+int fwg_rollout_available(const fwg_handle* h, const fwg_actor* a) {
+    if (!h || !a || h->observer != a || h->spec < 0 || !h->split || h->h.obs_log > 0) return 0;
+    if (h->h.model_n > 0 || h->h.randomize_scaling) return 0;   // (the per-env parameter queue launch sits between head and step)
+    if (a->act_dim != 3 || a->log_env != nullptr) return 0;
+    return launch_rollout(const_cast<fwg_handle*>(h), const_cast<fwg_actor*>(a), KArgs(), ActorArgs(), nullptr, true) == 0 ? 1 : 0;
+}
+
+int fwg_rollout_step(fwg_handle* h, fwg_actor* a, float* norm_obs_out, float* action_out, float* value_out, float* logp_out,
+                     float* norm_reward_out, uint8_t* done_prev_out, float* obs_io, float* reward_io, uint8_t* done_io,
+                     uint8_t* term_code_out, float* terminal_obs_out, float* metrics_out, int deterministic, void* stream) {
+    if (!h || !a || !obs_io || !reward_io || !done_io || !term_code_out) return fail_with(FWG_ERR_INVALID, "fwg_rollout_step: null argument");
+    if (!fwg_rollout_available(h, a))
+        return fail_with(FWG_ERR_INVALID, "fwg_rollout_step: needs a build-time specialised configuration with the dense observation batch "
+                                          "and this head attached (fwg_attach_observer); use fwg_step + fwg_actor_act otherwise");
+    HIP_TRY(hipSetDevice(a->device));
+    // head: on the observation / reward / done flags the env's last step left in obs_io / reward_io / done_io
+    ActorArgs AA = actor_args(a);
+    AA.obs = obs_io; AA.rew = reward_io; AA.done = done_io;
+    AA.norm_obs = norm_obs_out; AA.action = action_out; AA.value = value_out; AA.logp = logp_out; AA.norm_rew = norm_reward_out;
+    AA.done_out = done_prev_out; AA.deterministic = deterministic ? 1 : 0;
+    // env step: as fwg_step, the actions come from the head phase (LDS)
+    KArgs A;
+    base_args(h, &A);
+    A.actions = nullptr; A.obs = obs_io; A.rew = reward_io; A.done = done_io; A.term = term_code_out;
+    A.term_obs = terminal_obs_out; A.metrics = metrics_out; A.tgt_out = nullptr;
+    h->last_metrics_out = metrics_out;
+    fill_slots(h, h->gstep, &A);
+    if (h->graph_mode) { A.slots_in = h->d_slots + (h->gstep & 1); A.slots_out = h->d_slots + ((h->gstep + 1) & 1); }
+    a->parity ^= 1;          // the step phase belongs to the statistics copy the head phase publishes ...
+    observer_args(h, &A);    // (... its means and counter are taken from LDS in the kernel; acc / ret / gamma from here)
+#ifdef FWG_TIMELINE
+    A.trace = h->trace;
+#endif
+    if (launch_rollout(h, a, A, AA, (hipStream_t)stream, false) != 0) {
+        a->parity ^= 1;
+        return fail_with(FWG_ERR_INVALID, "fwg_rollout_step: no fused launch for this configuration");
+    }
+    HIP_TRY(hipGetLastError());
+    h->gstep += 1;
     return FWG_OK;
 }
 

@@ -29,8 +29,12 @@
 // k_actor_act reads copy [parity] and publishes copy [parity ^ 1], so captured launch sequences replay correctly
 struct ActorStats { float mean[FWG_ACT_MAX_OBS], var[FWG_ACT_MAX_OBS]; float count, ret_mean, ret_var, ret_count; unsigned act_counter, pad_[3]; };
 // Batch moments reach k_actor_act through the fixed-point accumulators described in fwgym_env.h (acc_*), filled either
-// by k_actor_stats or by the env step kernel itself (fwg_attach_observer); double-buffered by parity like the statistics:
-// k_actor_act consumes copy [parity] and clears copy [parity ^ 1] for the launches that follow it.
+// by k_actor_stats or by the env step kernel itself (fwg_attach_observer).  THREE sets, rotating with the act counter c of
+// the statistics copy a launch reads: producers (k_actor_stats, the env step) add into set c % 3, the act with counter c
+// consumes set c % 3, publishes c + 1 and clears set (c + 2) % 3 -- the set the producers AFTER THE NEXT act will add into.
+// No launch ever clears a set that the same launch reads or adds to, so the act and the env step that follows it can be
+// ONE launch (k_rollout: its blocks consume set c % 3, add into (c + 1) % 3 and block 0 clears (c + 2) % 3), and a captured
+// launch sequence replays whatever its length (the rotation lives on the device, not in the captured arguments).
 
 struct alignas(16) frag_t { unsigned x, y, z, w; };   // 8 bf16 = the A or B operand of one lane
 
@@ -44,7 +48,7 @@ struct ActorArgs {
 #endif
     float* ret;
     ActorStats* stats;                  // [2], indexed by parity
-    unsigned long long* acc; int acc_cols;   // [2][FWG_ACC_SHARDS][acc_cols]
+    unsigned long long* acc; int acc_cols;   // [FWG_ACC_SETS][FWG_ACC_SHARDS][acc_cols]
     const frag_t* frags;                // [net 2][part hi/lo][frag][64 lanes]
     const float* log_std;
     float* norm_obs; float* action; float* value; float* logp; float* norm_rew; uint8_t* done_out;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(FWG_ACT_BLOCK) void k_actor_stats(const ActorArgs A
         A.ret[e] = (A.done != nullptr && A.done[e]) ? 0.f : r;
         dr = r - S.ret_mean;
     }
-    unsigned long long* acc = A.acc + (size_t)A.parity * FWG_ACC_SHARDS * A.acc_cols;
+    unsigned long long* acc = A.acc + (size_t)(S.act_counter % FWG_ACC_SETS) * FWG_ACC_SHARDS * A.acc_cols;
     const long long win = actor_obs_win(A);
     const long er = valid ? e : 0;
 #define FWG_OBS_AT(k) (actor_obs_at(A, win, er, (k) & ~3)[(k) & 3])
@@ -248,21 +252,33 @@ __global__ __launch_bounds__(FWG_ACT_BLOCK) void k_actor_stats(const ActorArgs A
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// statistics update + normalisation + pi/vf forward + sampling.  Block = 8 waves (two per SIMD, so that one wave's
-// MFMAs overlap the other's tanh/conversion work), a wave = one 32-environment tile; the packed weights of both
-// networks sit in LDS once per block (76 KiB for obs_dim <= 16)
+// statistics update + normalisation + pi/vf forward + sampling for the 256 environments [env_first, env_first + 256) of one
+// 8-wave workgroup (two waves per SIMD, so that one wave's MFMAs overlap the other's tanh/conversion work; a wave = one
+// 32-environment tile); the packed weights of both networks sit in LDS once per workgroup (76 KiB for obs_dim <= 16).
+// Shared by k_actor_act (the head as a launch of its own) and k_rollout (fwgym.hip: the head AND the env step that takes its
+// actions in one launch -- `act_out` then receives the sampled actions, [256][4] floats in LDS).
 // ---------------------------------------------------------------------------------------------------------------------
+struct ActorLds {
+    frag_t* F;        // [net][part][nf][64] packed weights
+    float* mean_s;    // [64] updated running mean
+    float* rstd_s;    // [64] 1 / sqrt(updated running variance + eps)
+    float* misc;      // [0] 1 / sqrt(ret_var + eps), [1] updated running mean of the returns, [4 ...] batch sums
+    float* act_out;   // nullable: sampled actions of the workgroup's environments, [256][4]
+};
+__host__ __device__ inline int actor_weight_floats(int nk1, int parts) { return 2 * parts * actor_frags(nk1) * 64 * 4; }
+__host__ __device__ inline int actor_scratch_floats() { return 2 * FWG_ACT_MAX_OBS + 4 + 2 * FWG_ACT_MAX_OBS + 4; }
+
 template <int SPLIT, int NK1>
-__global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ unsigned actor_block(const ActorArgs& A, const ActorLds& Z, long env_first) {
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, j = l & 31, half = l >> 5;
     constexpr int nf = 2 * (NK1 + 1) + 15;
     constexpr int PARTS = SPLIT > 1 ? 2 : 1;
+    const bool first_block = env_first == 0;
     FWG_ATL(A, 0);
-    frag_t* F = reinterpret_cast<frag_t*>(lds);                     // [net][part][nf][64]
-    float* mean_s = lds + 2 * PARTS * nf * 64 * 4;                  // [64]
-    float* rstd_s = mean_s + FWG_ACT_MAX_OBS;                       // [64]
-    float* misc = rstd_s + FWG_ACT_MAX_OBS;                         // [0] = 1/sqrt(ret_var + eps)
+    frag_t* F = Z.F;
+    float* mean_s = Z.mean_s;
+    float* rstd_s = Z.rstd_s;
+    float* misc = Z.misc;
     // packed weights HBM/L2 -> LDS without a register round trip (global_load_lds, 1 KiB per wave instruction): in
     // flight while the statistics are folded and the observations normalised, waited for before the first MFMA
 #ifndef FWG_ABL_ACT_NO_STAGE
@@ -285,7 +301,7 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     }
 #endif
     // raw observation entries of this lane (k-slots of the first layer), requested before the statistics are folded
-    const long e = (long)blockIdx.x * FWG_ACT_ENVS + wv * 32 + j;
+    const long e = env_first + wv * 32 + j;
     const bool valid = e < A.N;
     const bool vec4 = (A.D & 3) == 0 && (A.obs_n & 3) == 0;
     const long long win = actor_obs_win(A);
@@ -320,12 +336,13 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     const uint8_t done_in = (A.done != nullptr && valid) ? A.done[e] : (uint8_t)0;
     FWG_ATL(A, 1);
     {   // add the accumulator shards (integers: exact, order-free) and fold the batch into the running statistics (the
-        // parallel-variance update of VecNormalize's RunningMeanStd).  Every block computes the same values; block 0
-        // publishes them and clears the other parity's accumulators for the launches that follow
+        // parallel-variance update of VecNormalize's RunningMeanStd).  Every block computes the same values; the first
+        // block publishes them and clears the accumulator set the producers after the NEXT act will add into
         const ActorStats& S0 = A.stats[A.parity];
         ActorStats& S1 = A.stats[A.parity ^ 1];
         const int D = A.D, cols = 2 * D + 4;
-        const unsigned long long* acc = A.acc + (size_t)A.parity * FWG_ACC_SHARDS * A.acc_cols;
+        const size_t set_words = (size_t)FWG_ACC_SHARDS * A.acc_cols;
+        const unsigned long long* acc = A.acc + (size_t)(act_ctr % FWG_ACC_SETS) * set_words;
         float* tot = misc + 4;   // [cols] batch sums, column layout of fwgym_env.h
         if (tid < cols) {
             long long sum = 0;
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
                 rs = 1.f / sqrtf(v + A.eps);
             }
             mean_s[f] = m; rstd_s[f] = rs;
-            if (blockIdx.x == 0) { S1.mean[f] = m; S1.var[f] = v; }
+            if (first_block) { S1.mean[f] = m; S1.var[f] = v; }
         }
         if (tid == FWG_ACT_MAX_OBS) {
             float rm = S0.ret_mean, rv = S0.ret_var, rc = S0.ret_count;
@@ -367,13 +384,14 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
                 rc = tt;
             }
             misc[0] = 1.f / sqrtf(rv + A.eps);
-            if (blockIdx.x == 0) {
+            misc[1] = rm;
+            if (first_block) {
                 S1.count = S0.count + n_obs; S1.ret_mean = rm; S1.ret_var = rv; S1.ret_count = rc;
-                S1.act_counter = S0.act_counter + 1u;
+                S1.act_counter = act_ctr + 1u;
             }
         }
-        if (blockIdx.x == 0) {
-            unsigned long long* nxt = A.acc + (size_t)(A.parity ^ 1) * FWG_ACC_SHARDS * A.acc_cols;
+        if (first_block) {
+            unsigned long long* nxt = A.acc + (size_t)((act_ctr + 2u) % FWG_ACC_SETS) * set_words;
             for (int i = tid; i < FWG_ACC_SHARDS * A.acc_cols; i += 64 * FWG_ACT_WAVES) nxt[i] = 0ull;
         }
     }
@@ -405,7 +423,6 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     }
     FWG_ATL(A, 3);
     dma_wait();
-    __syncthreads();
     FWG_ATL(A, 4);
     // both networks in one instruction stream: their MFMA chains and tanh phases are independent and interleave
 #ifdef FWG_ABL_ACT_NO_MLP   // measurement only (tools/ablate.py)
@@ -417,28 +434,47 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
 #endif
     FWG_ATL(A, 5);
     const float res[2][FWG_ACT_MAX_ACT] = {{o_pi[0], o_pi[1], o_pi[2], o_pi[3]}, {o_vf[0], o_vf[1], o_vf[2], o_vf[3]}};
-    if (half == 0 && valid) {
+    if (half == 0) {
         float n[4] = {0.f, 0.f, 0.f, 0.f};
         if (!A.deterministic) {
             const u4 b = philox4x32((unsigned)(A.env_base + e), act_ctr, 0u, FWG_STREAM_POLICY, A.seed_lo, A.seed_hi);
             box_muller(b, n);
         }
-        float lp = 0.f;
+        float lp = 0.f, act[FWG_ACT_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < FWG_ACT_MAX_ACT; ++i) {
             if (i < A.act_dim) {
                 const float ls = ls_in[i];
-                if (A.action != nullptr) A.action[e * A.act_dim + i] = res[0][i] + expf(ls) * n[i];
+                act[i] = res[0][i] + expf(ls) * n[i];
+                if (A.action != nullptr && valid) A.action[e * A.act_dim + i] = act[i];
                 lp += -0.5f * n[i] * n[i] - ls - 0.9189385332046727f;
             }
         }
-        if (A.logp != nullptr) A.logp[e] = lp;
-        if (A.value != nullptr) A.value[e] = res[1][0];
-        if (A.norm_rew != nullptr && A.rew != nullptr)
-            A.norm_rew[e] = fminf(fmaxf(rew_in * misc[0], -A.clip_rew), A.clip_rew);
-        if (A.done_out != nullptr && A.done != nullptr) A.done_out[e] = done_in;
+        // (k_rollout) the env step of this same launch takes the actions from here
+        if (Z.act_out != nullptr) *reinterpret_cast<float4*>(Z.act_out + (wv * 32 + j) * 4) = make_float4(act[0], act[1], act[2], act[3]);
+        if (valid) {
+            if (A.logp != nullptr) A.logp[e] = lp;
+            if (A.value != nullptr) A.value[e] = res[1][0];
+            if (A.norm_rew != nullptr && A.rew != nullptr)
+                A.norm_rew[e] = fminf(fmaxf(rew_in * misc[0], -A.clip_rew), A.clip_rew);
+            if (A.done_out != nullptr && A.done != nullptr) A.done_out[e] = done_in;
+        }
     }
     FWG_ATL(A, 6);
+    return act_ctr;
+}
+
+template <int SPLIT, int NK1>
+__global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PARTS = SPLIT > 1 ? 2 : 1;
+    ActorLds Z;
+    Z.F = reinterpret_cast<frag_t*>(lds);
+    Z.mean_s = lds + actor_weight_floats(NK1, PARTS);
+    Z.rstd_s = Z.mean_s + FWG_ACT_MAX_OBS;
+    Z.misc = Z.rstd_s + FWG_ACT_MAX_OBS;
+    Z.act_out = nullptr;
+    actor_block<SPLIT, NK1>(A, Z, (long)blockIdx.x * FWG_ACT_ENVS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -37,7 +37,8 @@ struct KArgs {
     int log_wrap_now;                            // parity's wrap copy is due (host-computed; recomputed in graph mode)
     // attached rollout head (fwg_attach_observer): every wave also adds the moments of its 64 observation records and
     // discounted returns to the head's accumulators (acc_*), so the head needs no pass over the batch
-    unsigned long long* acc;                     // nullable [FWG_ACC_SHARDS][acc_cols] fixed-point sums
+    unsigned long long* acc;                     // nullable [3 sets][FWG_ACC_SHARDS][acc_cols] fixed-point sums (fwgym_actor.h)
+    const unsigned* acc_ctr;                     // the head's act counter: this launch adds into set *acc_ctr % 3
     const float* acc_mean;                       // running observation mean [obs_dim] the deviations are taken from
     const float* acc_ret_mean;                   // ... and the running mean of the returns
     float* acc_ret;                              // [N] discounted returns (VecNormalize.ret)
@@ -63,6 +64,7 @@ struct KArgs {
 #define FWG_ACC_SHARDS 16
 #endif
 #define FWG_ACC_SCALE 1048576.f
+#define FWG_ACC_SETS 3   /* accumulator sets, rotating with the head's act counter (fwgym_actor.h) */
 __host__ __device__ inline int acc_cols_for(int D) { return (2 * D + 4 + 31) & ~31; }   // whole 32-column chunks
 
 // value of lane (l ^ MASK)
@@ -262,7 +264,7 @@ __device__ __forceinline__ void log_wrap(const DevCfg& c, float* log, long N, lo
 
 // LDS carve (in floats) for one 64-lane block: the action windows (streamed in by global_load_lds) and, for the
 // generic (non-specialised) kernel only, the per-lane scratch tables that config-driven indices address
-struct LdsMap { int aring, cring, lag, stage, tab, obs, total; };
+struct LdsMap { int aring, cring, lag, stage, flag, tab, obs, total; };
 #define FWG_TAB_TGT FWG_N_VARS               // table rows: simulator variables | targets | target errors
 #define FWG_TAB_ERR (FWG_N_VARS + FWG_MAX_TARGETS)
 #define FWG_TAB_INT (FWG_N_VARS + 2 * FWG_MAX_TARGETS)   // ... | windowed error sums (integrator observations)
@@ -273,8 +275,9 @@ __host__ __device__ inline bool obs_vec4(int obs_dim) { return (obs_dim % 4 == 0
 __host__ __device__ inline int obs_stage_stride(int obs_dim) { return obs_vec4(obs_dim) ? obs_dim : (obs_dim | 1); }
 // k_step2 hand-off areas (per lane): new state, noise, actuator states.  They ALIAS the output staging area: every use of
 // the staging area comes after the physics wave's first hand-shake mark (FWG_FLAG_WAIT level 1: its hand-off areas are read),
-// every hand-off access before it; the pad word of lane 0's hand-off area IS that mark.  Workgroup residency is bounded by
-// LDS (4 workgroups per CU need <= 40 KiB each; a fifth area would cost a fourth of the chip).
+// every hand-off access before it.  The mark itself is a word of its OWN (LdsMap::flag, outside the staging area: the physics
+// wave raises it to 2 long after its partner may have begun staging output records, so it must not alias a staged value).
+// Workgroup residency is bounded by LDS (4 workgroups per CU need <= 40 KiB each; a fifth area would cost a fourth of the chip).
 #define FWG_HAND_WORDS 20   /* y[4..15] | roll pitch yaw Va alpha beta | failure code | pad: five 16-byte LDS accesses per lane */
 #define FWG_ACT_WORDS 12    /* actuator states at t + h/2 and t + h (2 x 5) | pad: three 16-byte LDS accesses per lane (FWG_EXT_ACTUATORS) */
 #define FWG_SPLIT_WORDS (FWG_HAND_WORDS + 4 + FWG_ACT_WORDS)
@@ -288,6 +291,7 @@ __host__ __device__ inline LdsMap lds_map(int obs_dim, int n_obs, int window, in
     m.lag = o; o += obs_log > 0 ? 0 : (rows - 1) * ng * 4 * FWG_WAVE;   // lagged records [row-1][group][lane][4] (dense batch only)
     const int stage = FWG_WAVE * obs_stage_stride(obs_dim), hand = split ? FWG_WAVE * FWG_SPLIT_WORDS : 0;
     m.stage = o; o += stage > hand ? stage : hand;         // [lane][obs_dim] staging of the output records
+    m.flag = o; o += split ? 4 : 0;                        // k_step2: the one-way hand-shake mark (one word used)
     m.tab = o; o += generic ? FWG_TAB_ROWS * FWG_WAVE : 0;
     m.obs = o; o += generic ? obs_dim * FWG_WAVE : 0;
     m.total = (o + 3) & ~3;
@@ -937,7 +941,8 @@ __device__ __forceinline__ void add_obs_noise(const DevCfg& c, const KArgs& A, l
 // the block in linear order, 1 KiB per store instruction (16 B per lane) when the record size allows.  `lanes` selects
 // the records to write (all, or the finished episodes for the terminal observations).  Must be called by all lanes.
 // The observation batch is never read back by the kernels: streaming (non-temporal) stores keep it from displacing the
-// state arena, which the next launch re-reads, out of the L2 / Infinity Cache.
+// state arena, which the next launch re-reads, out of the L2 / Infinity Cache -- unless a rollout head is attached (`reread`),
+// which reads exactly this batch in the very next launch: plain stores then.
 __device__ __forceinline__ void stream_store4(float4* p, float4 v) {
     fwg_v4f x;
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
@@ -949,7 +954,7 @@ template <int ROLE> __device__ __forceinline__ void obs_sync() {
 }
 template <int ROLE, class OB>
 __device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ out, long env0, long N, const OB& ob,
-                                          float* stage, int lane, unsigned long long lanes) {
+                                          float* stage, int lane, unsigned long long lanes, bool reread = false) {
     const int D = c.obs_dim;
     obs_sync<ROLE>();  // the staging area may still be read by a previous call
     if (obs_vec4(D)) {
@@ -964,7 +969,7 @@ __device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ o
 #pragma unroll 4
         for (int i = lane; i < total4; i += FWG_WAVE) {
             const int l = (4 * i) / D;
-            if (((lanes >> l) & 1ull) && env0 + l < N) stream_store4(o4 + i, all[i]);
+            if (((lanes >> l) & 1ull) && env0 + l < N) { if (reread) o4[i] = all[i]; else stream_store4(o4 + i, all[i]); }
         }
     } else {
         const int Ds = obs_stage_stride(D);

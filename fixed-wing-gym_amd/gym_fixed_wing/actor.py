@@ -153,6 +153,24 @@ class DeviceActor(object):
             return t if t.is_contiguous() else t.contiguous()
         return np.ascontiguousarray(t)
 
+    def rollout_available(self, vec):
+        """True when head + env step of `vec` can run as ONE launch (fwg_rollout_step): this head attached to it, a specialised
+        kernel, the dense observation batch."""
+        return bool(self._lib.fwg_rollout_available(vec._handle, self._handle))
+
+    def rollout_step(self, vec, norm_obs=None, action=None, value=None, logp=None, norm_reward=None, done_out=None,
+                     deterministic=False):
+        """act() on the observation `vec` currently shows (and the reward / done flags of the step that led to it), then
+        vec.step_device() under the sampled actions -- one launch (fwg_rollout_step; the body of the reference's training loop,
+        examples/train_rl_controller.py:223-231).  Outputs as act(); afterwards vec._obs / _rew / _done hold the new step."""
+        m = self._mem
+        nat.check(self._lib, self._lib.fwg_rollout_step(
+            vec._handle, self._handle, self._p(norm_obs), self._p(action), self._p(value), self._p(logp), self._p(norm_reward),
+            self._p(done_out), m.ptr(vec._obs_buf), m.ptr(vec._rew), m.ptr(vec._done), m.ptr(vec._term), m.ptr(vec._term_obs),
+            m.ptr(vec._metrics), int(bool(deterministic)), m.stream()))
+        self._observed = False
+        return vec._obs, vec._rew, vec._done
+
     def observe(self, obs, reward=None, done=None):
         """VecNormalize.step_wait bookkeeping for a new batch: moments of `obs` ([N, obs_dim] or [N, L, n]); with
         `reward`/`done` also the discounted returns.  The statistics change at the next act()."""

@@ -168,9 +168,13 @@ class FusedRollout(object):
     bootstrap value of the observation after the last step).  Per step: fwg_step (which also leaves the batch moments for
     the attached head) and fwg_actor_act --
     the act that follows step t writes the rollout slice t+1 directly, so nothing is copied except the carried-over
-    slice 0.  `graph=True` captures the whole rollout into one hipGraph (n_steps must be even)."""
+    slice 0.  `graph=True` captures the whole rollout into one hipGraph (n_steps must be even).
 
-    def __init__(self, vec, actor, n_steps, graph=False):
+    `fused` (default: whenever fwg_rollout_available): act t and env step t run as ONE launch (fwg_rollout_step) -- a rollout is
+    then [env step 0] [act + step] x (n - 1) [act n]: n + 1 launches instead of 2 n, bit-identical buffers.  `tap(t, obs, rew,
+    done)` (eager mode only) is called after every env step with the env's raw output tensors (tests, logging)."""
+
+    def __init__(self, vec, actor, n_steps, graph=False, fused=None, tap=None):
         self.vec, self.actor, self.n_steps = vec, actor, int(n_steps)
         m, N, D, A = vec._mem, vec.num_envs, vec.obs_dim, actor.act_dim
         self.buf = {"obs": m.zeros((n_steps, N, D)), "actions": m.zeros((n_steps, N, A)), "values": m.zeros((n_steps, N)),
@@ -188,6 +192,14 @@ class FusedRollout(object):
             actor.attach(vec)
         else:
             actor.set_obs_log(vec)
+        can_fuse = self._attached and hasattr(actor, "rollout_available") and actor.rollout_available(vec)
+        if fused and not can_fuse:
+            raise ValueError("FusedRollout(fused=True): fwg_rollout_step is not available for this env / head (needs a specialised "
+                             "kernel, the dense observation batch and an attached head)")
+        # (FWGYM_ROLLOUT_FUSED=0: A/B measurements of the two-launch step against the one-launch step)
+        import os
+        self.fused = (can_fuse and os.environ.get("FWGYM_ROLLOUT_FUSED", "1") != "0") if fused is None else bool(fused)
+        self.tap = tap
         if graph:
             self._capture()
 
@@ -211,11 +223,28 @@ class FusedRollout(object):
 
     def _body(self):
         buf, cur, n = self.buf, self.cur, self.n_steps
+        vec, actor = self.vec, self.actor
+        tap = self.tap if self._graph is None and not getattr(self, "_capturing", False) else None
         for k in ("obs", "actions", "values", "logp"):
             buf[k][0][...] = cur[k]
+        if self.fused:
+            # env step 0 under the carried-over actions; then [act t + env step t] in one launch each; then act n
+            o, r, d = vec.step_device(buf["actions"][0])
+            if tap is not None:
+                tap(0, o, r, d)
+            for t in range(1, n):
+                o, r, d = actor.rollout_step(vec, norm_obs=buf["obs"][t], action=buf["actions"][t], value=buf["values"][t],
+                                             logp=buf["logp"][t], norm_reward=buf["rewards"][t - 1], done_out=buf["dones"][t - 1])
+                if tap is not None:
+                    tap(t, o, r, d)
+            actor.act(o, reward=r, done=d, norm_obs=cur["obs"], action=cur["actions"], value=cur["values"], logp=cur["logp"],
+                      norm_reward=buf["rewards"][n - 1], done_out=buf["dones"][n - 1])
+            return
         for t in range(n):
             nxt = cur if t == n - 1 else {k: buf[k][t + 1] for k in cur}
             self._step(buf["actions"][t], nxt, buf["rewards"][t], buf["dones"][t])
+            if tap is not None:
+                tap(t, self.vec._obs, self.vec._rew, self.vec._done)
 
     def _capture(self):
         import torch
@@ -226,16 +255,25 @@ class FusedRollout(object):
         self._prime()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):   # warm-up outside capture
-            self._step(self.cur["actions"], self.cur)
-            self._step(self.cur["actions"], self.cur)
+        with torch.cuda.stream(side):   # warm-up outside capture: two env steps, every kernel of the body launched once
+            if self.fused:
+                c = self.cur
+                vec.step_device(c["actions"])
+                o, r, d = self.actor.rollout_step(vec, norm_obs=c["obs"], action=c["actions"], value=c["values"], logp=c["logp"])
+                self.actor.act(o, reward=r, done=d, norm_obs=c["obs"], action=c["actions"], value=c["values"], logp=c["logp"])
+            else:
+                self._step(self.cur["actions"], self.cur)
+                self._step(self.cur["actions"], self.cur)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self._graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph()
         self._parity = vec.capture_begin()
-        with torch.cuda.graph(self._graph):
+        self._capturing = True
+        with torch.cuda.graph(graph):
             self._body()
+        self._capturing = False
         vec.capture_end()
+        self._graph = graph
 
     def run(self):
         self._prime()

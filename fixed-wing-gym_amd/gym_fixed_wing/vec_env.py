@@ -387,6 +387,13 @@ class FixedWingVecEnv(object):
         success sums): fwg_finish_episodes, one small launch, stream-ordered.  The step itself only parks the accumulators."""
         nat.check(self._lib, self._lib.fwg_finish_episodes(self._handle, self._mem.ptr(self._metrics), self._mem.stream()))
 
+    def metrics(self):
+        """Device tensor [N_METRICS, N] of the episodic metrics, valid for every env that has reported done: collects the
+        finished-episode records first (fwg_step itself only parks them, so reading `_metrics` right after a step would show
+        the previous episode's column or NaN).  Stream-ordered, no synchronisation."""
+        self.finish_episodes()
+        return self._metrics
+
     def _host(self, name, t):
         cache = self.__dict__.setdefault("_host_cache", {})
         key = (name, int(self._lib.fwg_global_step(self._handle)))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 18
+#define FWG_ABI_VERSION 19
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -297,7 +297,11 @@ int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const
  *   term_code_out    : uint8 [N]  FWG_TERM_*
  *   terminal_obs_out : NULL or float32 [N][obs_dim]; written for done envs only (VecEnv "terminal_observation")
  *   metrics_out      : NULL or float32 [FWG_N_METRICS][N]; written for done envs, by the NEXT fwg_finish_episodes /
- *                      fwg_reduce_success* call (the step itself only records the episode's accumulators)
+ *                      fwg_reduce_success* call (the step itself only records the episode's accumulators).  LIFETIME: the
+ *                      pointer of the LAST fwg_step is remembered and written through by fwg_reduce_success* -- keep the
+ *                      buffer alive (or pass the same one every step) until the next collection; readers on the device
+ *                      must order themselves after fwg_finish_episodes, not after fwg_step.  An env that ends two episodes
+ *                      between collections keeps only the later one's column (both count in the success sums)
  *   target_out       : NULL or float32 [N][n_targets] = info["target"] (fixed_wing.py:435) after the step */
 int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_out, uint8_t* done_out,
              uint8_t* term_code_out, float* terminal_obs_out, float* metrics_out, float* target_out, void* stream);
@@ -361,7 +365,10 @@ int fwg_note_replayed_steps(fwg_handle* h, int64_t n_steps);
 /* A captured sequence has the double-buffer copy its first launch reads baked in: it may only be replayed when the step
  * counter has the parity it had at fwg_capture_begin.  fwg_capture_parity: that parity (0 / 1) for the capture just
  * bracketed; fwg_replay_check: FWG_ERR_INVALID unless the handle's current step count has parity `capture_parity` -- call
- * it before every replay (host-only, no synchronisation). */
+ * it before every replay (host-only, no synchronisation).  With simulator.model / reward.randomize_scaling the captured
+ * sequence is also tied to the configuration generation: fwg_capture_begin fails while every per-env parameter set is stale
+ * (right after fwg_create / fwg_update_config / fwg_seed: issue fwg_reset or two direct steps first) and fwg_replay_check
+ * fails for a sequence captured before the last fwg_update_config / fwg_seed (capture again). */
 int fwg_capture_parity(const fwg_handle* h);
 int fwg_replay_check(const fwg_handle* h, int capture_parity);
 
@@ -425,6 +432,24 @@ int fwg_actor_observe(fwg_actor* a, const float* obs, const float* reward, const
 int fwg_actor_act(fwg_actor* a, const float* obs, const float* reward, const uint8_t* done, float* norm_obs_out,
                   float* action_out, float* value_out, float* logp_out, float* norm_reward_out, uint8_t* done_out,
                   int deterministic, void* stream);
+
+/* One rollout step in ONE launch: the head on the observation the env currently shows, then the env step under the actions
+ * just sampled -- the body of the reference's training loop, VecNormalize(SubprocVecEnv).step_wait inside PPO2's runner
+ * (examples/train_rl_controller.py:223-231), without a launch boundary between policy and env.  Equivalent to
+ *     fwg_actor_act(head, obs_io, reward_io, done_io, norm_obs_out, action_out, value_out, logp_out, norm_reward_out,
+ *                   done_prev_out, deterministic, stream);
+ *     fwg_step(env, action_out, obs_io, reward_io, done_io, term_code_out, terminal_obs_out, metrics_out, NULL, stream);
+ * bit for bit.  obs_io / reward_io / done_io are IN-OUT: on entry what the env's previous step (or fwg_reset, with
+ * reward_io / done_io zeroed) left there, on return this step's results; the four head outputs describe the observation on
+ * entry, norm_reward_out / done_prev_out the transition that led to it (each may be NULL).  Needs `head` attached to `env`
+ * (fwg_attach_observer: the step phase leaves the batch moments for the NEXT head) and a configuration
+ * fwg_rollout_available() accepts: a build-time / run-time specialised kernel, dense observation batch (no row log), no
+ * per-env aircraft parameters; callers fall back to the two calls above otherwise.  Counts as one fwg_step and one
+ * fwg_actor_act for the hipGraph rules (even numbers per captured sequence). */
+int fwg_rollout_available(const fwg_handle* env, const fwg_actor* head);
+int fwg_rollout_step(fwg_handle* env, fwg_actor* head, float* norm_obs_out, float* action_out, float* value_out, float* logp_out,
+                     float* norm_reward_out, uint8_t* done_prev_out, float* obs_io, float* reward_io, uint8_t* done_io,
+                     uint8_t* term_code_out, float* terminal_obs_out, float* metrics_out, int deterministic, void* stream);
 
 /* Global step counter driving the ring slots (diagnostics/tests). */
 int64_t fwg_global_step(const fwg_handle* h);

@@ -52,8 +52,22 @@ def close(a, b, rtol, atol, what):
     return float(err.max()) if err.size else 0.0
 
 
+def check_derived_views(vec, oracles, what, atol=2e-3):
+    """The host views of the derived variables (field('roll') ..., written by store_sim with derived_views=True -- what PID
+    / host controllers and the single-env facade read) against the oracle envs' current simulator state."""
+    for name in ("roll", "pitch", "Va", "alpha"):
+        got = _np(vec.field(name)).astype(np.float64)
+        want = np.array([o.simulator.state[name].value for o in oracles], dtype=np.float64)
+        d = got - want
+        if name == "roll":
+            d = (d + np.pi) % (2 * np.pi) - np.pi
+        if np.abs(d).max() > atol:
+            i = int(np.argmax(np.abs(d)))
+            raise Mismatch("{}: derived view {} of env {}: got {!r} want {!r}".format(what, name, i, got[i], want[i]))
+
+
 def run_gym_parity(vec, oracles, n_steps, action_fn, rtol=2e-3, atol=2e-3, check_metrics=True, reset_kw=None,
-                   metric_rtol=None, log=None):
+                   metric_rtol=None, log=None, check_views=False):
     """Free-running comparison over n_steps.  `action_fn(t) -> float32 [N,3]`.  Oracle envs are reset by hand when
     done (the VecEnv auto-resets).  Returns summary statistics."""
     N = vec.num_envs
@@ -111,6 +125,8 @@ def run_gym_parity(vec, oracles, n_steps, action_fn, rtol=2e-3, atol=2e-3, check
         if tgt is not None:
             worst["target"] = max(worst["target"], close(tgt, w_tgt, rtol, atol, "step {} target".format(t)))
         worst["obs"] = max(worst["obs"], close(obs.reshape(N, -1), np.stack(w_obs).reshape(N, -1), rtol, atol, "step {} obs".format(t)))
+        if check_views and (done.any() or t % 16 == 0):   # (after an auto-reset: the NEW episode's initial state)
+            check_derived_views(vec, oracles, "step {}".format(t), max(atol, 2e-3))
         if log is not None and t % 20 == 0:
             log("step {} worst {}".format(t, worst))
     worst["episodes"] = episodes

@@ -193,7 +193,9 @@ def test_two_wave_kernel_through_foreseen_episode_ends_emulated():
     assert vec.spec_index == 0 and vec.obs_log_rows == presets.OBS_LOG_ROWS
     orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
     acts = _actions(7, steps, n)
-    res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3)
+    # (check_views: the derived host views -- field('roll') ... -- must show the NEW episode's state after a foreseen
+    # auto-reset whose rows the physics wave installs itself)
+    res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3, check_views=True)
     assert res["episodes"] >= 4 * n
     vec.close()
 

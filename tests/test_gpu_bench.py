@@ -38,3 +38,28 @@ def test_bench_through_torchrun_with_rccl():
     assert out.returncode == 0, out.stderr[-3000:]
     j = _last_json(out.stdout)
     assert j["n_gpus"] == 1 and j["value"] > 1e9
+
+
+def test_bench_line_carries_the_rollout_figure():
+    """BASELINE configs[4] (the PPO rollout loop) rides in the default line as `c5` (+ `c5_bf16`)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = _last_json(out.stdout)
+    for k in ("c5", "c5_bf16", "steady_state", "c2"):
+        assert k in j and "error" not in j[k], (k, j.get(k))
+    assert j["c5"]["value"] > 1.5e9 and j["c5"]["launches_per_step"] == 1 and j["rccl_ranks"] is None
+
+
+def test_two_rank_rccl_smoke():
+    """Two ranks, one GPU each, RCCL all-gather of the success vector: only where the box has two GPUs (the driver's 8-GPU node);
+    skips cleanly on the single-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "256", "--warmup", "20",
+                          "--no-cpu-baseline", "--no-side"], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = _last_json(out.stdout)
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["config"]["total_envs"] == 2 * 65536 and j["value"] > 2e9

@@ -103,7 +103,7 @@ def test_running_statistics_survive_graph_replay():
     np.testing.assert_allclose(float(ret.var), allx[:, 0].var(), rtol=2e-3)
 
 
-def _fused_vs_torch(vec, mk_actor, n_steps, graph=False):
+def _fused_vs_torch(vec, mk_actor, n_steps, graph=False, fused=None):
     """The fused rollout against the plain-torch formulation (VecNormalizeDevice + MlpPolicy) driven with the SAME
     actions: normalised observations/rewards, values and log-probabilities of every stored transition."""
     import math
@@ -121,12 +121,15 @@ def _fused_vs_torch(vec, mk_actor, n_steps, graph=False):
 
     def spy(a, want_obs=True):
         o, r, d = orig(a)   # always with the observation: row-log envs hand out the window view here
-        if not graph:
-            raw.append((np.array(_to_np(o)), np.array(_to_np(r)), np.array(_to_np(d))))
         return o, r, d
     vec.step_device = spy
     obs0 = np.array(_to_np(vec._obs))
-    ro = FusedRollout(vec, actor, n_steps, graph=graph)
+
+    def tap(t, o, r, d):   # (fused launch: the env step happens inside fwg_rollout_step, not through step_device)
+        if len(raw) <= t:
+            raw.append((np.array(_to_np(o)).reshape(N, -1), np.array(_to_np(r)), np.array(_to_np(d))))
+    ro = FusedRollout(vec, actor, n_steps, graph=graph, fused=fused, tap=None if graph else tap)
+    assert fused is None or ro.fused == fused
     buf = {k: np.array(_to_np(v)) for k, v in ro.run().items()}
     last_value = np.array(_to_np(ro.last_value))
     vec.step_device = orig
@@ -290,3 +293,123 @@ def test_actor_reads_the_row_log_window_in_place_on_gpu():
             for u, v in zip(x[:3], y[:3]):
                 assert torch.equal(u, v), "step {}".format(t)
     vec.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# head + env step in ONE launch (fwg_rollout_step / k_rollout)
+# ----------------------------------------------------------------------------------------------------------------------
+def _rollouts(vec_factory, fused, n_steps, reps, graph=False, seed=5):
+    """`reps` consecutive rollouts of a fresh env under a fresh head; every buffer of every rollout + the final statistics."""
+    from gym_fixed_wing.actor import DeviceActor
+    from gym_fixed_wing.rollout import FusedRollout
+    vec = vec_factory()
+    vec.reset()
+    torch.manual_seed(0)
+    policy = MlpPolicy(vec.obs_dim)
+    with torch.no_grad():
+        policy.log_std.copy_(torch.tensor([-1.0, -0.7, -1.2]))
+    actor = DeviceActor.for_env(vec, seed=seed)
+    actor.load_policy(policy)
+    ro = FusedRollout(vec, actor, n_steps, graph=graph, fused=fused)
+    assert ro.fused == fused
+    out = []
+    for _ in range(reps):
+        buf = ro.run()
+        out.append({k: np.array(_to_np(v)) for k, v in buf.items()})
+        out[-1]["last_value"] = np.array(_to_np(ro.last_value))
+    st = actor.get_stats()
+    state = np.array(_to_np(vec.state))
+    obs = np.array(_to_np(vec._obs))
+    actor.close()
+    vec.close()
+    return out, st, state, obs
+
+
+def _assert_same_rollouts(a, b):
+    (ra, sa, xa, oa), (rb, sb, xb, ob) = a, b
+    for rep, (u, v) in enumerate(zip(ra, rb)):
+        for k in u:
+            np.testing.assert_array_equal(u[k], v[k], err_msg="rollout {} {}".format(rep, k))
+    for k in sa:
+        np.testing.assert_array_equal(np.asarray(sa[k]), np.asarray(sb[k]), err_msg="statistics " + k)
+    np.testing.assert_array_equal(oa, ob)
+    np.testing.assert_array_equal(xa, xb)   # the whole state arena
+
+
+def test_fused_launch_equals_two_launches_emulated():
+    """fwg_rollout_step (head + env step in one launch, k_rollout) == fwg_actor_act followed by fwg_step, bit for bit: rollout
+    buffers, running statistics, the env's state arena.  70 envs = one workgroup of the fused kernel with two 64-env groups,
+    the second partly out of range, the other two entirely; steps_max 9 puts episode ends (metrics record, auto-reset, terminal
+    observation) inside the fused launches."""
+    from emu.host_backend import HostBackend, build_emu_spec
+    from gym_fixed_wing.config import EnvConfig
+    import copy
+    cfg = configs.reference_like("examples")
+    ckw = {"steps_max": 9}
+    lib = build_emu_spec(EnvConfig(copy.deepcopy(cfg), config_kw=copy.deepcopy(ckw)), auto_reset=True, store_derived=False)
+
+    def mk():
+        return FixedWingVecEnv(copy.deepcopy(cfg), num_envs=70, config_kw=copy.deepcopy(ckw), as_numpy=True, _backend=HostBackend(),
+                               _lib_path=lib, derived_views=False, seed=3)
+    two = _rollouts(mk, False, 12, 2)
+    one = _rollouts(mk, True, 12, 2)
+    _assert_same_rollouts(one, two)
+    assert sum(int(r["dones"].sum()) for r in one[0]) >= 2 * 70
+
+
+def test_fused_launch_matches_torch_emulated():
+    """... and against the plain-torch formulation (VecNormalizeDevice + MlpPolicy) on the raw env outputs of every step."""
+    from emu.host_backend import HostBackend, build_emu_spec
+    from gym_fixed_wing.actor import DeviceActor
+    from gym_fixed_wing.config import EnvConfig
+    import copy
+    cfg = configs.reference_like("examples")
+    ckw = {"steps_max": 9}
+    lib = build_emu_spec(EnvConfig(copy.deepcopy(cfg), config_kw=copy.deepcopy(ckw)), auto_reset=True, store_derived=False)
+    vec = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=70, config_kw=copy.deepcopy(ckw), as_numpy=True, _backend=HostBackend(),
+                          _lib_path=lib, derived_views=False)
+    vec.reset()
+    buf = _fused_vs_torch(vec, lambda v: DeviceActor.for_env(v, seed=5), 12, fused=True)
+    assert buf["dones"].sum() == 70
+
+
+@pytest.mark.gpu
+def test_fused_launch_equals_two_launches_on_gpu():
+    """The C5 workload's configuration (a build-time preset) at 65 536 envs and at a batch that is not a multiple of the fused
+    kernel's 256 envs per workgroup: eager rollouts and replayed hipGraphs of the one-launch step == the two-launch step."""
+    cfg = configs.reference_like("examples")
+    for n, steps, reps, graph in ((65536, 16, 2, False), (4096 + 37, 32, 2, False), (65536, 16, 3, True)):
+        def mk():
+            return FixedWingVecEnv(cfg, num_envs=n, device=0, derived_views=False, seed=2)
+        two = _rollouts(mk, False, steps, reps, graph=graph)
+        one = _rollouts(mk, True, steps, reps, graph=graph)
+        _assert_same_rollouts(one, two)
+
+
+@pytest.mark.gpu
+def test_fused_launch_through_episode_ends_on_gpu():
+    """Episode ends inside the fused launches (time limit at 20 steps: synchronised ends of all envs, then scattered failure ends
+    under the random-init policy), run-time specialised kernel."""
+    import copy
+    from gym_fixed_wing import jit
+    cfg = configs.reference_like("examples")
+    ckw = {"steps_max": 20}
+    if jit.prebuild(copy.deepcopy(cfg), copy.deepcopy(ckw), None, derived_views=False) is None:
+        pytest.skip("hipcc not available for the run-time specialisation")
+
+    def mk():
+        return FixedWingVecEnv(copy.deepcopy(cfg), num_envs=4096, device=0, config_kw=copy.deepcopy(ckw), derived_views=False, seed=2,
+                               specialize=True)
+    two = _rollouts(mk, False, 32, 2)
+    one = _rollouts(mk, True, 32, 2)
+    _assert_same_rollouts(one, two)
+    assert sum(int(r["dones"].sum()) for r in one[0]) >= 3 * 4096
+
+
+@pytest.mark.gpu
+def test_fused_launch_matches_torch_on_gpu():
+    from gym_fixed_wing.actor import DeviceActor
+    cfg = configs.reference_like("examples")
+    vec = FixedWingVecEnv(cfg, num_envs=4096, device=0, derived_views=False)
+    vec.reset()
+    _fused_vs_torch(vec, lambda v: DeviceActor.for_env(v, seed=5), 32, fused=True)

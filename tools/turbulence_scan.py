@@ -31,6 +31,13 @@ Variant tokens (joined with '+'):
   statespace                    the oracle's streaming joint filter with the product's Philox stream (what the kernels run;
                                 turbulence_output as in sim_config.json unless `filter` / `increment` is given)
   P_<name>=<v>                  aircraft parameter override
+  wind=<k>                      SCENARIO side (round 4): a steady wind of magnitude k x W20 (the intensity's wind speed at 20 ft,
+                                15 / 30 / 45 kt) in a random horizontal direction per episode is written into the scenario's
+                                state["wind_n/e/d"] (get_initial_state, fixed_wing.py:848-862, records them) WITHOUT re-deriving the
+                                body velocities: the initial airspeed vector is off by the wind.  (Re-deriving them is exactly the
+                                no-wind episode: d/dt(v - R'w) = -omega x (v - R'w) + f/m, a steady wind drops out of the dynamics.)
+  wind3d                        ... direction uniform on the sphere instead of horizontal
+  windabs=<m/s>                 ... magnitude in m/s whatever the intensity
 
 Usage: python tools/turbulence_scan.py --intensity severe --variants base,scale=2 [--seeds 1] [--jobs 8]
 CPU only; ~1 min per variant and intensity on 8 cores."""
@@ -166,6 +173,19 @@ def fly(args):
                           sim_config_path=sp, sim_parameter_path=pp)
     env.simulator.seed(seed)
     env.simulator.env_id = seed & 0xFFFF
+    if "wind" in v or "windabs" in v:   # scenario-side steady wind (see the module docstring)
+        w20 = {"none": 0.0, "light": 15.0, "moderate": 30.0, "severe": 45.0}[intensity] * 0.514444
+        mag = v["windabs"] if "windabs" in v else v["wind"] * w20
+        rs = np.random.RandomState(777 + seed)
+        if v.get("wind3d"):
+            d = rs.standard_normal(3)
+            d /= np.linalg.norm(d)
+        else:
+            psi = rs.uniform(0, 2 * np.pi)
+            d = np.array([np.cos(psi), np.sin(psi), 0.0])
+        st = dict(sc["state"])
+        st["wind_n"], st["wind_e"], st["wind_d"] = (float(mag * d[0]), float(mag * d[1]), float(mag * d[2]))
+        sc = {"state": st, "target": sc["target"]}
     obs = env.reset(state=sc["state"], target=sc["target"])
     pid = ss.VariantPID(env.simulator.dt)
     pid.set_reference(sc["target"]["roll"], sc["target"]["pitch"], sc["target"]["Va"])
@@ -205,6 +225,9 @@ def distance(ours, pub):
         if key in ours["buckets"] and key in pub["buckets"]:
             terms["rew_" + key] = (ours["buckets"][key]["mean"] - pub["buckets"][key]["mean"]) / (0.3 * abs(pub["buckets"][key]["mean"]))
     terms["timeout"] = (ours["length"]["timeout_%"] - pub["length"]["timeout_%"]) / 5.0
+    for k in ("d5_std", "d10_std", "d20_std"):   # spread of the reward change over the first steps (x3.8 at severe in the published traces)
+        if k in ours.get("early", {}) and k in pub.get("early", {}):
+            terms["early_" + k[:-4]] = (ours["early"][k] - pub["early"][k]) / (0.3 * pub["early"][k] + 0.003)
     jo, jp = ours["jitter"].get("30-130"), pub["jitter"].get("30-130")
     if jo and jp:
         terms["jit_lag1"] = (jo["lag1"] - jp["lag1"]) / 0.1
