@@ -84,13 +84,15 @@ struct NoHeadStats { static constexpr bool enabled = false; const float* mean = 
 struct HeadStats { static constexpr bool enabled = true; const float* mean; float ret_mean; unsigned ctr; };
 template <class OB, class HS = NoHeadStats>
 __device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, const OB& ob, float reward, bool done, bool valid,
-                                             int lane, long e, int sub, const HS& hs = HS()) {
+                                             int lane, long e, int sub, float ret_prev, const HS& hs = HS()) {
 #ifndef FWG_ABL_NO_ACC
     const int D = c.obs_dim;
     // VecNormalize.step_wait: ret = ret * gamma + r; ret_rms.update(ret); ret[done] = 0
+    // (ret_prev = A.acc_ret[e], requested with the bookkeeping rows: a load issued HERE, after the step's stores, would sit
+    // through the acknowledgement of every one of them -- 3-4k ticks at the end of every wave, tools/timeline_rollout.py)
     float dr = 0.f;
     if (valid) {
-        const float r = A.acc_ret[e] * A.acc_gamma + reward;
+        const float r = ret_prev * A.acc_gamma + reward;
         A.acc_ret[e] = done ? 0.f : r;
         dr = r - (HS::enabled ? hs.ret_mean : *(FWG_KCONST(float)*)A.acc_ret_mean);
     }
@@ -247,6 +249,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             for (int i = 0; i < 6; ++i) gust[i] *= E.gust_gain;
         }
     }
+    float ret_prev = 0.f;
     float4 act_q3 = make_float4(0.f, 0.f, 0.f, 0.f), act_q4 = act_q3;
     if (SPLIT && GYM && ext_act) {   // y[12..15] | y[16], y[17], ...: the actuator part of the simulator rows
         act_q3 = load_group(A.S, A.N, (L.sim >> 2) + 3, e);
@@ -257,6 +260,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
         // order = order of need (returns are in order): bookkeeping rows, action windows, lagged observation rows
         load_gym(c, A.S, A.N, e, E, A.bit_goal);
+        if (A.acc != nullptr && valid) ret_prev = A.acc_ret[e];   // attached rollout head: the env's discounted return so far
         for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.act_ring >> 2) + s, e), lds + M.aring + s * (4 * FWG_WAVE));
         if (c.use_cmd_ring)
             for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
@@ -791,7 +795,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     const unsigned long long done_mask = __ballot(done && valid);
     // waves in which no episode ends have their final observation records here: the moments for an attached rollout head
     // go out before the remaining stores, whose issue then hides the round trip of the atomics
-    if (A.acc != nullptr && done_mask == 0ull) step_moments(c, A, ob, reward, done, valid, lane, e, sub, hs);
+    if (A.acc != nullptr && done_mask == 0ull) step_moments(c, A, ob, reward, done, valid, lane, e, sub, ret_prev, hs);
     // hand-shake B: the output staging area aliases the hand-off areas (first mark, raised right after barrier A), and an env
     // that is re-initialised HERE has rows the physics wave wrote in this launch (second mark: they are in memory).  A
     // foreseen end whose new episode the partner installs needs neither acknowledgement
@@ -857,7 +861,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         }
     }
 
-    if (A.acc != nullptr && done_mask != 0ull) step_moments(c, A, ob, reward, done, valid, lane, e, sub, hs);
+    if (A.acc != nullptr && done_mask != 0ull) step_moments(c, A, ob, reward, done, valid, lane, e, sub, ret_prev, hs);
     FWG_TL(A, 8);
     // ---- phase F: outputs and the state write-back
 #ifndef FWG_ABL_NO_OBSWRITE
@@ -930,9 +934,12 @@ __global__ __launch_bounds__(2 * FWG_RO_ENVS, 2) void k_rollout(const DevCfg* __
     Z.mean_s = lds + shared;
     Z.rstd_s = Z.mean_s + FWG_ACT_MAX_OBS;
     Z.misc = Z.rstd_s + FWG_ACT_MAX_OBS;
+    Z.bias = Z.misc + 4 + 2 * FWG_ACT_MAX_OBS + 4;
     Z.act_out = lds + shared + actor_scratch_floats();
     const unsigned act_ctr = actor_block<HSPLIT, NK1>(AA, Z, (long)blockIdx.x * FWG_RO_ENVS);
-    __syncthreads();   // actions and statistics are in LDS; the weights are dead: their area becomes the step areas
+    // actions and statistics are in LDS; the weights are dead: their area becomes the step areas.  (LDS-only barrier: a
+    // __syncthreads() would also sit through the acknowledgement of the head's output stores, 2-3k ticks)
+    FWG_BLOCK_SYNC_LDS();
     const int wave = threadIdx.x >> 6, group = wave & (FWG_RO_GROUPS - 1);
     const int sub = (int)blockIdx.x * FWG_RO_GROUPS + group;
     const HeadStats hs{Z.mean_s, Z.misc[1], act_ctr + 1u};
@@ -1826,7 +1833,9 @@ static void launch_one(const fwg_handle* h, const KArgs& A, hipStream_t stream) 
             return;
         }
 #endif
+#ifndef FWG_DEV_FAST_BUILD   /* tools/isa.py -DFWG_DEV_FAST_BUILD: only the two-wave / fused kernels of the frozen configuration */
         hipLaunchKernelGGL((k_step<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
+#endif
     } else hipLaunchKernelGGL((k_reset<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
 }
 
@@ -1838,8 +1847,10 @@ static void launch(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
         FWG_SPEC_LIST(FWG_SPEC_CASE)
         default: break;
     }
+#ifndef FWG_DEV_FAST_BUILD
     if (h->h.turbulence) launch_one<IS_STEP, true, -1>(h, A, stream);
     else launch_one<IS_STEP, false, -1>(h, A, stream);
+#endif
 }
 
 // =====================================================================================================================
@@ -1857,6 +1868,7 @@ struct fwg_actor {
     unsigned long long* d_acc;   // [FWG_ACC_SETS][FWG_ACC_SHARDS][acc_cols] fixed-point batch moments (rotation: fwgym_actor.h)
     int acc_cols;
     frag_t* d_frags;
+    float* d_bias;         // [2][FWG_ACT_BIAS_FLOATS]
     float* d_log_std;
     float* d_ret;
     size_t lds_act[2];     // dynamic LDS of k_actor_act<1>, <3>
@@ -1867,14 +1879,13 @@ struct fwg_actor {
 };
 
 static size_t actor_lds_bytes(int nk1, int parts) {
-    return (size_t)2 * parts * actor_frags(nk1) * 64 * sizeof(frag_t) +
-           (2 * FWG_ACT_MAX_OBS + 4 + 2 * FWG_ACT_MAX_OBS + 4) * sizeof(float);
+    return (size_t)(actor_weight_floats(nk1, parts) + actor_scratch_floats()) * sizeof(float);
 }
 
 static ActorArgs actor_args(const fwg_actor* a) {
     ActorArgs A;
     memset(&A, 0, sizeof(A));
-    A.ret = a->d_ret; A.stats = a->d_stats; A.frags = a->d_frags; A.log_std = a->d_log_std;
+    A.ret = a->d_ret; A.stats = a->d_stats; A.frags = a->d_frags; A.bias = a->d_bias; A.log_std = a->d_log_std;
     A.acc = a->d_acc; A.acc_cols = a->acc_cols;
     A.N = (long)a->n_envs; A.env_base = (long)a->env_base;
     A.D = a->D; A.nk1 = a->nk1; A.act_dim = a->act_dim; A.parity = a->parity; A.training = a->training;
@@ -1946,6 +1957,8 @@ int fwg_actor_create(int device, int64_t n_envs, int obs_dim, int act_dim, float
     HIP_TRY(hipMalloc((void**)&a->d_acc, acc_bytes));
     HIP_TRY(hipMemset(a->d_acc, 0, acc_bytes));
     HIP_TRY(hipMalloc((void**)&a->d_frags, nfrag * sizeof(frag_t)));
+    HIP_TRY(hipMalloc((void**)&a->d_bias, 2 * FWG_ACT_BIAS_FLOATS * sizeof(float)));
+    HIP_TRY(hipMemset(a->d_bias, 0, 2 * FWG_ACT_BIAS_FLOATS * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&a->d_log_std, FWG_ACT_MAX_ACT * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&a->d_ret, (size_t)n_envs * sizeof(float)));
     HIP_TRY(hipMemset(a->d_frags, 0, nfrag * sizeof(frag_t)));
@@ -1973,7 +1986,7 @@ int fwg_actor_create(int device, int64_t n_envs, int obs_dim, int act_dim, float
 
 void fwg_actor_destroy(fwg_actor* a) {
     if (!a) return;
-    (void)hipFree(a->d_stats); (void)hipFree(a->d_acc); (void)hipFree(a->d_frags); (void)hipFree(a->d_log_std); (void)hipFree(a->d_ret);
+    (void)hipFree(a->d_stats); (void)hipFree(a->d_acc); (void)hipFree(a->d_frags); (void)hipFree(a->d_bias); (void)hipFree(a->d_log_std); (void)hipFree(a->d_ret);
     delete a;
 }
 
@@ -1984,18 +1997,21 @@ int fwg_actor_set_weights(fwg_actor* a, const fwg_actor_weights* w) {
     for (const float* p : need) if (!p) return fail_with(FWG_ERR_INVALID, "fwg_actor_set_weights: null weight array");
     HIP_TRY(hipSetDevice(a->device));
     std::vector<unsigned> all;
+    std::vector<float> biases;
     for (int net = 0; net < 2; ++net) {
         std::vector<unsigned> hi, lo;
         const float* w0 = net ? w->vf_w0 : w->pi_w0; const float* b0 = net ? w->vf_b0 : w->pi_b0;
         const float* w1 = net ? w->vf_w1 : w->pi_w1; const float* b1 = net ? w->vf_b1 : w->pi_b1;
         const float* w2 = net ? w->vf_w2 : w->pi_w2; const float* b2 = net ? w->vf_b2 : w->pi_b2;
         const int out = net ? 1 : a->act_dim;
-        actor_pack_layer(hi, lo, w0, b0, 64, a->D, 2, a->nk1, false, FWG_ACT_PRESCALE);
-        actor_pack_layer(hi, lo, w1, b1, 64, 64, 2, 4, true, FWG_ACT_PRESCALE);
-        actor_pack_layer(hi, lo, w2, b2, out, 64, 1, 4, true, 1.f);
+        actor_pack_layer(hi, lo, w0, 64, a->D, 2, a->nk1, false, FWG_ACT_PRESCALE);
+        actor_pack_layer(hi, lo, w1, 64, 64, 2, 4, true, FWG_ACT_PRESCALE);
+        actor_pack_layer(hi, lo, w2, out, 64, 1, 4, true, 1.f);
         all.insert(all.end(), hi.begin(), hi.end());
         all.insert(all.end(), lo.begin(), lo.end());
+        actor_pack_bias(biases, b0, b1, b2, out);
     }
+    HIP_TRY(hipMemcpy(a->d_bias, biases.data(), biases.size() * sizeof(float), hipMemcpyHostToDevice));
     const size_t want = (size_t)2 * 2 * actor_frags(a->nk1) * 64 * 4;
     if (all.size() != want) return fail_with(FWG_ERR_INVALID, "fwg_actor_set_weights: internal packing size mismatch");
     HIP_TRY(hipMemcpy(a->d_frags, all.data(), all.size() * sizeof(unsigned), hipMemcpyHostToDevice));

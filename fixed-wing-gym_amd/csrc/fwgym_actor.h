@@ -44,12 +44,13 @@ struct ActorArgs {
     // obs[((win + r) N + e) obs_n + j], win = obs_slots->log_win (graph mode: read on the device) or obs_win (host value)
     const StepSlots* obs_slots; long long obs_win; int obs_n;
 #ifdef FWG_TIMELINE
-    long long* trace;   // measurement builds: [block][wave][8] s_memtime stamps
+    long long* trace;   // measurement builds: [block][wave][16] s_memtime stamps
 #endif
     float* ret;
     ActorStats* stats;                  // [2], indexed by parity
     unsigned long long* acc; int acc_cols;   // [FWG_ACC_SETS][FWG_ACC_SHARDS][acc_cols]
     const frag_t* frags;                // [net 2][part hi/lo][frag][64 lanes]
+    const float* bias;                  // [net 2][FWG_ACT_BIAS_FLOATS] fp32 biases (hidden layers pre-multiplied by 2 log2 e)
     const float* log_std;
     float* norm_obs; float* action; float* value; float* logp; float* norm_rew; uint8_t* done_out;
     long N; long env_base;
@@ -58,8 +59,9 @@ struct ActorArgs {
     unsigned seed_lo, seed_hi;
 };
 
-// frags per network and part: layer 1: 2 row tiles x (nk1 + bias), layer 2: 2 x (4 + bias), layer 3: 1 x (4 + bias)
-__host__ __device__ inline int actor_frags(int nk1) { return 2 * (nk1 + 1) + 2 * 5 + 5; }
+// frags per network and part: layer 1: 2 row tiles x nk1, layer 2: 2 x 4, layer 3: 1 x 4 (the biases are kept apart, in fp32)
+__host__ __device__ inline int actor_frags(int nk1) { return 2 * nk1 + 2 * 4 + 4; }
+#define FWG_ACT_BIAS_FLOATS 160   /* per network: layer 1 (64) | layer 2 (64) | layer 3 (32, act_dim / 1 used) */
 // logical input index of k-slot (kk, half, t): first layer = features in order; later layers = the accumulator
 // registers of the previous layer in register order (see the header comment)
 __host__ __device__ inline int k_input(int kk, int half, int t) { return 16 * kk + 8 * half + t; }
@@ -96,7 +98,7 @@ __device__ __forceinline__ long long actor_obs_win(const ActorArgs& A) { return 
 
 #ifdef FWG_TIMELINE
 #define FWG_ATL(A, i) do { if ((A).trace != nullptr) { const long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); \
-        if ((threadIdx.x & 63) == 0) (A).trace[(blockIdx.x * FWG_ACT_WAVES + (threadIdx.x >> 6)) * 8 + (i)] = t_; } } while (0)
+        if ((threadIdx.x & 63) == 0) (A).trace[(blockIdx.x * FWG_ACT_WAVES + (threadIdx.x >> 6)) * 16 + (i)] = t_; } } while (0)
 #else
 #define FWG_ATL(A, i) do { } while (0)
 #endif
@@ -131,6 +133,9 @@ typedef float fwg_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     const fwg_f32x2 v = {a, b};
     const fwg_bf16x2 h = __builtin_convertvector(v, fwg_bf16x2);
+#ifdef FWG_ABL_NO_LO   /* measurement only: no low part */
+    hi = __builtin_bit_cast(unsigned, h); lo = 0u; return;
+#endif
     const fwg_f32x2 r = v - __builtin_convertvector(h, fwg_f32x2);
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, fwg_bf16x2));
@@ -146,77 +151,179 @@ __device__ __forceinline__ float tanh_prescaled(float a) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(fwg_exp2(a) + 1.f);
 }
 
-// acc += A[idx] * B over the split parts; F = this network's fragments in LDS [part][nf][64]
+// acc += A * B over the split parts (a_lo unused for single products)
 template <int SPLIT>
-__device__ __forceinline__ f32x16 mma(const frag_t* F, int nf, int idx, int l, const frag_t& b_hi, const frag_t& b_lo, f32x16 acc) {
-    const frag_t a_hi = F[idx * 64 + l];
+__device__ __forceinline__ f32x16 mma3(const frag_t& a_hi, const frag_t& a_lo, const frag_t& b_hi, const frag_t& b_lo, f32x16 acc) {
     if (SPLIT > 1) {
-        const frag_t a_lo = F[(nf + idx) * 64 + l];
         acc = fwg_mfma_bf16(a_lo, b_hi, acc);
         acc = fwg_mfma_bf16(a_hi, b_lo, acc);
     }
     return fwg_mfma_bf16(a_hi, b_hi, acc);
 }
-
-// acc += bias (the extra k-block against the constant ones operand)
+// the same k-block into TWO accumulator tiles, alternating between them: an MFMA never follows the one whose result it
+// accumulates onto (back-to-back dependent MFMAs wait for the whole pipe depth: 130 instead of 32 ticks each, measured)
 template <int SPLIT>
-__device__ __forceinline__ f32x16 mma_bias(const frag_t* F, int nf, int idx, int l, const frag_t& ones, f32x16 acc) {
-    if (SPLIT > 1) acc = fwg_mfma_bf16(F[(nf + idx) * 64 + l], ones, acc);
-    return fwg_mfma_bf16(F[idx * 64 + l], ones, acc);
+__device__ __forceinline__ void mma3x2(const frag_t& a0_hi, const frag_t& a0_lo, const frag_t& a1_hi, const frag_t& a1_lo, const frag_t& b_hi,
+                                       const frag_t& b_lo, f32x16& acc0, f32x16& acc1) {
+    if (SPLIT > 1) {
+        acc0 = fwg_mfma_bf16(a0_lo, b_hi, acc0); acc1 = fwg_mfma_bf16(a1_lo, b_hi, acc1);
+        acc0 = fwg_mfma_bf16(a0_hi, b_lo, acc0); acc1 = fwg_mfma_bf16(a1_hi, b_lo, acc1);
+    }
+    acc0 = fwg_mfma_bf16(a0_hi, b_hi, acc0); acc1 = fwg_mfma_bf16(a1_hi, b_hi, acc1);
+}
+// one k-block into the three partial accumulators of a single output tile (layer 3: one tile, so the three products of the
+// split get an accumulator each; added up at the end)
+template <int SPLIT>
+__device__ __forceinline__ void mma3s(const frag_t& a_hi, const frag_t& a_lo, const frag_t& b_hi, const frag_t& b_lo, f32x16& acc, f32x16& acc_a,
+                                      f32x16& acc_b) {
+    if (SPLIT > 1) {
+        acc_a = fwg_mfma_bf16(a_lo, b_hi, acc_a);
+        acc_b = fwg_mfma_bf16(a_hi, b_lo, acc_b);
+    }
+    acc = fwg_mfma_bf16(a_hi, b_hi, acc);
+}
+// NF consecutive weight fragments of one network from LDS (F = [part][nfw][64]) into registers: requested ahead of the MFMAs
+// that consume them, so that no MFMA waits for an LDS round trip
+template <int SPLIT, int NF>
+__device__ __forceinline__ void load_frags(const frag_t* F, int nfw, int base, int l, frag_t (&hi)[NF], frag_t (&lo)[NF]) {
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        hi[i] = F[(base + i) * 64 + l];
+        if (SPLIT > 1) lo[i] = F[(nfw + base + i) * 64 + l];
+    }
+}
+// accumulator tile `it` (rows 32 it ... 32 it + 31) initialised with the layer's bias: lane l receives rows
+// (r & 3) + 8 (r >> 2) + 4 half of every column, i.e. four 16-byte pieces of the bias vector (fp32, exact -- the bias used to
+// ride in an extra k-block against a constant "ones" operand: 10 of the 104 MFMAs per tile)
+__device__ __forceinline__ f32x16 bias_tile(const float* b, int it, int half) {
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(b + 32 * it + 8 * q + 4 * half);
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+    return a;
 }
 
-// two accumulator tiles (64 hidden units) -> tanh -> the four k-blocks of the next layer's B operand
-__device__ __forceinline__ void hidden_to_b(const f32x16& a0, const f32x16& a1, frag_t (&hi)[4], frag_t (&lo)[4]) {
+// eight accumulator values (one k-block of the next layer: registers 8 kb ... 8 kb + 7 of tile a) -> tanh -> B operand
+__device__ __forceinline__ void hidden_block(const f32x16& a, int kb, frag_t& hi, frag_t& lo) {
+    float x[8];
+#if defined(FWG_ABL_TANH_ID)   /* measurement only: no tanh */
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        float x[8];
-#if !defined(FWG_EMU)
+    for (int t = 0; t < 8; ++t) x[t] = a[8 * kb + t] * 0.01f;
+#elif !defined(FWG_EMU)
 #pragma unroll
-        for (int t = 0; t < 8; t += 2) {   // the add and the fma of 1 - 2 / (2^a + 1) on pairs (v_pk_add_f32 / v_pk_fma_f32)
-            const float u0 = kk < 2 ? a0[8 * kk + t] : a1[8 * (kk - 2) + t], u1 = kk < 2 ? a0[8 * kk + t + 1] : a1[8 * (kk - 2) + t + 1];
-            const fwg_f32x2 d = fwg_f32x2{fwg_exp2(u0), fwg_exp2(u1)} + fwg_f32x2{1.f, 1.f};
-            const fwg_f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-            const fwg_f32x2 y = __builtin_elementwise_fma(r, fwg_f32x2{-2.f, -2.f}, fwg_f32x2{1.f, 1.f});
-            x[t] = y[0]; x[t + 1] = y[1];
-        }
+    for (int t = 0; t < 8; t += 2) {   // the add and the fma of 1 - 2 / (2^a + 1) on pairs (v_pk_add_f32 / v_pk_fma_f32)
+        const float u0 = a[8 * kb + t], u1 = a[8 * kb + t + 1];
+        const fwg_f32x2 d = fwg_f32x2{fwg_exp2(u0), fwg_exp2(u1)} + fwg_f32x2{1.f, 1.f};
+        const fwg_f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const fwg_f32x2 y = __builtin_elementwise_fma(r, fwg_f32x2{-2.f, -2.f}, fwg_f32x2{1.f, 1.f});
+        x[t] = y[0]; x[t + 1] = y[1];
+    }
 #else
 #pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] = tanh_prescaled(kk < 2 ? a0[8 * kk + t] : a1[8 * (kk - 2) + t]);
+    for (int t = 0; t < 8; ++t) x[t] = tanh_prescaled(a[8 * kb + t]);
 #endif
-        split8(x, hi[kk], lo[kk]);
-    }
+    split8(x, hi, lo);
+}
+// two accumulator tiles (64 hidden units) -> the four k-blocks of the next layer's B operand
+__device__ __forceinline__ void hidden_to_b(const f32x16& a0, const f32x16& a1, frag_t (&hi)[4], frag_t (&lo)[4]) {
+    hidden_block(a0, 0, hi[0], lo[0]); hidden_block(a0, 1, hi[1], lo[1]);
+    hidden_block(a1, 0, hi[2], lo[2]); hidden_block(a1, 1, hi[3], lo[3]);
 }
 
-// one network (obs -> 64 -> 64 -> out) for the 32 environments of this half-wave tile; result rows 0..3 in out[0..3]
-// of the lanes with half == 0
+// instruction-scheduling directives (LLVM SchedGroupMask): `n` groups of {1 MFMA, `valu` VALU / transcendental instructions}
+#ifdef FWG_EMU
+#define FWG_SCHED_MFMA_VALU(n, valu) do { } while (0)
+#define FWG_SCHED_FENCE() do { } while (0)
+#else
+#define FWG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define FWG_SCHED_MFMA_VALU(n, valu)                                        \
+    do {                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               \
+            __builtin_amdgcn_sched_group_barrier(0x002, (valu), 0);          \
+        }                                                                    \
+    } while (0)
+#endif
+
+// Both networks (obs -> 64 -> 64 -> out) for the 32 environments of this wave's tile, as ONE software pipeline: while the
+// matrix pipe works through a layer of one network, the vector units turn the other network's previous layer into the next
+// B operand (tanh + bf16 hi / lo split: ~180 VALU per layer and network, against 24 MFMAs = 768 pipe cycles), and every
+// weight fragment is in registers before the MFMA that takes it is issued.  FP / FV: the networks' fragments in LDS
+// ([part][nfw][64], nfw = 2 NK1 + 12: layer 1 tiles 0 / 1, layer 2 tiles 0 / 1, layer 3), bP / bV their biases (fp32: 64 | 64 |
+// 32, hidden layers pre-multiplied by 2 log2 e like the weights).  Result rows 0..3 in out[0..3] of the lanes with half == 0.
 template <int SPLIT, int NK1>
-__device__ __forceinline__ f32x16 mlp_forward(const frag_t* F, int l, const frag_t (&bx_hi)[NK1], const frag_t (&bx_lo)[NK1]) {
-    constexpr int nk1 = NK1, nf = 2 * (NK1 + 1) + 15;
-    const frag_t ones = frag_t{(l >> 5) == 0 ? 0x3F80u : 0u, 0u, 0u, 0u};   // 1.0 in k-slot (half 0, t 0)
-    f32x16 a[2];
+__device__ __forceinline__ void mlp_pair(const ActorArgs& A, const frag_t* FP, const frag_t* FV, const float* bP, const float* bV, int l,
+                                         const frag_t (&bx_hi)[NK1], const frag_t (&bx_lo)[NK1], f32x16& o_pi, f32x16& o_vf) {
+    constexpr int nfw = 2 * NK1 + 12;
+    const int half = l >> 5;
+    // ---- layer 1 of both networks
+    frag_t w1p_hi[2 * NK1], w1p_lo[2 * NK1], w1v_hi[2 * NK1], w1v_lo[2 * NK1];
+    load_frags<SPLIT, 2 * NK1>(FP, nfw, 0, l, w1p_hi, w1p_lo);
+    load_frags<SPLIT, 2 * NK1>(FV, nfw, 0, l, w1v_hi, w1v_lo);
+    f32x16 p0 = bias_tile(bP, 0, half), p1 = bias_tile(bP, 1, half), v0 = bias_tile(bV, 0, half), v1 = bias_tile(bV, 1, half);
+    frag_t w2_hi[8], w2_lo[8];
+    load_frags<SPLIT, 8>(FP, nfw, 2 * NK1, l, w2_hi, w2_lo);   // (layer 2 of pi: lands under the layer-1 MFMAs)
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        f32x16 acc = {0.f};
+    for (int kk = 0; kk < NK1; ++kk) mma3x2<SPLIT>(w1p_hi[kk], w1p_lo[kk], w1p_hi[NK1 + kk], w1p_lo[NK1 + kk], bx_hi[kk], bx_lo[kk], p0, p1);
 #pragma unroll
-        for (int kk = 0; kk < NK1; ++kk) acc = mma<SPLIT>(F, nf, it * (nk1 + 1) + kk, l, bx_hi[kk], bx_lo[kk], acc);
-        a[it] = mma_bias<SPLIT>(F, nf, it * (nk1 + 1) + nk1, l, ones, acc);
+    for (int kk = 0; kk < NK1; ++kk) mma3x2<SPLIT>(w1v_hi[kk], w1v_lo[kk], w1v_hi[NK1 + kk], w1v_lo[NK1 + kk], bx_hi[kk], bx_lo[kk], v0, v1);
+    // ---- pi: hidden 1 -> B (vector units; the vf layer-1 MFMAs above are still in the pipe)
+    frag_t bp_hi[4], bp_lo[4], bv_hi[4], bv_lo[4];
+    FWG_ATL(A, 8);
+    hidden_to_b(p0, p1, bp_hi, bp_lo);
+    FWG_SCHED_FENCE();
+    FWG_ATL(A, 9);
+    // ---- pi layer 2 (matrix pipe) || vf: hidden 1 -> B (vector units), one k-block of each per round: the round is its own
+    // scheduling region, so the {1 MFMA, n VALU} groups below are met exactly
+    f32x16 h0 = bias_tile(bP + 64, 0, half), h1 = bias_tile(bP + 64, 1, half);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        mma3x2<SPLIT>(w2_hi[kk], w2_lo[kk], w2_hi[4 + kk], w2_lo[4 + kk], bp_hi[kk], bp_lo[kk], h0, h1);
+        hidden_block(kk < 2 ? v0 : v1, kk & 1, bv_hi[kk], bv_lo[kk]);
+        FWG_SCHED_MFMA_VALU(SPLIT > 1 ? 6 : 2, SPLIT > 1 ? 8 : 24);
+        FWG_SCHED_FENCE();
     }
-    frag_t bh_hi[4], bh_lo[4];
-    hidden_to_b(a[0], a[1], bh_hi, bh_lo);
-    const int base2 = 2 * (nk1 + 1);
+    p0 = h0; p1 = h1;
+    FWG_ATL(A, 10);
+    // ---- vf layer 2 || pi: hidden 2 -> B
+    load_frags<SPLIT, 8>(FV, nfw, 2 * NK1, l, w2_hi, w2_lo);
+    h0 = bias_tile(bV + 64, 0, half); h1 = bias_tile(bV + 64, 1, half);
+    FWG_SCHED_FENCE();
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        f32x16 acc = {0.f};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = mma<SPLIT>(F, nf, base2 + it * 5 + kk, l, bh_hi[kk], bh_lo[kk], acc);
-        a[it] = mma_bias<SPLIT>(F, nf, base2 + it * 5 + 4, l, ones, acc);
+    for (int kk = 0; kk < 4; ++kk) {
+        mma3x2<SPLIT>(w2_hi[kk], w2_lo[kk], w2_hi[4 + kk], w2_lo[4 + kk], bv_hi[kk], bv_lo[kk], h0, h1);
+        hidden_block(kk < 2 ? p0 : p1, kk & 1, bp_hi[kk], bp_lo[kk]);
+        FWG_SCHED_MFMA_VALU(SPLIT > 1 ? 6 : 2, SPLIT > 1 ? 8 : 24);
+        FWG_SCHED_FENCE();
     }
-    hidden_to_b(a[0], a[1], bh_hi, bh_lo);
-    const int base3 = base2 + 10;
-    f32x16 out = {0.f};
+    v0 = h0; v1 = h1;
+    FWG_ATL(A, 11);
+    // ---- pi layer 3 || vf: hidden 2 -> B
+    frag_t w3_hi[4], w3_lo[4];
+    load_frags<SPLIT, 4>(FP, nfw, 2 * NK1 + 8, l, w3_hi, w3_lo);
+    o_pi = bias_tile(bP + 128, 0, half);
+    f32x16 oa = {0.f}, ob = {0.f};
+    FWG_SCHED_FENCE();
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) out = mma<SPLIT>(F, nf, base3 + kk, l, bh_hi[kk], bh_lo[kk], out);
-    return mma_bias<SPLIT>(F, nf, base3 + 4, l, ones, out);
+    for (int kk = 0; kk < 4; ++kk) {
+        mma3s<SPLIT>(w3_hi[kk], w3_lo[kk], bp_hi[kk], bp_lo[kk], o_pi, oa, ob);
+        hidden_block(kk < 2 ? v0 : v1, kk & 1, bv_hi[kk], bv_lo[kk]);
+        FWG_SCHED_MFMA_VALU(SPLIT > 1 ? 3 : 1, SPLIT > 1 ? 16 : 48);
+        FWG_SCHED_FENCE();
+    }
+    FWG_ATL(A, 12);
+    // ---- vf layer 3
+    load_frags<SPLIT, 4>(FV, nfw, 2 * NK1 + 8, l, w3_hi, w3_lo);
+    o_vf = bias_tile(bV + 128, 0, half);
+    f32x16 va = {0.f}, vb = {0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) mma3s<SPLIT>(w3_hi[kk], w3_lo[kk], bv_hi[kk], bv_lo[kk], o_vf, va, vb);
+    if (SPLIT > 1) {   // (only rows 0..3 are outputs)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o_pi[i] += oa[i] + ob[i]; o_vf[i] += va[i] + vb[i]; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -264,14 +371,15 @@ struct ActorLds {
     float* rstd_s;    // [64] 1 / sqrt(updated running variance + eps)
     float* misc;      // [0] 1 / sqrt(ret_var + eps), [1] updated running mean of the returns, [4 ...] batch sums
     float* act_out;   // nullable: sampled actions of the workgroup's environments, [256][4]
+    float* bias;      // [2][FWG_ACT_BIAS_FLOATS] the networks' biases
 };
 __host__ __device__ inline int actor_weight_floats(int nk1, int parts) { return 2 * parts * actor_frags(nk1) * 64 * 4; }
-__host__ __device__ inline int actor_scratch_floats() { return 2 * FWG_ACT_MAX_OBS + 4 + 2 * FWG_ACT_MAX_OBS + 4; }
+__host__ __device__ inline int actor_scratch_floats() { return 2 * FWG_ACT_MAX_OBS + 4 + 2 * FWG_ACT_MAX_OBS + 4 + 2 * FWG_ACT_BIAS_FLOATS; }
 
 template <int SPLIT, int NK1>
 __device__ __forceinline__ unsigned actor_block(const ActorArgs& A, const ActorLds& Z, long env_first) {
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, j = l & 31, half = l >> 5;
-    constexpr int nf = 2 * (NK1 + 1) + 15;
+    constexpr int nf = 2 * NK1 + 12;
     constexpr int PARTS = SPLIT > 1 ? 2 : 1;
     const bool first_block = env_first == 0;
     FWG_ATL(A, 0);
@@ -279,24 +387,22 @@ __device__ __forceinline__ unsigned actor_block(const ActorArgs& A, const ActorL
     float* mean_s = Z.mean_s;
     float* rstd_s = Z.rstd_s;
     float* misc = Z.misc;
-    // packed weights HBM/L2 -> LDS without a register round trip (global_load_lds, 1 KiB per wave instruction): in
-    // flight while the statistics are folded and the observations normalised, waited for before the first MFMA
+    // packed weights L2 -> registers now, -> LDS after the statistics are folded (below): every wave moves its share of the 1 KiB
+    // pieces, 16 bytes per lane and piece.  (Round 3 streamed them with global_load_lds: the LDS-DMA path delivers ~25 GB/s per
+    // CU whatever the number of waves issuing -- 56 KiB landed 5k ticks after the request, 1.7k of them exposed; plain loads
+    // come in at the L1 rate and the ds_write_b128 cost 13 cycles each)
+    constexpr int n_pieces = PARTS == 2 ? 2 * 2 * nf : 2 * nf;
+    constexpr int per_wave = (n_pieces + FWG_ACT_WAVES - 1) / FWG_ACT_WAVES;
+    float4 wreg[per_wave];
 #ifndef FWG_ABL_ACT_NO_STAGE
-    if (PARTS == 2) {   // source and destination have the same layout: ONE linear copy of 2 * 2 * nf KiB, a wave moves 1 KiB
-        constexpr int total = 2 * 2 * nf;   // per instruction; the pieces are dealt to the 8 waves round-robin
 #pragma unroll
-        for (int i = 0; i < (total + FWG_ACT_WAVES - 1) / FWG_ACT_WAVES; ++i) {
-            const int fr = wv + i * FWG_ACT_WAVES;
-            if (fr < total) dma_group(reinterpret_cast<const float4*>(A.frags + fr * 64 + l), reinterpret_cast<float*>(F + fr * 64));
-        }
-    } else {            // single products: only the hi parts are staged
-#pragma unroll
-        for (int i = 0; i < (2 * nf + FWG_ACT_WAVES - 1) / FWG_ACT_WAVES; ++i) {
-            const int q = wv + i * FWG_ACT_WAVES;
-            if (q < 2 * nf) {
-                const int net = q / nf, fr = q - net * nf;
-                dma_group(reinterpret_cast<const float4*>(A.frags + ((net * 2) * nf + fr) * 64 + l), reinterpret_cast<float*>(F + (net * nf + fr) * 64));
-            }
+    for (int i = 0; i < per_wave; ++i) {
+        const int q = wv + i * FWG_ACT_WAVES;
+        wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < n_pieces) {
+            // split products: source and destination have the same layout [net][part][nf]; single products: only the hi parts
+            const int src = PARTS == 2 ? q : ((q / nf) * 2 * nf + (q % nf));
+            wreg[i] = reinterpret_cast<const float4*>(A.frags + src * 64)[l];
         }
     }
 #endif
@@ -329,6 +435,7 @@ __device__ __forceinline__ unsigned actor_block(const ActorArgs& A, const ActorL
     // the normalised-observation stores waits for their acknowledgement (vmcnt counts in issue order), and a uniform load
     // after a store is no longer a scalar load
     const unsigned act_ctr = A.stats[A.parity].act_counter;
+    const float bias_in = tid < 2 * FWG_ACT_BIAS_FLOATS ? A.bias[tid] : 0.f;   // (parked in LDS with the batch sums below)
     float ls_in[FWG_ACT_MAX_ACT];
 #pragma unroll
     for (int i = 0; i < FWG_ACT_MAX_ACT; ++i) ls_in[i] = i < A.act_dim ? A.log_std[i] : 0.f;
@@ -350,6 +457,7 @@ __device__ __forceinline__ unsigned actor_block(const ActorArgs& A, const ActorL
             for (int sh = 0; sh < FWG_ACC_SHARDS; ++sh) sum += (long long)acc[(long)sh * A.acc_cols + tid];
             tot[tid] = (tid == 2 || tid == 3) ? (float)sum : (float)sum * (1.f / FWG_ACC_SCALE);
         }
+        if (tid < 2 * FWG_ACT_BIAS_FLOATS) Z.bias[tid] = bias_in;
         // (LDS-only barriers here: __syncthreads() drains vmcnt, i.e. it would wait for the whole weight staging above --
         // the fold and the normalisation below are meant to run UNDER it; dma_wait() before the first MFMA is the drain)
         FWG_BLOCK_SYNC_LDS();
@@ -422,15 +530,22 @@ __device__ __forceinline__ unsigned actor_block(const ActorArgs& A, const ActorL
         split8(x, bx_hi[kk], bx_lo[kk]);
     }
     FWG_ATL(A, 3);
-    dma_wait();
+#ifndef FWG_ABL_ACT_NO_STAGE
+#pragma unroll
+    for (int i = 0; i < per_wave; ++i) {
+        const int q = wv + i * FWG_ACT_WAVES;
+        if (q < n_pieces) reinterpret_cast<float4*>(F + q * 64)[l] = wreg[i];
+    }
+#endif
+    FWG_BLOCK_SYNC_LDS();
     FWG_ATL(A, 4);
     // both networks in one instruction stream: their MFMA chains and tanh phases are independent and interleave
 #ifdef FWG_ABL_ACT_NO_MLP   // measurement only (tools/ablate.py)
     f32x16 o_pi = {0.f}, o_vf = {0.f};
     o_pi[0] = __uint_as_float(bx_hi[0].x ^ F[l].x); o_vf[0] = __uint_as_float(bx_lo[0].y);
 #else
-    const f32x16 o_pi = mlp_forward<SPLIT, NK1>(F, l, bx_hi, bx_lo);
-    const f32x16 o_vf = mlp_forward<SPLIT, NK1>(F + PARTS * nf * 64, l, bx_hi, bx_lo);
+    f32x16 o_pi, o_vf;
+    mlp_pair<SPLIT, NK1>(A, F, F + PARTS * nf * 64, Z.bias, Z.bias + FWG_ACT_BIAS_FLOATS, l, bx_hi, bx_lo, o_pi, o_vf);
 #endif
     FWG_ATL(A, 5);
     const float res[2][FWG_ACT_MAX_ACT] = {{o_pi[0], o_pi[1], o_pi[2], o_pi[3]}, {o_vf[0], o_vf[1], o_vf[2], o_vf[3]}};
@@ -474,28 +589,25 @@ __global__ __launch_bounds__(64 * FWG_ACT_WAVES) void k_actor_act(const ActorArg
     Z.rstd_s = Z.mean_s + FWG_ACT_MAX_OBS;
     Z.misc = Z.rstd_s + FWG_ACT_MAX_OBS;
     Z.act_out = nullptr;
+    Z.bias = Z.misc + 4 + 2 * FWG_ACT_MAX_OBS + 4;
     actor_block<SPLIT, NK1>(A, Z, (long)blockIdx.x * FWG_ACT_ENVS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host: weight packing into MFMA operand fragments
 // ---------------------------------------------------------------------------------------------------------------------
-// one layer: W [out][in] row-major, b [out]; nit row tiles, nk k-blocks (+1 bias block) -> hi/lo words appended
-static void actor_pack_layer(std::vector<unsigned>& hi, std::vector<unsigned>& lo, const float* W, const float* b, int out,
+// one layer: W [out][in] row-major; nit row tiles, nk k-blocks -> hi/lo words appended (biases: actor_pack_bias)
+static void actor_pack_layer(std::vector<unsigned>& hi, std::vector<unsigned>& lo, const float* W, int out,
                              int in, int nit, int nk, bool chained, float scale) {
     for (int it = 0; it < nit; ++it)
-        for (int kk = 0; kk <= nk; ++kk)
+        for (int kk = 0; kk < nk; ++kk)
             for (int l = 0; l < 64; ++l) {
                 unsigned wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
                 const int i = 32 * it + (l & 31), half = l >> 5;
                 for (int t = 0; t < 8; ++t) {
                     float v = 0.f;
-                    if (kk < nk) {
-                        const int k = chained ? k_chained(kk, half, t) : k_input(kk, half, t);
-                        if (i < out && k < in) v = scale * W[(size_t)i * in + k];
-                    } else if (half == 0 && t == 0 && i < out) {
-                        v = scale * b[i];
-                    }
+                    const int k = chained ? k_chained(kk, half, t) : k_input(kk, half, t);
+                    if (i < out && k < in) v = scale * W[(size_t)i * in + k];
                     const unsigned h16 = bf16_rne(v), l16 = bf16_rne(v - bf16_to_f32(h16));
                     wh[t >> 1] |= h16 << (16 * (t & 1));
                     wl[t >> 1] |= l16 << (16 * (t & 1));
@@ -503,4 +615,10 @@ static void actor_pack_layer(std::vector<unsigned>& hi, std::vector<unsigned>& l
                 hi.insert(hi.end(), wh, wh + 4);
                 lo.insert(lo.end(), wl, wl + 4);
             }
+}
+// the three bias vectors of one network: 64 | 64 | 32 floats (hidden layers pre-scaled like their weights)
+static void actor_pack_bias(std::vector<float>& out, const float* b0, const float* b1, const float* b2, int n_out) {
+    for (int i = 0; i < 64; ++i) out.push_back(FWG_ACT_PRESCALE * b0[i]);
+    for (int i = 0; i < 64; ++i) out.push_back(FWG_ACT_PRESCALE * b1[i]);
+    for (int i = 0; i < 32; ++i) out.push_back(i < n_out ? b2[i] : 0.f);
 }

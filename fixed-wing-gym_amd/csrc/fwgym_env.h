@@ -50,7 +50,7 @@ struct KArgs {
 };
 #ifdef FWG_TIMELINE
 #define FWG_TL(A, i) do { if ((A).trace != nullptr) { const long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); \
-        if ((threadIdx.x & 63) == 0) (A).trace[(blockIdx.x * 2 + (threadIdx.x >> 6)) * 16 + (i)] = t_; } } while (0)
+        if ((threadIdx.x & 63) == 0) (A).trace[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (i)] = t_; } } while (0)
 #else
 #define FWG_TL(A, i) do { } while (0)
 #endif

@@ -20,7 +20,7 @@ for precise in (True, False):
     actor.load_policy(MlpPolicy(vec.obs_dim))
     actor.attach(vec)
     nb = (n + 255) // 256
-    trace = torch.zeros((nb, 8, 8), dtype=torch.int64, device="cuda")
+    trace = torch.zeros((nb, 8, 16), dtype=torch.int64, device="cuda")
     lib.fwg_debug_set_actor_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.fwg_debug_set_actor_trace(actor._handle, ctypes.c_void_p(trace.data_ptr()))
     a0 = torch.rand((n, 3), device="cuda") * 2 - 1
@@ -36,7 +36,7 @@ for precise in (True, False):
             rows.append(trace.cpu().numpy().astype(np.float64)); evs.append(e0.elapsed_time(e1) * 1e3)
     T = np.stack(rows)
     rel = T - T[:, :, :, 0:1].min(axis=2, keepdims=True)
-    med = np.median(rel.reshape(-1, 8), axis=0)
+    med = np.median(rel.reshape(-1, 16), axis=0)
     spread = np.median(T[:, :, :, 0].max(axis=(1, 2)) - T[:, :, :, 0].min(axis=(1, 2)))
     print("precise={}: event {:.2f} us, first->last block start {:.0f} ticks; stamps (ticks since block start, median over waves): {}".format(
         precise, np.median(evs), spread, "  ".join("{}:{:.0f}".format(i, med[i]) for i in range(7))))
