@@ -101,19 +101,50 @@ __device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, co
     unsigned long long* acc = A.acc + (size_t)(ctr % FWG_ACC_SETS) * FWG_ACC_SHARDS * A.acc_cols;
     // the running means the deviations are taken from: written by the head's previous launch, constant during this one.
     // Read through a plain pointer (after this kernel's stores) every one of them was a vector load with a wait of its own --
-    // 2 D serial round trips, most of what the attached moments cost (§5); as scalar loads they arrive in a few batches
+    // 2 D serial round trips, most of what the attached moments cost (§5); as scalar loads they arrive in a few batches.
+    // (k_rollout: from LDS.  Loaded UNCONDITIONALLY, all at once: inside the per-column conditionals the compiler gave every
+    // one of them a branch, a ds_read and a wait of its own -- 24 serial LDS round trips at the very end of every wave)
     FWG_KCONST(float)* mean_k = (FWG_KCONST(float)*)A.acc_mean;
-#define FWG_OBS_AT(k) ob.get(k)
-    struct MeanRef {
-        const float* head; FWG_KCONST(float)* k;
-        __device__ __forceinline__ float operator[](int i) const { return HS::enabled ? head[i] : k[i]; }
-    } const mean_at{hs.mean, mean_k};
+    const float one = valid ? 1.f : 0.f;
 #pragma unroll
     for (int chunk = 0; chunk < (2 * FWG_MAX_OBS * FWG_MAX_ROWS + 4 + 31) / 32; ++chunk) {
         if (32 * chunk < 2 * D + 4) {
+            // the 16 observation entries this chunk's columns belong to: column 4 + 2 k / 5 + 2 k = deviation of entry k / its
+            // square (layout of fwgym_env.h, FWG_ACC_COLUMN); entry of column 32 chunk + i: k = 16 chunk - 2 + (i >> 1)
+            float dev[16], mean[16];
+            if (HS::enabled) {   // k_rollout: the updated running means from LDS -- five 16-byte reads, all issued before the first
+                // use (rounded(): an empty asm the value passes through; it pins the reads HERE, for all lanes -- left alone the
+                // compiler sinks every one of them into a branch on `valid` of its own, each with its own wait)
+                float4 q[5];
+#pragma unroll
+                for (int g = 0; g < 5; ++g) {
+                    const int k0 = 16 * chunk - 4 + 4 * g;   // entries k0 .. k0 + 3 (the head keeps 64 means: zeros beyond D)
+                    q[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k0 >= 0 && k0 < D && k0 + 3 < FWG_ACT_MAX_OBS) q[g] = *reinterpret_cast<const float4*>(hs.mean + k0);
+                }
+#pragma unroll
+                for (int g = 0; g < 5; ++g) { q[g].x = rounded(q[g].x); q[g].y = rounded(q[g].y); q[g].z = rounded(q[g].z); q[g].w = rounded(q[g].w); }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {   // entry k = 16 chunk - 2 + j sits at position j + 2 of the 20 values read
+                    const float4 g = q[(j + 2) >> 2];
+                    mean[j] = ((j + 2) & 3) == 0 ? g.x : ((j + 2) & 3) == 1 ? g.y : ((j + 2) & 3) == 2 ? g.z : g.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = 16 * chunk - 2 + j;
+                dev[j] = 0.f;
+                if (k >= 0 && k < D && k < FWG_MAX_OBS * FWG_MAX_ROWS) {
+                    const float m = HS::enabled ? mean[j] : mean_k[k];
+                    dev[j] = valid ? ob.get(k) - m : 0.f;
+                }
+            }
             float v[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) v[i] = FWG_ACC_COLUMN(32 * chunk + i, D, valid, FWG_OBS_AT, mean_at, dr, true, true);
+            for (int i = 0; i < 32; ++i) {
+                const int col = 32 * chunk + i;
+                v[i] = col == 0 ? dr : col == 1 ? dr * dr : (col == 2 || col == 3) ? one : ((i & 1) == 0 ? dev[i >> 1] : dev[i >> 1] * dev[i >> 1]);
+            }
 #ifdef FWG_ABL_NO_TOTALS
             acc_flush(acc, A.acc_cols, sub & (FWG_ACC_SHARDS - 1), chunk, lane, v[0] + v[7] + v[13] + v[27]);
 #else
@@ -121,7 +152,6 @@ __device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, co
 #endif
         }
     }
-#undef FWG_OBS_AT
 #endif
 }
 
