@@ -252,11 +252,11 @@ def main():
     class Runner(object):
         """One env batch of this rank + its action pool, captured launch sequences and success reduction."""
 
-        def __init__(self, cfg, ckw, skw, n, first, log_rows, seed=0):
+        def __init__(self, cfg, ckw, skw, n, first, log_rows, seed=0, extra=None):
             # derived_views=False: the rollout loop never reads roll/pitch/... back from the arena (they are in the
             # observations), so the kernel does not write those host-view rows
             self.vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, sim_config_kw=skw, seed=seed, env_id_base=first,
-                                       auto_reset=True, derived_views=False, obs_log_rows=log_rows, **kw)
+                                       auto_reset=True, derived_views=False, obs_log_rows=log_rows, **dict(kw, **(extra or {})))
             self.vec.reset()
             self.n = n
             self.graphs = {}
@@ -453,13 +453,19 @@ def main():
         if vec.obs_log_rows:
             # an observation CONSUMER inside the replayed sequence: every step is followed by the gather of the dense
             # [N][length][n_obs] batch out of the row log (what a torch policy reads under graph replay), steady state
-            sides["obs_delivered"] = side_entry(R.time_replays(sc, sreps, want_obs=True), n_envs,
-                note="steady state + fwg_obs_gather after every step inside the replayed graph: the dense observation batch a "
-                     "torch consumer reads (the HIP rollout head reads the row log in place instead: --workload c5)")
+            mirrored = R.vec.set_obs_mirror(True)
+            R.graphs.clear()    # (captured sequences bake the launch arguments in)
+            sides["obs_delivered"] = side_entry(R.time_replays(sc, sreps, want_obs=True), n_envs, mirror=bool(mirrored),
+                note="steady state + the dense [N][5][12] observation batch a torch consumer reads, current after every step of the "
+                     "replayed graph: " + ("assembled inside the step kernel (fwg_set_obs_mirror: the physics wave copies the lagged "
+                     "rows in its idle tail, the gym wave adds the new record)" if mirrored else "fwg_obs_gather after every step") +
+                     " (the HIP rollout head reads the row log in place instead: c5)")
+            R.vec.set_obs_mirror(False)
+            R.graphs.clear()
     if side_ok and world == 1 and args.workload == "c3" and not args.stagger and not args.envs and not args.total_envs:
-        def side_env(name, wl_cfg, n, rows, alg, note, stag=True):
+        def side_env(name, wl_cfg, n, rows, alg, note, stag=True, extra=None):
             try:
-                S = Runner(wl_cfg[0], wl_cfg[1], wl_cfg[2], n, 0, rows)
+                S = Runner(wl_cfg[0], wl_cfg[1], wl_cfg[2], n, 0, rows, extra=extra)
                 S.enable_graphs()
                 S.run(sc, max(1, STEADY_STATE_STEPS // sc), 0)
                 fresh = S.time_replays(sc, sreps)
@@ -485,6 +491,17 @@ def main():
         side_env("integrator_4x64", (cfg, ckw, hi), n_envs, log_rows, alg_b,
                  "the same workload with 4 RK4 sub-steps and 64 exact actuator micro-steps per env step: the first scheme clearly "
                  "more accurate than the reference's adaptive RK45 at rtol 1e-3 (profiles/r02_convergence.json)", stag=False)
+        # the GENERIC kernel (what a configuration outside the presets runs when no specialised kernel can be compiled for it:
+        # no hipcc on the machine, or specialize=False): the same workload with steps_max 1999, which matches no preset
+        gk = _copy.deepcopy(ckw or {})
+        gk["steps_max"] = 1999
+        import warnings as _warnings
+        with _warnings.catch_warnings():
+            _warnings.simplefilter("ignore")
+            side_env("generic_kernel", (cfg, gk, skw), n_envs, log_rows, alg_b,
+                     "the same workload on the GENERIC kernel (configuration interpreted at run time: scalar loads, LDS tables, scratch), "
+                     "what a non-preset configuration runs without a run-time specialised kernel (FixedWingVecEnv compiles one by "
+                     "default when hipcc is present, and warns either way)", stag=False, extra={"specialize": False})
         from gym_fixed_wing import presets as _pr
         try:   # every env flies its own aircraft (16 parameters re-sampled at every reset); gentle actions: random full-scale
             # actions crash the randomised aircraft within a few dozen steps and the run then measures failure ends

@@ -207,6 +207,41 @@ __device__ __forceinline__ float fast_atan2(float y, float x) {
     return copysignf(r, y);
 }
 
+// ---- pairs of floats as ONE value: on the device they live in an aligned register pair and `a * b + c` is a single
+// v_pk_fma_f32 (v_pk_mul_f32, v_pk_add_f32) -- two results per issue slot.  A wave issues at most one vector instruction every
+// ~5 cycles however much is independent (tools/ub_valu.hip), and the physics wave's ~1 900 dependent instructions ARE the
+// length of an env step: wherever two lanes of arithmetic have the same shape they are written on pairs.  (GCC-style vector:
+// the host emulation build compiles the same source.)
+typedef float f2 __attribute__((vector_size(8)));
+__host__ __device__ __forceinline__ f2 mk2(float a, float b) { f2 r = {a, b}; return r; }
+__host__ __device__ __forceinline__ f2 splat2(float a) { f2 r = {a, a}; return r; }
+__device__ __forceinline__ f2 fmax2(f2 a, f2 b) { return mk2(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])); }
+__device__ __forceinline__ f2 fmin2(f2 a, f2 b) { return mk2(fminf(a[0], b[0]), fminf(a[1], b[1])); }
+__device__ __forceinline__ f2 fabs2(f2 a) { return mk2(fabsf(a[0]), fabsf(a[1])); }
+// two atan2 side by side: same octant folding as fast_atan2, the polynomial on pairs
+__device__ __forceinline__ f2 fast_atan2x2(f2 y, f2 x) {
+    const f2 ax = fabs2(x), ay = fabs2(y);
+    const f2 mx = fmax2(ax, ay), mn = fmin2(ax, ay);
+    const f2 a = mk2(mx[0] > 0.f ? mn[0] * frcp(mx[0]) : 0.f, mx[1] > 0.f ? mn[1] * frcp(mx[1]) : 0.f);
+    const f2 s = a * a;
+    f2 p = splat2(0.0024566026404500008f);
+    p = p * s - splat2(0.014400825835764408f);
+    p = p * s + splat2(0.03978026658296585f);
+    p = p * s - splat2(0.07234764844179153f);
+    p = p * s + splat2(0.1049889475107193f);
+    p = p * s - splat2(0.14161212742328644f);
+    p = p * s + splat2(0.19985903799533844f);
+    p = p * s - splat2(0.33332598209381104f);
+    p = p * s + splat2(0.9999998807907104f);
+    const f2 r = p * a;
+    float r0 = r[0], r1 = r[1];
+    r0 = ay[0] > ax[0] ? 1.57079632679489661923f - r0 : r0;
+    r1 = ay[1] > ax[1] ? 1.57079632679489661923f - r1 : r1;
+    r0 = x[0] < 0.f ? 3.14159265358979323846f - r0 : r0;
+    r1 = x[1] < 0.f ? 3.14159265358979323846f - r1 : r1;
+    return mk2(copysignf(r0, y[0]), copysignf(r1, y[1]));
+}
+
 #define FWG_PI 3.14159265358979323846f
 #define FWG_TWO_PI 6.28318530717958647692f
 #define FWG_INV_TWO_PI 0.15915494309189533577f

@@ -29,8 +29,9 @@ __device__ __forceinline__ Air airspeed(const Rot& R, float u, float v, float w,
     const float xz2 = a.ua * a.ua + a.wa * a.wa;
     const float v2 = fmaxf(xz2 + a.va * a.va, 1e-30f);
     a.Va = v2 * frsq(v2);
-    a.alpha = fast_atan2(a.wa, a.ua);
-    a.beta = fast_atan2(a.va, xz2 * frsq(fmaxf(xz2, 1e-30f)));  // = asin(va / Va)
+    const f2 ab = fast_atan2x2(mk2(a.wa, a.va), mk2(a.ua, xz2 * frsq(fmaxf(xz2, 1e-30f))));   // beta = asin(va / Va)
+    a.alpha = ab[0];
+    a.beta = ab[1];
     return a;
 }
 
@@ -287,7 +288,12 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, const AP& aero, float (
             const float bw = (st == 0 || st == 3) ? c.h_sixth : 2.f * c.h_sixth;
             const float aw = (st == 2) ? c.h : c.half_h;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) { acc[i] += bw * k[i]; ys[i] = yb[i] + aw * k[i]; }
+            for (int i = 0; i + 1 < NB; i += 2) {   // the update on pairs (NB is odd: the last state alone)
+                const f2 kk = mk2(k[i], k[i + 1]);
+                const f2 an = mk2(acc[i], acc[i + 1]) + splat2(bw) * kk, yn = mk2(yb[i], yb[i + 1]) + splat2(aw) * kk;
+                acc[i] = an[0]; acc[i + 1] = an[1]; ys[i] = yn[0]; ys[i + 1] = yn[1];
+            }
+            acc[NB - 1] += bw * k[NB - 1]; ys[NB - 1] = yb[NB - 1] + aw * k[NB - 1];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) yb[i] += acc[i];

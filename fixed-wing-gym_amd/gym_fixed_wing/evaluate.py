@@ -28,8 +28,16 @@ def evaluation_overrides(use_pid, config_kw=None):
 
 
 def evaluate_on_set(scenarios, config_path=None, policy=None, config_kw=None, turbulence_intensity="none", device=0,
-                    seed=0, metrics=METRICS, pid_gains=None, **vec_kw):
-    """policy: None => the PID baseline; otherwise a callable obs[N, ...] (device tensor) -> actions[N, 3]."""
+                    seed=0, metrics=METRICS, pid_gains=None, first_step_policy=None, **vec_kw):
+    """policy: None => the PID baseline; otherwise a callable obs[N, ...] (device tensor) -> actions[N, 3].
+
+    first_step_policy: the callable that produces the FIRST action of every episode (default: `policy`).  The reference's
+    evaluation wraps the envs in VecNormalize but takes the observation of a scenario's reset straight from
+    env_method("reset", ...) (evaluate_controller.py:118), which bypasses the wrapper: the model's first action of every
+    episode is computed from the UN-normalised observation, all later ones from normalised ones (:139, :153).  The published
+    RL results carry that step (second-step reward error against eval_res_RL_MLP_none.npy 0.023 -> 0.0006 with it, control
+    variation 0.29 -> 0.36 against the published 0.41); pass the policy WITHOUT its observation normalisation here to fly the
+    reference's protocol to the letter."""
     import torch
     use_pid = policy is None
     n = len(scenarios)
@@ -60,12 +68,12 @@ def evaluate_on_set(scenarios, config_path=None, policy=None, config_kw=None, tu
     rewards = [[] for _ in range(n)]
     res = {m: {} for m in metrics}
     finished = {}
-    for _ in range(vec.cfg["steps_max"] + 1):
+    for t_step in range(vec.cfg["steps_max"] + 1):
         if use_pid:
             row = obs.reshape(n, -1)
             act = pid.get_action(row[:, i_phi], row[:, i_theta], row[:, i_va], row[:, i_om])
         else:
-            act = as_t(policy(obs)).to(dev)
+            act = as_t((first_step_policy if (t_step == 0 and first_step_policy is not None) else policy)(obs)).to(dev)
         act = torch.where(active[:, None], act.float(), torch.zeros_like(act, dtype=torch.float32))
         obs, rew, done, infos = vec.step(act if isinstance(vec._obs, torch.Tensor) else act.cpu().numpy())
         obs, rew, done = as_t(obs), as_t(rew), as_t(done).bool()

@@ -122,16 +122,40 @@ class FixedWingVecEnv(object):
             obs_log_rows = _presets.OBS_LOG_ROWS if self._row_log_applies() else 0
         self.obs_log_rows = int(obs_log_rows)
         self._c = ec.compile(auto_reset=auto_reset, store_derived=self.derived_views, obs_log_rows=self.obs_log_rows)
-        # configurations outside the build-time presets run the generic kernel unless a specialised copy of the
-        # library is compiled for them (opt-in: specialize=True or FWGYM_JIT=1; see jit.py)
+        # Configurations outside the build-time presets run the GENERIC kernel -- it interprets the configuration (scalar
+        # loads, LDS tables, ~4 KB of scratch per lane) and takes about five times as long per step -- unless a specialised
+        # copy of the library is compiled for them (jit.py: hipcc, one to two minutes once per distinct configuration, cached
+        # by content hash).  Default: compile whenever hipcc is on the machine; specialize=False / FWGYM_JIT=0 keep the
+        # generic kernel (FWGYM_JIT=1 insists).  Either way the choice is announced: nobody should find out from a profile.
+        # (Batches below 1 024 envs -- the single-env class, unit tests -- are bound by launch and host overhead whatever the
+        # kernel: they keep the generic kernel silently unless asked.)
+        big = self.num_envs >= 1024
         if specialize is None:
-            specialize = os.environ.get("FWGYM_JIT", "0") == "1"
-        if specialize and _lib_path is None and not self._preset_matches():
-            from . import jit
-            path = jit.specialised_library(ec, auto_reset=auto_reset, store_derived=self.derived_views, base_lib=self._lib,
-                                           obs_log_rows=self.obs_log_rows)
-            if path is not None:
-                self._lib = nat.load_library(path)
+            env_jit = os.environ.get("FWGYM_JIT")
+            if env_jit is not None:
+                specialize = env_jit == "1"
+            else:
+                from . import jit as _jit
+                specialize = big and _jit.hipcc_path() is not None
+        if _lib_path is None and (specialize or big) and not self._preset_matches():
+            import warnings
+            path = None
+            if specialize:
+                from . import jit
+                if not jit.is_cached(ec, auto_reset=auto_reset, store_derived=self.derived_views, base_lib=self._lib,
+                                     obs_log_rows=self.obs_log_rows):
+                    warnings.warn("FixedWingVecEnv: this configuration is not one of the build-time presets; compiling a "
+                                  "specialised kernel for it with hipcc (one to two minutes, cached afterwards; "
+                                  "specialize=False or FWGYM_JIT=0 run the ~5x slower generic kernel instead)", RuntimeWarning, stacklevel=2)
+                path = jit.specialised_library(ec, auto_reset=auto_reset, store_derived=self.derived_views, base_lib=self._lib,
+                                               obs_log_rows=self.obs_log_rows)
+                if path is not None:
+                    self._lib = nat.load_library(path)
+            if path is None:
+                warnings.warn("FixedWingVecEnv: this configuration is not one of the build-time presets and no specialised "
+                              "kernel is available ({}): it runs the GENERIC kernel, about 5x slower per step than a specialised "
+                              "one".format("specialisation switched off" if not specialize else "hipcc missing or the compile failed"),
+                              RuntimeWarning, stacklevel=2)
         self.layout = nat.Layout()
         nat.check(self._lib, self._lib.fwg_get_layout(ctypes.byref(self._c), ctypes.byref(self.layout)))
         N, m = self.num_envs, self._mem
@@ -215,6 +239,24 @@ class FixedWingVecEnv(object):
         nat.check(self._lib, self._lib.fwg_set_graph_mode(self._handle, int(bool(enable)), self._mem.stream()))
         self._graph_mode = bool(enable)
         self._refresh_obs_view()
+
+    def set_obs_mirror(self, enable=True):
+        """Row-log envs: every step also leaves the dense [N, obs_dim] batch of the new observation in `_obs_dense`, assembled
+        inside the step kernel (fwg_set_obs_mirror) -- the form a torch consumer needs under hipGraph replay, where the
+        zero-copy window would go stale.  Opt-in (+432 B per env-step at C3); needs a specialised two-wave kernel and no
+        attached head.  Without it the observation handed out in graph mode is gathered by a launch of its own (fwg_obs_gather).
+        Returns whether the mirror is on."""
+        self._mirror = False
+        if not self.obs_log_rows:
+            return False
+        if enable:
+            st = self._lib.fwg_set_obs_mirror(self._handle, self._mem.ptr(self._obs_dense))
+            if st == 0:
+                self.obs_dense_gather()     # the current window, once; every step / reset keeps it current from here on
+                self._mirror = True
+        else:
+            self._lib.fwg_set_obs_mirror(self._handle, ctypes.c_void_p())
+        return self._mirror
 
     def capture_begin(self):
         """Brackets the step calls issued under stream capture.  Returns the step parity of the capture: the graph may only
@@ -304,11 +346,16 @@ class FixedWingVecEnv(object):
         return self._out(self._obs, (N,) + self.obs_shape)
 
     def obs_dense(self, out=None):
-        """Dense [N, obs_dim] copy of the current observation.  Row-log mode: gathered on the device from the window of
-        the last completed step (fwg_obs_gather; the position is read on the device in graph mode, so the call may be
-        captured and replayed)."""
+        """Dense [N, obs_dim] copy of the current observation.  Row-log mode: the mirror the step kernel keeps current
+        (set_obs_mirror) or, without it, gathered on the device from the window of the last completed step (fwg_obs_gather;
+        the position is read on the device in graph mode, so the call may be captured and replayed)."""
         if not self.obs_log_rows:
             return self._obs
+        if getattr(self, "_mirror", False) and out is None:
+            return self._obs_dense
+        return self.obs_dense_gather(out)
+
+    def obs_dense_gather(self, out=None):
         out = self._obs_dense if out is None else out
         nat.check(self._lib, self._lib.fwg_obs_gather(self._handle, self._mem.ptr(self._obs_buf), self._mem.ptr(out),
                                                       self._mem.stream()))
@@ -320,7 +367,7 @@ class FixedWingVecEnv(object):
         stale under replay, so the observation handed out is the dense copy gathered on the device instead."""
         if not self.obs_log_rows:
             return
-        if self._graph_mode:
+        if self._graph_mode or getattr(self, "_mirror", False):
             if want_obs:
                 self._obs = self.obs_dense()
             return

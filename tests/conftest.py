@@ -9,6 +9,11 @@ for p in (ROOT, os.path.join(ROOT, "fixed-wing-gym_amd"), os.path.join(ROOT, "te
         sys.path.insert(0, p)
 
 
+# the suite exercises the GENERIC kernel with its many small configuration variants: no run-time specialisation unless a test asks
+# for it (specialize=True); FixedWingVecEnv would otherwise compile a library per variant (its default when hipcc is present)
+os.environ.setdefault("FWGYM_JIT", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -24,9 +24,10 @@ def main():
     os.makedirs(os.path.dirname(out), exist_ok=True)
     inc = out + ".specs.inc"
     isa.spec_file(preset, inc)
-    csrc = os.path.join(ROOT, "fixed-wing-gym_amd", "csrc")
+    csrc = os.environ.get("DEVLIB_CSRC", os.path.join(ROOT, "fixed-wing-gym_amd", "csrc"))   # (another tree: an earlier commit's csrc/)
+    inc_dir = os.path.join(os.path.dirname(os.path.dirname(csrc)), "include") if "DEVLIB_CSRC" in os.environ else os.path.join(ROOT, "include")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=fast",
-           "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, '-DFWG_SPECS_FILE="{}"'.format(inc),
+           "-fno-slp-vectorize", "-I" + inc_dir, "-I" + csrc, '-DFWG_SPECS_FILE="{}"'.format(inc),
            "-DFWG_DEV_FAST_BUILD", "-o", out, os.path.join(csrc, "fwgym.hip")] + flags
     subprocess.run(cmd, check=True)
     os.remove(inc)
