@@ -453,15 +453,12 @@ def main():
         if vec.obs_log_rows:
             # an observation CONSUMER inside the replayed sequence: every step is followed by the gather of the dense
             # [N][length][n_obs] batch out of the row log (what a torch policy reads under graph replay), steady state
-            mirrored = R.vec.set_obs_mirror(True)
-            R.graphs.clear()    # (captured sequences bake the launch arguments in)
-            sides["obs_delivered"] = side_entry(R.time_replays(sc, sreps, want_obs=True), n_envs, mirror=bool(mirrored),
-                note="steady state + the dense [N][5][12] observation batch a torch consumer reads, current after every step of the "
-                     "replayed graph: " + ("assembled inside the step kernel (fwg_set_obs_mirror: the physics wave copies the lagged "
-                     "rows in its idle tail, the gym wave adds the new record)" if mirrored else "fwg_obs_gather after every step") +
-                     " (the HIP rollout head reads the row log in place instead: c5)")
-            R.vec.set_obs_mirror(False)
-            R.graphs.clear()
+            sides["obs_delivered"] = side_entry(R.time_replays(sc, sreps, want_obs=True), n_envs,
+                note="steady state + fwg_obs_gather after every step inside the replayed graph: the dense observation batch a "
+                     "torch consumer reads out of a ROW-LOG env (the HIP rollout head reads the log in place instead: c5).  A consumer "
+                     "that needs the dense batch every step is served cheaper by the dense layout (obs_log_rows=0): `dense_layout`. "
+                     "(Round 4 also built the copy inside the step kernel -- the physics wave moving the lagged rows in its idle "
+                     "tail: 19.4 us, +432 B per env-step of traffic on a kernel that moves 724; not kept.)")
     if side_ok and world == 1 and args.workload == "c3" and not args.stagger and not args.envs and not args.total_envs:
         def side_env(name, wl_cfg, n, rows, alg, note, stag=True, extra=None):
             try:

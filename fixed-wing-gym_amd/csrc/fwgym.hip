@@ -597,34 +597,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 store_sim<TURB>(c, A.S, A.N, e, E);
             }
         }
-        // dense mirror of the observation (fwg_set_obs_mirror): the lagged rows that sit in the log already -- the records of
-        // earlier steps -- are copied by THIS wave, in its idle tail; the padding rows of early lanes and a foreseen end's new
-        // window went out above (both copies at once); the gym wave adds row 0, and every row of a lane whose step failed or
-        // whose episode ends unforeseen (after this wave's second mark, so its stores land on top of these)
-        if (A.obs_mirror != nullptr && c.obs_log > 0 && c.obs_length > 1) {
-            if (valid && fail == 0 && !end_p) {
-#pragma unroll
-                for (int r = 1; r < FWG_MAX_ROWS; ++r) {
-                    if (r >= c.obs_length) continue;
-                    if (early_p && r * c.obs_step >= (int)steps_p) continue;   // (padding row: written above)
-                    const float* src = A.obs + (((A.log_win + r) * A.N + e) * c.n_obs);
-                    float v[FWG_MAX_OBS];
-                    if ((c.n_obs & 3) == 0) {
-#pragma unroll
-                        for (int q = 0; q < FWG_MAX_OBS / 4; ++q) {
-                            if (4 * q < c.n_obs) {
-                                const float4 t = reinterpret_cast<const float4*>(src)[q];
-                                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < FWG_MAX_OBS; ++j) v[j] = j < c.n_obs ? src[j] : 0.f;
-                    }
-                    mirror_store_row(c, A.obs_mirror, e, r, v);
-                }
-            }
-        }
         // hand-shake B, second mark, one way: everything above is in memory.  The gym wave waits for it only in a wave that
         // re-initialises an env itself (an episode that ended unforeseen: it overwrites this launch's simulator rows, and an
         // early lane's padding rows); this wave waits for nobody
@@ -926,13 +898,12 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     if (c.obs_log == 0) {
         write_obs<ROLE>(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull, A.acc != nullptr);
     } else {
-        float* const mirror = SPLIT ? A.obs_mirror : nullptr;
-        if (valid && !pre_rows) log_store_row(c, A.obs, A.N, e, log_win, 0, ob, mirror);   // the new record: 64 consecutive rows per wave
+        if (valid && !pre_rows) log_store_row(c, A.obs, A.N, e, log_win, 0, ob);   // the new record: 64 consecutive rows per wave
         if (__ballot((done || (early && !tail_rows)) && valid && !pre_rows) != 0ull) {
 #pragma unroll
             for (int r = 1; r < FWG_MAX_ROWS; ++r)
                 if (r < c.obs_length && valid && !pre_rows && (done || (early && !tail_rows && r * c.obs_step >= (int)log_pad_t)))
-                    log_store_row(c, A.obs, A.N, e, log_win, r, ob, mirror);
+                    log_store_row(c, A.obs, A.N, e, log_win, r, ob);
         }
     }
 #else
@@ -1057,7 +1028,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
         const long long win = A.log_win;
 #pragma unroll
         for (int r = 0; r < FWG_MAX_ROWS; ++r)
-            if (r < c.obs_length) log_store_row(c, A.obs, A.N, e, win, r, ob, A.obs_mirror);
+            if (r < c.obs_length) log_store_row(c, A.obs, A.N, e, win, r, ob);
     }
     if (sel) {
         store_sim<TURB>(c, A.S, A.N, e, E);
@@ -1310,7 +1281,6 @@ struct fwg_handle {
     StepSlots* d_slots;
     size_t lds_bytes;
     float* last_metrics_out;      // metrics block of the last fwg_step (what fwg_reduce_success* collect into)
-    float* obs_mirror;            // fwg_set_obs_mirror: dense copy of the observation written by every step / reset (row-log mode)
     unsigned* d_mq;               // simulator.model / randomize_scaling: two reset queues [2][1 + N] (by the parity of the step count)
     int model_all_stale;          // every env needs a new prepared set (start, fwg_update_config, fwg_seed): full-grid draw next
     struct fwg_actor* observer;   // attached rollout head (fwg_attach_observer) or null
@@ -1688,7 +1658,6 @@ int fwg_reset(fwg_handle* h, const uint8_t* mask, const float* init_state, const
     KArgs A;
     base_args(h, &A);
     A.mask = mask; A.init_state = init_state; A.init_target = init_target; A.obs = obs_out;
-    A.obs_mirror = h->obs_mirror;
     fill_slots(h, h->gstep - 1, &A);  // initial records take the ring position of the last completed step
     if (h->graph_mode) { A.slots_in = h->d_slots + (h->gstep & 1); A.reset_launch = 1; }
     if (h->d_mq != nullptr) A.mq = h->d_mq + (size_t)((h->gstep - 1) & 1) * (size_t)(1 + h->n_envs);   // as if part of the last step
@@ -1705,7 +1674,6 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
     base_args(h, &A);
     A.actions = actions; A.obs = obs_out; A.rew = reward_out; A.done = done_out; A.term = term_code_out;
     A.term_obs = terminal_obs_out; A.metrics = metrics_out; A.tgt_out = target_out;
-    A.obs_mirror = h->obs_mirror;
     h->last_metrics_out = metrics_out;
     fill_slots(h, h->gstep, &A);
     if (h->graph_mode) { A.slots_in = h->d_slots + (h->gstep & 1); A.slots_out = h->d_slots + ((h->gstep + 1) & 1); }
@@ -1730,18 +1698,6 @@ int fwg_obs_window(const fwg_handle* h, int64_t* plane) {
     if (!h || !plane) return fail_with(FWG_ERR_INVALID, "fwg_obs_window: null argument");
     if (h->h.obs_log <= 0) return fail_with(FWG_ERR_INVALID, "fwg_obs_window: the env writes the dense observation batch");
     *plane = host_slots(h, h->gstep - 1).log_win;   // last completed step
-    return FWG_OK;
-}
-
-int fwg_set_obs_mirror(fwg_handle* h, float* dense_obs_out) {
-    if (!h) return fail_with(FWG_ERR_INVALID, "fwg_set_obs_mirror: null handle");
-    if (dense_obs_out != nullptr) {
-        if (h->h.obs_log <= 0) return fail_with(FWG_ERR_INVALID, "fwg_set_obs_mirror: the env writes the dense observation batch already");
-        if (h->spec < 0 || !h->split)
-            return fail_with(FWG_ERR_INVALID, "fwg_set_obs_mirror: needs a specialised two-wave kernel (use fwg_obs_gather with the generic kernel)");
-        if (h->observer != nullptr) return fail_with(FWG_ERR_INVALID, "fwg_set_obs_mirror: not together with an attached rollout head");
-    }
-    h->obs_mirror = dense_obs_out;
     return FWG_OK;
 }
 

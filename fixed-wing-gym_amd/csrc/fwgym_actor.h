@@ -537,6 +537,23 @@ __device__ __forceinline__ unsigned actor_block(const ActorArgs& A, const ActorL
         if (q < n_pieces) reinterpret_cast<float4*>(F + q * 64)[l] = wreg[i];
     }
 #endif
+    // the sampling noise does not depend on the networks: drawn here (Philox + Box-Muller + exp(log_std)), under the wait for the
+    // other waves' weight pieces, instead of after the MLP at the end of the head phase
+    float noise_n[4] = {0.f, 0.f, 0.f, 0.f}, noise_s[FWG_ACT_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, lp = 0.f;
+    if (half == 0) {
+        if (!A.deterministic) {
+            const u4 b = philox4x32((unsigned)(A.env_base + e), act_ctr, 0u, FWG_STREAM_POLICY, A.seed_lo, A.seed_hi);
+            box_muller(b, noise_n);
+        }
+#pragma unroll
+        for (int i = 0; i < FWG_ACT_MAX_ACT; ++i) {
+            if (i < A.act_dim) {
+                const float ls = ls_in[i];
+                noise_s[i] = expf(ls) * noise_n[i];
+                lp += -0.5f * noise_n[i] * noise_n[i] - ls - 0.9189385332046727f;
+            }
+        }
+    }
     FWG_BLOCK_SYNC_LDS();
     FWG_ATL(A, 4);
     // both networks in one instruction stream: their MFMA chains and tanh phases are independent and interleave
@@ -545,24 +562,18 @@ __device__ __forceinline__ unsigned actor_block(const ActorArgs& A, const ActorL
     o_pi[0] = __uint_as_float(bx_hi[0].x ^ F[l].x); o_vf[0] = __uint_as_float(bx_lo[0].y);
 #else
     f32x16 o_pi, o_vf;
+    // (a static s_setprio 1 for the second-dispatched half of the waves around this call: measured, no effect)
     mlp_pair<SPLIT, NK1>(A, F, F + PARTS * nf * 64, Z.bias, Z.bias + FWG_ACT_BIAS_FLOATS, l, bx_hi, bx_lo, o_pi, o_vf);
 #endif
     FWG_ATL(A, 5);
     const float res[2][FWG_ACT_MAX_ACT] = {{o_pi[0], o_pi[1], o_pi[2], o_pi[3]}, {o_vf[0], o_vf[1], o_vf[2], o_vf[3]}};
     if (half == 0) {
-        float n[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!A.deterministic) {
-            const u4 b = philox4x32((unsigned)(A.env_base + e), act_ctr, 0u, FWG_STREAM_POLICY, A.seed_lo, A.seed_hi);
-            box_muller(b, n);
-        }
-        float lp = 0.f, act[FWG_ACT_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+        float act[FWG_ACT_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < FWG_ACT_MAX_ACT; ++i) {
             if (i < A.act_dim) {
-                const float ls = ls_in[i];
-                act[i] = res[0][i] + expf(ls) * n[i];
+                act[i] = res[0][i] + noise_s[i];
                 if (A.action != nullptr && valid) A.action[e * A.act_dim + i] = act[i];
-                lp += -0.5f * n[i] * n[i] - ls - 0.9189385332046727f;
             }
         }
         // (k_rollout) the env step of this same launch takes the actions from here

@@ -10,8 +10,7 @@ struct KArgs {
     long N;
     long env_base;            // global index of env 0 of this handle (RNG streams)
     const float* actions;     // [N][3]
-    float* obs;               // [N][obs_dim] (dense batch) or the observation row log
-    float* obs_mirror;        // row-log mode, nullable (fwg_set_obs_mirror): dense [N][obs_dim] copy of the new observation
+    float* obs;               // [N][obs_dim]
     float* rew;               // [N]
     uint8_t* done;            // [N]
     uint8_t* term;            // [N]
@@ -209,29 +208,9 @@ __device__ __forceinline__ KArgs resolve_slots(const DevCfg& c, const KArgs& A0)
 __device__ __forceinline__ float* log_row(const DevCfg& c, float* log, long N, long e, long long plane) {
     return log + ((plane * N + e) * c.n_obs);
 }
-// row r of env e into the dense mirror [N][obs_length n_obs] (fwg_set_obs_mirror): 16-byte pieces when the row allows
-__device__ __forceinline__ void mirror_store_row(const DevCfg& c, float* mirror, long e, int r, const float (&v)[FWG_MAX_OBS]) {
-    float* dst = mirror + (e * c.obs_length + r) * c.n_obs;
-    if ((c.n_obs & 3) == 0) {
-#pragma unroll
-        for (int q = 0; q < FWG_MAX_OBS / 4; ++q)
-            if (4 * q < c.n_obs) reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < FWG_MAX_OBS; ++j)
-            if (j < c.n_obs) dst[j] = v[j];
-    }
-}
 // record r (0 = newest) of the observation record `ob` -> row r of the window starting at plane `win`
 template <class OB>
-__device__ __forceinline__ void log_store_row(const DevCfg& c, float* log, long N, long e, long long win, int r, const OB& ob,
-                                              float* mirror = nullptr) {
-    if (mirror != nullptr) {
-        float v[FWG_MAX_OBS];
-#pragma unroll
-        for (int j = 0; j < FWG_MAX_OBS; ++j) v[j] = j < c.n_obs ? ob.get(r * c.n_obs + j) : 0.f;
-        mirror_store_row(c, mirror, e, r, v);
-    }
+__device__ __forceinline__ void log_store_row(const DevCfg& c, float* log, long N, long e, long long win, int r, const OB& ob) {
     float* row = log_row(c, log, N, e, win + r);
     if ((c.n_obs & 3) == 0) {
 #pragma unroll
@@ -860,7 +839,6 @@ __device__ __forceinline__ void early_rows_to_log(const DevCfg& c, const KArgs& 
             for (int j = 0; j < FWG_MAX_OBS; ++j)
                 if (j < c.n_obs) dst[j] = v[j];
         }
-        if (A.obs_mirror != nullptr) mirror_store_row(c, A.obs_mirror, e, r, v);
     }
 }
 __device__ __forceinline__ void early_rows_request(const DevCfg& c, const KArgs& A, long e, float (&rec)[FWG_MAX_OBS]) {
@@ -1409,19 +1387,21 @@ __device__ __forceinline__ void reset_rows_to_log(const DevCfg& c, const KArgs& 
         if (r >= c.obs_length) continue;
         const float noise = D.row_noise[r];
         float* dst = log_row(c, A.obs, A.N, e, win + r);
-        float vr[FWG_MAX_OBS];
-#pragma unroll
-        for (int j = 0; j < FWG_MAX_OBS; ++j) vr[j] = j < c.n_obs ? row.get(j) + noise * (c.obs[j].norm ? c.obs[j].inv_var : 1.f) : 0.f;
         if ((c.n_obs & 3) == 0) {
 #pragma unroll
-            for (int q = 0; q < FWG_MAX_OBS / 4; ++q)
-                if (4 * q < c.n_obs) reinterpret_cast<float4*>(dst)[q] = make_float4(vr[4 * q], vr[4 * q + 1], vr[4 * q + 2], vr[4 * q + 3]);
+            for (int q = 0; q < FWG_MAX_OBS / 4; ++q) {
+                if (4 * q < c.n_obs) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = row.get(4 * q + i) + noise * (c.obs[4 * q + i].norm ? c.obs[4 * q + i].inv_var : 1.f);
+                    reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j)
-                if (j < c.n_obs) dst[j] = vr[j];
+                if (j < c.n_obs) dst[j] = row.get(j) + noise * (c.obs[j].norm ? c.obs[j].inv_var : 1.f);
         }
-        if (A.obs_mirror != nullptr) mirror_store_row(c, A.obs_mirror, e, r, vr);
     }
 }
 

@@ -151,7 +151,7 @@ EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fw
            "fwg_capture_begin", "fwg_capture_end", "fwg_capture_parity", "fwg_replay_check", "fwg_finish_episodes", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
            "fwg_actor_set_stats", "fwg_actor_get_stats", "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe",
            "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window", "fwg_reduce_success_device",
-           "fwg_obs_gather", "fwg_actor_set_obs_log", "fwg_selftest_philox", "fwg_rollout_available", "fwg_rollout_step", "fwg_set_obs_mirror"]
+           "fwg_obs_gather", "fwg_actor_set_obs_log", "fwg_selftest_philox", "fwg_rollout_available", "fwg_rollout_step"]
 _libs = {}
 
 
@@ -232,8 +232,6 @@ def load_library(path=None):
     lib.fwg_attach_observer.argtypes = [vp, vp]
     lib.fwg_attach_observer.restype = C.c_int
     lib.fwg_actor_act.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
-    lib.fwg_set_obs_mirror.argtypes = [vp, vp]
-    lib.fwg_set_obs_mirror.restype = C.c_int
     lib.fwg_rollout_available.argtypes = [vp, vp]
     lib.fwg_rollout_available.restype = C.c_int
     lib.fwg_rollout_step.argtypes = [vp, vp] + [vp] * 12 + [C.c_int, vp]

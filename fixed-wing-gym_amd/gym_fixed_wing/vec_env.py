@@ -240,24 +240,6 @@ class FixedWingVecEnv(object):
         self._graph_mode = bool(enable)
         self._refresh_obs_view()
 
-    def set_obs_mirror(self, enable=True):
-        """Row-log envs: every step also leaves the dense [N, obs_dim] batch of the new observation in `_obs_dense`, assembled
-        inside the step kernel (fwg_set_obs_mirror) -- the form a torch consumer needs under hipGraph replay, where the
-        zero-copy window would go stale.  Opt-in (+432 B per env-step at C3); needs a specialised two-wave kernel and no
-        attached head.  Without it the observation handed out in graph mode is gathered by a launch of its own (fwg_obs_gather).
-        Returns whether the mirror is on."""
-        self._mirror = False
-        if not self.obs_log_rows:
-            return False
-        if enable:
-            st = self._lib.fwg_set_obs_mirror(self._handle, self._mem.ptr(self._obs_dense))
-            if st == 0:
-                self.obs_dense_gather()     # the current window, once; every step / reset keeps it current from here on
-                self._mirror = True
-        else:
-            self._lib.fwg_set_obs_mirror(self._handle, ctypes.c_void_p())
-        return self._mirror
-
     def capture_begin(self):
         """Brackets the step calls issued under stream capture.  Returns the step parity of the capture: the graph may only
         be replayed at that parity (replay_check)."""
@@ -346,16 +328,11 @@ class FixedWingVecEnv(object):
         return self._out(self._obs, (N,) + self.obs_shape)
 
     def obs_dense(self, out=None):
-        """Dense [N, obs_dim] copy of the current observation.  Row-log mode: the mirror the step kernel keeps current
-        (set_obs_mirror) or, without it, gathered on the device from the window of the last completed step (fwg_obs_gather;
-        the position is read on the device in graph mode, so the call may be captured and replayed)."""
+        """Dense [N, obs_dim] copy of the current observation.  Row-log mode: gathered on the device from the window of
+        the last completed step (fwg_obs_gather; the position is read on the device in graph mode, so the call may be
+        captured and replayed)."""
         if not self.obs_log_rows:
             return self._obs
-        if getattr(self, "_mirror", False) and out is None:
-            return self._obs_dense
-        return self.obs_dense_gather(out)
-
-    def obs_dense_gather(self, out=None):
         out = self._obs_dense if out is None else out
         nat.check(self._lib, self._lib.fwg_obs_gather(self._handle, self._mem.ptr(self._obs_buf), self._mem.ptr(out),
                                                       self._mem.stream()))
@@ -367,7 +344,7 @@ class FixedWingVecEnv(object):
         stale under replay, so the observation handed out is the dense copy gathered on the device instead."""
         if not self.obs_log_rows:
             return
-        if self._graph_mode or getattr(self, "_mirror", False):
+        if self._graph_mode:
             if want_obs:
                 self._obs = self.obs_dense()
             return

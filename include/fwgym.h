@@ -316,13 +316,6 @@ int fwg_step(fwg_handle* h, const float* actions, float* obs_out, float* reward_
  * fwg_step / fwg_reset.  Values are identical to the dense batch.  `plane` refers to the last completed step. */
 int64_t fwg_obs_log_floats(const fwg_config* cfg_host, int64_t n_envs);
 int fwg_obs_window(const fwg_handle* h, int64_t* plane);
-/* Row-log envs: from now on every fwg_step / fwg_reset ALSO leaves the dense batch [N][obs_length * n_obs] of the new
- * observation in `dense_obs_out` (NULL switches it off) -- what get_observation returns (fixed_wing.py:776-846) for a consumer
- * that needs a contiguous batch every step (a torch policy under hipGraph replay).  The copy is assembled inside the step
- * kernel: the physics wave moves the lagged rows in its idle tail, the gym wave adds the new record; no gather launch
- * (fwg_obs_gather: 8 us + a launch boundary per step at 65 536 envs).  Needs a specialised two-wave kernel and no attached
- * rollout head (the HIP head reads the log in place).  The buffer is NOT filled by this call: fwg_obs_gather once, then step. */
-int fwg_set_obs_mirror(fwg_handle* h, float* dense_obs_out);
 /* Dense copy [N][obs_length * n_obs] of the current window of `obs_log` (the buffer fwg_step writes), for consumers that
  * need contiguous rows.  Stream-ordered; in graph mode the window position is read on the DEVICE, so the call may be
  * captured and replayed (a host-side view from fwg_obs_window is only valid for direct calls).  n_obs % 4 == 0. */

@@ -230,40 +230,3 @@ def test_device_resident_positions_equal_host_positions_emulated(kind, rows, ckw
         np.testing.assert_array_equal(np.asarray(oa).reshape(6, -1), np.asarray(ob).reshape(6, -1))
     a.close(), b.close()
 
-
-def test_obs_mirror_equals_the_gathered_window_emulated():
-    """fwg_set_obs_mirror: the dense copy the two waves of the step kernel assemble (lagged rows by the physics wave, the new
-    record by the gym wave; padding rows of early lanes, foreseen time-limit ends installed by the physics wave, failure ends
-    re-initialised by the gym wave) == fwg_obs_gather of the row log, after every step of three episodes per env."""
-    import copy
-    from emu.host_backend import HostBackend, build_emu_spec
-    from gym_fixed_wing.config import EnvConfig
-    from gym_fixed_wing import presets
-    cfg = configs.reference_like("cnn")
-    ckw = {"steps_max": 23, "observation": {"step": 2}}
-    skw = {"turbulence": True, "turbulence_intensity": "moderate"}
-    ec = EnvConfig(copy.deepcopy(cfg), config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
-    lib = build_emu_spec(ec, auto_reset=True, store_derived=True, obs_log_rows=presets.OBS_LOG_ROWS)
-    n = 70
-    vec = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=n, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw), seed=5,
-                          as_numpy=True, _backend=HostBackend(), _lib_path=lib)
-    assert vec.spec_index == 0 and vec.obs_log_rows
-    vec.reset()
-    assert vec.set_obs_mirror(True)
-    rng = np.random.default_rng(1)
-    ends = 0
-    for t in range(75):
-        a = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
-        if t % 11 == 3:
-            a[:7] = 1.0   # hard-over commands: a few failure ends on top of the time-limit ones
-        _, _, d = vec.step_device(a)
-        ends += int(np.asarray(d).sum())
-        mirror = np.array(vec.obs_dense())
-        gathered = np.array(vec.obs_dense_gather(out=np.zeros_like(mirror)))
-        np.testing.assert_array_equal(mirror, gathered, err_msg="step {}".format(t))
-        if t == 40:   # an explicit reset of some envs keeps the mirror current too
-            vec.reset(indices=[1, 5, 64, 69])
-            mirror = np.array(vec.obs_dense())
-            np.testing.assert_array_equal(mirror, np.array(vec.obs_dense_gather(out=np.zeros_like(mirror))))
-    assert ends >= 2 * n + 40   # (three rounds of time-limit ends, shifted for the four envs reset by hand, plus failure ends)
-    vec.close()
