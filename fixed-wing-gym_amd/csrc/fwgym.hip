@@ -357,6 +357,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     bool pre_end = false, pre_draw = false, pre_rows = false;
     float4 pre_tag = make_float4(0.f, 0.f, 0.f, 0.f), pre_old = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 int_old = make_float4(0.f, 0.f, 0.f, 0.f);   // integration_window: cumulative error sums W + 1 records back
+    float4 sum_prev = make_float4(0.f, 0.f, 0.f, 0.f);  // the cumulative error sums through the previous record (packed Fix3)
     ResetDraw RD;
     // lanes in the first steps of an episode: the padding rows of their observation, up to the "action" entries
     bool pre_early = false;
@@ -389,6 +390,10 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
         }
         E.steps += 1u;
+        if (c.metrics) {   // S_(t-1): the cumulative error sums (fixed point, fwgym_env.h Fix3) through the previous record
+            int slot = A.slot_end - 1; slot += (slot < 0) ? FWG_END_RING : 0;
+            sum_prev = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+        }
         if (c.int_window) {   // S_(t-1-W): the record W + 1 positions before this step's in the cumulative error ring
             int slot = A.slot_end - (c.int_window + 1); slot += (slot < 0) ? FWG_END_RING : 0;
             int_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
@@ -621,18 +626,22 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // cumulative sums: S_(t-1) (E.esum has not taken this step's error yet) - S_(t-1-W), padded with the initial error while
     // the episode is younger than the window.  After a failed step the histories are one record shorter: S_(t-2) - S_(t-2-W)
     float wsum[3] = {0.f, 0.f, 0.f};
+    Fix3 S_prev = {{0ll, 0ll, 0ll}};   // cumulative error sums through the previous record (exact: fixed point)
+    if (c.metrics) S_prev = fix3_unpack(sum_prev);
     if (c.int_window) {
         const int t = (int)E.steps, W = c.int_window;
         if (ok) {
+            const Fix3 o = fix3_unpack(int_old);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) wsum[k] = E.esum[k] - ((t - 1 - W >= 0) ? (k == 0 ? int_old.x : (k == 1 ? int_old.y : int_old.z)) : 0.f);
-        } else {
-            float4 o2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < 3; ++k) wsum[k] = fix_to_float(S_prev.s[k] - ((t - 1 - W >= 0) ? o.s[k] : 0ll));
+        } else {   // S_(t-2) = S_(t-1) - the previous record's error (E.perr is the very float that was quantised into it)
+            Fix3 o2 = {{0ll, 0ll, 0ll}};
             if (t - 2 - W >= 0) {
                 int slot = A.slot_end - (W + 2); slot += (slot < 0) ? FWG_END_RING : 0;
-                o2 = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+                o2 = fix3_unpack(CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e));
             }
-            wsum[0] = E.esum[0] - E.perr[0] - o2.x; wsum[1] = E.esum[1] - E.perr[1] - o2.y; wsum[2] = E.esum[2] - E.perr[2] - o2.z;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wsum[k] = fix_to_float(S_prev.s[k] - fix_quant(E.perr[k]) - o2.s[k]);
         }
 #pragma unroll
         for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
@@ -742,7 +751,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
             // the ring holds the episode's CUMULATIVE error sums: the sum over the last 50 records is then the difference
             // of two entries (one load at the episode end instead of the whole window)
-            if (valid) store_group_once(A.S, A.N, (L.end_ring >> 2) + A.slot_end, e, make_float4(E.esum[0], E.esum[1], E.esum[2], 0.f));
+            Fix3 S_new;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) S_new.s[k] = S_prev.s[k] + (k < c.n_targets ? fix_quant(err[k]) : 0ll);
+            if (valid) store_group_once(A.S, A.N, (L.end_ring >> 2) + A.slot_end, e, fix3_pack(S_new));
+            S_prev = S_new;   // (from here on: the sums through the LAST record of the histories, whether this step appended one or not)
         }
     } else {
         done = true;
@@ -845,12 +858,15 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     R.e0[k] = E.e0[k]; R.esum[k] = E.esum[k]; R.eabs[k] = E.eabs[k]; R.emin[k] = E.emin[k]; R.emax[k] = E.emax[k];
-                    R.end_sum[k] = E.esum[k]; R.rise[k] = E.rise[k];
+                    R.rise[k] = E.rise[k];
                 }
                 R.settle[0] = E.settle[0]; R.settle[1] = E.settle[1]; R.gcnt[0] = E.gcnt[0]; R.gcnt[1] = E.gcnt[1]; R.sdcmd = E.sdcmd;
-                if (R.n_rec > (unsigned)FWG_END_WINDOW) {
-                    // (requested before the integration for a foreseen end, before the bookkeeping stores otherwise)
-                    R.end_sum[0] -= pre_old.x; R.end_sum[1] -= pre_old.y; R.end_sum[2] -= pre_old.z;
+                {   // sum of the last <= 50 errors, exactly: S_last - S_(last - 50) in fixed point (the old slot was requested
+                    // before the integration for a foreseen end, before the bookkeeping stores otherwise)
+                    const Fix3 old = fix3_unpack(pre_old);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        R.end_sum[k] = fix_to_float(S_prev.s[k] - (R.n_rec > (unsigned)FWG_END_WINDOW ? old.s[k] : 0ll));
                 }
                 if (E.flags & FWG_FLAG_FIN_PENDING) fin_collect_pending(c, A, e);   // (rare) never collected: fold it now
                 fin_store(c, A.S, A.N, e, R);
@@ -1011,15 +1027,19 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
         const bool last_failed = (E.flags & FWG_FLAG_LAST_FAILED) != 0u;
         const int steps = (int)(f2u(q0.w) & 0xFFFFu), W = c.int_window;
         const int n = last_failed ? steps : steps + 1;                  // records in the old histories
-        const float esum[3] = {q2.x, q2.y, q2.z}, perr[3] = {q2.w, q3.w, q4.y}, e0[3] = {q7.y, q7.z, q7.w};
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n - W - 2 >= 0) {   // S_(n-W-2): W + 1 records before the last one (which sits one slot earlier after a failed step)
+        const float perr[3] = {q2.w, q3.w, q4.y}, e0[3] = {q7.y, q7.z, q7.w};
+        // S_(n-1): the cumulative sums (fixed point, fwgym_env.h Fix3) through the last record, which sits one slot earlier after
+        // a failed step; S_(n-2) = S_(n-1) - that record's error; S_(n-W-2): W + 1 records before the last one
+        int last = A.slot_end - (last_failed ? 1 : 0); last += (last < 0) ? FWG_END_RING : 0;
+        const Fix3 Sl = fix3_unpack(CGROUP(A.S, A.N, (c.L.end_ring >> 2) + last, e));
+        Fix3 o = {{0ll, 0ll, 0ll}};
+        if (n - W - 2 >= 0) {
             int slot = A.slot_end - (last_failed ? 1 : 0) - (W + 1); slot += (slot < 0) ? FWG_END_RING : 0; slot += (slot < 0) ? FWG_END_RING : 0;
-            o = CGROUP(A.S, A.N, (c.L.end_ring >> 2) + slot, e);
+            o = fix3_unpack(CGROUP(A.S, A.N, (c.L.end_ring >> 2) + slot, e));
         }
-        E.int_reset[0] = esum[0] - perr[0] - o.x + (float)(W + 1) * e0[0];
-        E.int_reset[1] = esum[1] - perr[1] - o.y + (float)(W + 1) * e0[1];
-        E.int_reset[2] = esum[2] - perr[2] - o.z + (float)(W + 1) * e0[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) E.int_reset[k] = fix_to_float(Sl.s[k] - fix_quant(perr[k]) - o.s[k]) + (float)(W + 1) * e0[k];
+        (void)q2;
     }
     if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane * 4, A.slot_end, A.slot_lag, A.bit_goal);
     if (c.obs_log == 0) {

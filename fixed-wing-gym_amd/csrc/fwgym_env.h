@@ -312,6 +312,45 @@ struct LdsTable {
     __device__ __forceinline__ void put(int i, float x) { p[i * FWG_WAVE] = x; }
 };
 
+// ---- The end-error ring holds the episode's CUMULATIVE error sums (one 16-byte slot per record, 51 slots): the sum over the
+// last 50 records -- end_error, fixed_wing.py:1106-1107 -- is the difference of two slots, one load at the episode end instead of
+// the whole window; integration_window sums likewise.  The sums are 42-bit FIXED POINT (2^-22 resolution, three to a slot): a
+// float32 running sum reaches 10^3 - 10^4 late in a 2 000-step episode and the difference of two of them then carries 1e-4 - 1e-3
+// of absolute error (rounds 1-3); integer sums are exact, so the window sum carries only the 50 quantisation errors of its own
+// terms (< 6e-6, 1e-7 on the mean) whatever the episode length.  |error| < 512 and |sum| < 5e5 by construction.
+#define FWG_ESUM_FRAC 22
+#define FWG_ESUM_SCALE 4194304.f
+struct Fix3 { long long s[3]; };
+__device__ __forceinline__ long long fix_quant(float err) {
+#ifdef FWG_EMU
+    const float x = rintf(err * FWG_ESUM_SCALE);
+    return (long long)(x >= 2147483520.f ? 2147483520.f : (x <= -2147483520.f ? -2147483520.f : x));
+#else
+    return (long long)__float2int_rn(err * FWG_ESUM_SCALE);   // (v_cvt_i32_f32 saturates)
+#endif
+}
+__device__ __forceinline__ float fix_to_float(long long d) {   // d 2^-22 for |d| < 2^47: two exact conversions and one fma
+    const int hi = (int)(d >> 16), lo = (int)(d & 0xFFFFll);
+    return ((float)hi * 65536.f + (float)lo) * (1.f / FWG_ESUM_SCALE);
+}
+__device__ __forceinline__ float4 fix3_pack(const Fix3& f) {
+    const unsigned long long M = 0x3FFFFFFFFFFull;
+    const unsigned long long a = (unsigned long long)f.s[0] & M, b = (unsigned long long)f.s[1] & M, c = (unsigned long long)f.s[2] & M;
+    const unsigned long long lo = a | (b << 42), hi = (b >> 22) | (c << 20);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
+                       __uint_as_float((unsigned)(hi >> 32)));
+}
+__device__ __forceinline__ Fix3 fix3_unpack(const float4& q) {
+    const unsigned long long M = 0x3FFFFFFFFFFull;
+    const unsigned long long lo = (unsigned long long)__float_as_uint(q.x) | ((unsigned long long)__float_as_uint(q.y) << 32);
+    const unsigned long long hi = (unsigned long long)__float_as_uint(q.z) | ((unsigned long long)__float_as_uint(q.w) << 32);
+    Fix3 f;
+    f.s[0] = (long long)((lo & M) << 22) >> 22;
+    f.s[1] = (long long)((((lo >> 42) | (hi << 22)) & M) << 22) >> 22;
+    f.s[2] = (long long)(((hi >> 20) & M) << 22) >> 22;
+    return f;
+}
+
 struct Env {
     float y[NY];
     float wind[3];
@@ -1465,7 +1504,12 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
     }
     E.settle[0] = 0xFFFFFFFFu; E.settle[1] = 0xFFFFFFFFu;
     E.sdcmd = 0.f;
-    if (c.metrics) GROUP(A.S, A.N, (c.L.end_ring >> 2) + g_end, e) = make_float4(err[0], err[1], err[2], 0.f);
+    if (c.metrics) {   // record 0 of the cumulative error sums (fixed point, see Fix3)
+        Fix3 s0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s0.s[k] = fix_quant(err[k]);
+        GROUP(A.S, A.N, (c.L.end_ring >> 2) + g_end, e) = fix3_pack(s0);
+    }
     E.wcnt = 0u; E.gcnt[0] = 0u; E.gcnt[1] = 0u;
     if (c.goal_enabled) {   // the ring keeps its old contents (see goal_push); only the word holding g_bit is touched
         // (have_gw: the step kernel holds that very word in E.gw already -- it is the one this step's record went into)
