@@ -358,6 +358,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     float4 pre_tag = make_float4(0.f, 0.f, 0.f, 0.f), pre_old = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 int_old = make_float4(0.f, 0.f, 0.f, 0.f);   // integration_window: cumulative error sums W + 1 records back
     float4 sum_prev = make_float4(0.f, 0.f, 0.f, 0.f);  // the cumulative error sums through the previous record (packed Fix3)
+    Fix3 S_prev = {{0ll, 0ll, 0ll}};                    // ... unpacked at the end of the pre-barrier work (exact: fixed point)
     ResetDraw RD;
     // lanes in the first steps of an episode: the padding rows of their observation, up to the "action" entries
     bool pre_early = false;
@@ -499,6 +500,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (pre_install) pre_rows = pre_draw && f2u(pre_tag.x) == dc.generation && f2u(pre_tag.y) == E.episode + 1u;
         if (tail_rows || pre_install)   // (every lane) for the partner: this step's index if its rows need padding | install flag
             *reinterpret_cast<float4*>(acts) = make_float4(u2f((tail_rows && early_now) ? E.steps : 0u), u2f(pre_rows ? 1u : 0u), 0.f, 0.f);
+        // (unpacked here, in the time this wave waits for its partner anyway, not on the chain after the barrier)
+        if (c.metrics) S_prev = fix3_unpack(sum_prev);
     };
     if (SPLIT && GYM) {
         FWG_DMA_DRAIN();   // this wave's own streamed windows have landed (no other wave reads them)
@@ -626,8 +629,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // cumulative sums: S_(t-1) (E.esum has not taken this step's error yet) - S_(t-1-W), padded with the initial error while
     // the episode is younger than the window.  After a failed step the histories are one record shorter: S_(t-2) - S_(t-2-W)
     float wsum[3] = {0.f, 0.f, 0.f};
-    Fix3 S_prev = {{0ll, 0ll, 0ll}};   // cumulative error sums through the previous record (exact: fixed point)
-    if (c.metrics) S_prev = fix3_unpack(sum_prev);
     if (c.int_window) {
         const int t = (int)E.steps, W = c.int_window;
         if (ok) {
@@ -754,7 +755,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             Fix3 S_new;
 #pragma unroll
             for (int k = 0; k < 3; ++k) S_new.s[k] = S_prev.s[k] + (k < c.n_targets ? fix_quant(err[k]) : 0ll);
-            if (valid) store_group_once(A.S, A.N, (L.end_ring >> 2) + A.slot_end, e, fix3_pack(S_new));
+            // (a plain store: the NEXT step reads this very slot back -- a streaming store would push it out of the L2 first)
+            if (valid) GROUP(A.S, A.N, (L.end_ring >> 2) + A.slot_end, e) = fix3_pack(S_new);
             S_prev = S_new;   // (from here on: the sums through the LAST record of the histories, whether this step appended one or not)
         }
     } else {
