@@ -2157,7 +2157,14 @@ static int launch_rollout_one(fwg_handle* h, fwg_actor* a, const KArgs& A, const
             if (bytes > 160 * 1024) return 1;
             const dim3 grid((unsigned)((h->n_envs + FWG_RO_ENVS - 1) / FWG_RO_ENVS)), block(2 * FWG_RO_ENVS);
             const void* fn = a->precise ? (const void*)k_rollout<TURB, SPEC, 3> : (const void*)k_rollout<TURB, SPEC, 1>;
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
+            // more than 64 KiB of dynamic LDS has to be asked for -- once per kernel and device, on the first (never captured:
+            // FusedRollout warms every kernel up outside the capture) launch, not inside a stream capture
+            static size_t granted[2][16] = {};
+            size_t& have = granted[a->precise ? 1 : 0][h->device & 15];
+            if (have < bytes) {
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
+                have = bytes;
+            }
             if (a->precise) hipLaunchKernelGGL((k_rollout<TURB, SPEC, 3>), grid, block, bytes, stream, h->d_cfg, h->d_dyn, A, AA);
             else hipLaunchKernelGGL((k_rollout<TURB, SPEC, 1>), grid, block, bytes, stream, h->d_cfg, h->d_dyn, A, AA);
             return 0;

@@ -20,9 +20,10 @@ def parse(path, kernel):
 
 
 out = {}
-TAG = sys.argv[1] if len(sys.argv) > 1 else "v13"
-for key, fn, kernel in (("c3_log", "r03_c3_rocprofv3_summary_{}.txt".format(TAG), "k_step2<true, 6>"),
-                        ("c3", "r03_c3_dense_rocprofv3_summary_{}.txt".format(TAG), "k_step2<true, 4>")):
+TAG = sys.argv[1] if len(sys.argv) > 1 else "v15"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r04"
+for key, fn, kernel in (("c3_log", "{}_c3_rocprofv3_summary_{}.txt".format(RND, TAG), "k_step2<true, 6>"),
+                        ("c3", "{}_c3_dense_rocprofv3_summary_{}.txt".format(RND, TAG), "k_step2<true, 4>")):
     p = os.path.join(ROOT, "profiles", fn)
     if not os.path.exists(p):
         continue
