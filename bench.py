@@ -85,10 +85,59 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0
 
 
+def _usable_cpus(present):
+    """Host threads this process may actually keep busy: the affinity mask, capped by the container's CPU quota (cgroup v2
+    cpu.max / v1 cfs_quota_us).  os.cpu_count() reports the machine; a pod limited to a dozen CPUs that starts one worker per
+    reported core measures time-slicing, not the host (round 3/4: 31 env-steps/s per process at "256 cores" against 750 for a
+    process by itself -- a total of ten single-process rates)."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = present
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        usable = max(1, min(usable, int(quota)))
+    return usable, quota
+
+
+def _spin_worker(seconds):
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(2000):
+            n += 1
+    return n / (time.perf_counter() - t0)
+
+
+def _effective_parallelism(ctx, usable, seconds=1.5):
+    """How many processes' worth of interpreter work the host really delivers at once (a pure-Python spin loop, `usable`
+    processes against one): catches CPU limits that no file shows (shares, a throttled pod, SMT siblings counted as cores)."""
+    with ctx.Pool(1) as pool:
+        one = pool.map(_spin_worker, [seconds])[0]
+    with ctx.Pool(usable) as pool:
+        agg = sum(pool.map(_spin_worker, [seconds] * usable))
+    return max(1.0, agg / one)
+
+
 def cpu_baseline(wl, seconds, max_procs=0):
     import multiprocessing as mp
     present = os.cpu_count() or 1
-    cores = max(1, present if max_procs <= 0 else min(present, max_procs))
+    usable, quota = _usable_cpus(present)
+    cores = max(1, usable if max_procs <= 0 else min(usable, max_procs))
     try:   # one interpreter + NumPy/SciPy per process: stay well inside the host's free memory
         import psutil
         cores = max(1, min(cores, int(psutil.virtual_memory().available // (512 << 20))))
@@ -101,8 +150,15 @@ def cpu_baseline(wl, seconds, max_procs=0):
     saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS")}
     for k in saved:
         os.environ[k] = "1"
+    effective = None
     try:
         ctx = mp.get_context("spawn")
+        if cores > 16:   # one worker per core the host really gives us, not per core it lists
+            try:
+                effective = _effective_parallelism(ctx, cores)
+                cores = max(1, min(cores, int(round(effective))))
+            except Exception:
+                effective = None
         with ctx.Pool(1) as pool:   # the single-process rate next to it: shows whether the all-core figure is oversubscribed
             n1, dt1 = pool.map(_cpu_worker, [(wl, min(seconds, 4.0), 99)])[0]
         with ctx.Pool(cores) as pool:
@@ -114,9 +170,10 @@ def cpu_baseline(wl, seconds, max_procs=0):
             else:
                 os.environ[k] = v
     total = sum(n / dt for n, dt in res)
-    out = {"value": total, "unit": "env-steps/s", "cores": cores, "cores_present": present, "kind": "port",
+    out = {"value": total, "unit": "env-steps/s", "cores": cores, "cores_present": present, "cpu_quota": quota, "effective_parallelism": effective, "kind": "port",
            "per_process": total / cores, "single_process": n1 / dt1, "threads_per_process": 1,
-           "sample": "{} oracle processes (one per host core, one thread each; float64 NumPy restatement, 1 env each, same workload "
+           "sample": "{} oracle processes (one per host core the process can really keep busy -- affinity mask, container quota, a "
+                     "measured spin-loop calibration --, one thread each; float64 NumPy restatement, 1 env each, same workload "
                      "config) x {:.0f} s, {} env-steps in total; a process by itself: {:.0f} env-steps/s".format(
                          cores, seconds, sum(n for n, _ in res), n1 / dt1)}
     try:   # second CPU number: the product kernel source compiled for the host (tests/emu, lock-step lane
@@ -453,10 +510,10 @@ def main():
         if vec.obs_log_rows:
             # an observation CONSUMER inside the replayed sequence: every step is followed by the gather of the dense
             # [N][length][n_obs] batch out of the row log (what a torch policy reads under graph replay), steady state
-            sides["obs_delivered"] = side_entry(R.time_replays(sc, sreps, want_obs=True), n_envs,
+            sides["obs_gather_row_log"] = side_entry(R.time_replays(sc, sreps, want_obs=True), n_envs,
                 note="steady state + fwg_obs_gather after every step inside the replayed graph: the dense observation batch a "
                      "torch consumer reads out of a ROW-LOG env (the HIP rollout head reads the log in place instead: c5).  A consumer "
-                     "that needs the dense batch every step is served cheaper by the dense layout (obs_log_rows=0): `dense_layout`. "
+                     "that needs the dense batch every step is served cheaper by the dense layout (obs_layout='dense'): `obs_delivered`. "
                      "(Round 4 also built the copy inside the step kernel -- the physics wave moving the lagged rows in its idle "
                      "tail: 19.4 us, +432 B per env-step of traffic on a kernel that moves 724; not kept.)")
     if side_ok and world == 1 and args.workload == "c3" and not args.stagger and not args.envs and not args.total_envs:
@@ -479,7 +536,20 @@ def main():
 
         if vec.obs_log_rows:
             side_env("dense_layout", (cfg, ckw, skw), n_envs, 0, alg_b,
-                     "the same workload with the dense [N][5][12] observation batch written by every step (obs_log_rows=0)")
+                     "the same workload with the dense [N][5][12] observation batch written by every step (obs_layout='dense')")
+            # what delivering the dense batch to a torch consumer on EVERY step of a replayed graph costs, steady state: the
+            # cheaper of the two ways the package offers (FixedWingVecEnv warns when graph mode is enabled on a row-log env
+            # whose consumer takes the batch every step)
+            d, g = sides.get("dense_layout", {}), sides.get("obs_gather_row_log", {})
+            cands = [(d.get("steady_state_ms_per_step"), "dense layout (the step kernel writes the batch), steady state"),
+                     (g.get("ms_per_step"), "row log + fwg_obs_gather after every step, steady state")]
+            cands = [c_ for c_ in cands if c_[0]]
+            if cands:
+                ms, via = min(cands)
+                sides["obs_delivered"] = side_entry(ms, n_envs, via=via, row_log_gather_ms_per_step=g.get("ms_per_step"),
+                                                    dense_layout_ms_per_step=d.get("steady_state_ms_per_step"),
+                                                    note="the dense [N][5][12] observation batch in a torch consumer's hands after every "
+                                                         "step, episode ages uniform: the cheaper of the dense layout and row log + gather")
         c2 = workload("c2")
         side_env("c2", c2[:3], c2[3], None, ALG_BYTES["c2"], c2[4] + " (BASELINE configs[1]; 64 workgroups: launch-latency bound)", stag=False)
         import copy as _copy

@@ -245,9 +245,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // Which lanes are concerned it learns from the gym wave through LDS at the barrier (a load of the counters of its own would
     // have to be waited for at the kernel entry or be kept from the scheduler's hoisting: both measured slower).
     // (steps that fail or end an episode otherwise are completed by the gym wave as before)
-    const bool tail_rows = SPLIT && c.obs_log > 0 && c.obs_length > 1 && A.acc == nullptr;
-    const bool pre_install = SPLIT && c.auto_reset && c.obs_log > 0 && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 && A.acc == nullptr &&
-                             !c.has_int_obs;   // (integrator entries of a reset observation depend on how the old episode ends)
+    // (HS::enabled -- the fused rollout launch -- has an observer attached by construction)
+    const bool tail_rows = SPLIT && !HS::enabled && c.obs_log > 0 && c.obs_length > 1 && A.acc == nullptr;
+    // (dense batch: the same, the new window going into the env's record of the batch -- unless every step re-draws observation noise)
+    const bool pre_install = SPLIT && !HS::enabled && c.auto_reset && (c.obs_log > 0 || !c.obs_noise) && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 &&
+                             A.acc == nullptr && !c.has_int_obs;   // (integrator entries of a reset observation depend on how the old episode ends)
 
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
     // LDS copy once the streamed window has landed, i.e. after the integration)
@@ -295,7 +297,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (c.use_cmd_ring)
             for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
 #ifndef FWG_ABL_NO_LAG
-        if (c.obs_log == 0) stream_lag_rows(c, A, e, lds + M.lag);
+        // (k_step2: requested by the gym wave once its bookkeeping rows and action windows have landed, see below)
+        if (c.obs_log == 0) { if (!SPLIT) stream_lag_rows(c, A, e, lds + M.lag); }
         else log_wrap(c, A.obs, A.N, e, A.gnow, valid, A.log_wrap_now);
 #endif
     }
@@ -399,12 +402,16 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             int slot = A.slot_end - (c.int_window + 1); slot += (slot < 0) ? FWG_END_RING : 0;
             int_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
         }
-        // lanes in the first steps of an episode (row-log mode): their record 0 is requested now, the padding rows follow at
-        // the end of this block
-        const bool early_now = c.obs_log > 0 && c.obs_length > 1 && valid && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
+        // lanes in the first steps of an episode: their record 0 is requested now, the padding rows follow at the end of this
+        // block (row-log mode without an observer: the partner's tail work instead, tail_rows)
+        const bool early_now = c.obs_length > 1 && valid && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
         float rec0[FWG_MAX_OBS];
         if (!tail_rows && __ballot(early_now) != 0ull) {
-            if (early_now) early_rows_request(c, A, e, rec0);
+            if (early_now) {
+                int slot0 = 0;
+                if (c.obs_log == 0) { slot0 = A.slot_lag - (int)E.steps; slot0 += (slot0 < 0) ? c.L.lag_depth : 0; }
+                early_rows_request(c, A, e, rec0, slot0);
+            }
         }
         E.sft += 1u;
         if (c.steps_max > 0 && E.steps >= (unsigned)c.steps_max) { done = true; term = FWG_TERM_STEPS; }
@@ -504,9 +511,21 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (c.metrics) S_prev = fix3_unpack(sum_prev);
     };
     if (SPLIT && GYM) {
-        FWG_DMA_DRAIN();   // this wave's own streamed windows have landed (no other wave reads them)
+        FWG_DMA_DRAIN();   // this wave's own streamed action windows have landed (no other wave reads them)
+        FWG_TL(A, 1);
+        // dense batch: the lagged observation rows (12 KiB per wave, straight from HBM) are requested only NOW and land under the
+        // pre-barrier work below, which does not read them.  Requested with the other rows they delay everything: behind a
+        // global_load_lds the compiler turns every wait for a vector-memory result into vmcnt(0) ("pending flat" in its counter
+        // model), so the gym wave sat through all of them before its first instruction (~6.6k ticks into the kernel instead of
+        // ~3.6k) and reached barrier A 1.7k ticks AFTER its partner (tools/timeline.py).  Measured against this, same box:
+        // plain streaming loads parked in LDS +0.3 us per step, straight into the record's registers 238 -> 255 VGPRs and
+        // spills, requests from inline assembly (not counted by the compiler, explicit partial wait) +0.15 us.
+#ifndef FWG_ABL_NO_LAG
+        if (c.obs_log == 0) stream_lag_rows(c, A, e, lds + M.lag);
+#endif
         FWG_WAVE_SYNC();
         gym_prework();
+        if (c.obs_log == 0 && c.obs_length > 1) FWG_DMA_DRAIN();   // (landed by now; drains the rare stores of a draw piece too)
         // a foreseen end's operands, requested above, are pinned in registers here (see FWG_TOUCH: the episode-end branch then
         // runs without a wait); the terminal observation's lagged rows MUST have landed before the barrier -- the partner
         // writes the new window over their planes after it.  (Not a drain: that would sit through the acknowledgement of
@@ -589,7 +608,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // disjoint from the ones the partner re-initialises itself)
         if (pre_install && __ballot(end_p) != 0ull) {
             if (end_p) {   // (the partner checked the draw's tag)
-                reset_rows_to_log(c, A, e, RDp, aring, A.slot_lag, A.log_win);
+                reset_rows_to_log(c, A, e, RDp, aring, A.slot_lag, A.log_win, c.obs_log == 0);
 #pragma unroll
                 for (int i = 0; i < NY; ++i) E.y[i] = RDp.y[i];
 #pragma unroll
@@ -821,9 +840,9 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 
     // ---- phase D: observation (fixed_wing.py:776-846)
 #ifndef FWG_ABL_NO_LAG
-    if (c.obs_log == 0) load_lag_rows(c, lds + M.lag + lane * 4, ob);
+    if (c.obs_log == 0) load_lag_rows(c, lds + M.lag + lane * 4, ob, pre_early ? (int)E.steps : (1 << 30));
 #endif
-    build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid && c.obs_log == 0, A.slot_act, obs_action);
+    build_row0(c, A, e, E, T, ob, c.use_cmd_ring ? cring : aring, A.slot_lag, ok && valid && c.obs_log == 0 && !pre_rows, A.slot_act, obs_action);   // (pre_rows: the slot takes the NEW episode's record 0, from the partner)
     FWG_TL(A, 14);
     // row-log mode: the lagged rows stay where they are; only lanes that need the COMPLETE record in registers (episode
     // end: terminal observation) read them back, and only early-episode / failed lanes compute rows of their own
@@ -914,7 +933,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // ---- phase F: outputs and the state write-back
 #ifndef FWG_ABL_NO_OBSWRITE
     if (c.obs_log == 0) {
-        write_obs<ROLE>(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~0ull, A.acc != nullptr);
+        write_obs<ROLE>(c, A.obs, env0, A.N, ob, lds + M.stage, lane, ~__ballot(pre_rows), A.acc != nullptr);   // (pre_rows: the partner wrote the new window)
     } else {
         if (valid && !pre_rows) log_store_row(c, A.obs, A.N, e, log_win, 0, ob);   // the new record: 64 consecutive rows per wave
         if (__ballot((done || (early && !tail_rows)) && valid && !pre_rows) != 0ull) {

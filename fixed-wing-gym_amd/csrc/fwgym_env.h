@@ -302,11 +302,13 @@ __host__ __device__ inline LdsMap lds_map(int obs_dim, int n_obs, int window, in
 // unrolling, so the register-array flavour costs nothing; the generic kernel indexes lane-private LDS columns
 // ([entry][lane], conflict-free) with wave-uniform run-time indices.
 template <int ROWS> struct RegTable {
+    static constexpr bool in_regs = true;
     float v[ROWS];
     __device__ __forceinline__ float get(int i) const { return v[i]; }
     __device__ __forceinline__ void put(int i, float x) { v[i] = x; }
 };
 struct LdsTable {
+    static constexpr bool in_regs = false;
     float* p;
     __device__ __forceinline__ float get(int i) const { return p[i * FWG_WAVE]; }
     __device__ __forceinline__ void put(int i, float x) { p[i * FWG_WAVE] = x; }
@@ -785,12 +787,13 @@ __device__ __forceinline__ void stream_lag_rows(const DevCfg& c, const KArgs& A,
         for (int g = 0; g < ng; ++g)
             dma_group_once(&CGROUP(A.S, A.N, (c.L.lag_ring >> 2) + A.lag_slots[r] * ng + g, e), lds_lag + ((r - 1) * ng + g) * (4 * FWG_WAVE));
 }
+// (keep_from: rows whose lag reaches this many steps back are padding rows this lane has prepared already -- early_rows_pre)
 template <class OB>
-__device__ __forceinline__ void load_lag_rows(const DevCfg& c, const float* lag_lane, OB& ob) {
+__device__ __forceinline__ void load_lag_rows(const DevCfg& c, const float* lag_lane, OB& ob, int keep_from = 1 << 30) {
     const int ng = c.L.lag_groups;
 #pragma unroll
     for (int r = 1; r < FWG_MAX_ROWS; ++r) {
-        if (r < c.obs_length) {
+        if (r < c.obs_length && r * c.obs_step < keep_from) {
 #pragma unroll
             for (int g = 0; g < FWG_MAX_OBS / 4; ++g) {
                 if (g < ng) {
@@ -805,6 +808,18 @@ __device__ __forceinline__ void load_lag_rows(const DevCfg& c, const float* lag_
     }
 }
 
+// Values requested long before their use (a foreseen episode end's prefetches) are "touched" where they have surely landed:
+// the compiler places its s_waitcnt at the touch, where nothing younger is in flight, instead of at the first use -- there,
+// after divergent code that issued a number of stores it cannot count, it falls back to vmcnt(0) and the wave sits through
+// the acknowledgement of every store it has just issued (2-3k ticks on the episode-end path, tools/timeline.py).
+// Likewise a load inside a RARE branch whose result is used after the join: untouched, the wait lands at the use, on the
+// path of every wave, and counts the stores issued before the branch (fix_lagged_rows: the dense batch paid 2-4k ticks per
+// step for the lag-ring reads of lanes that almost never exist)
+#ifdef FWG_EMU
+#define FWG_TOUCH(x) ((void)(x))
+#else
+#define FWG_TOUCH(x) asm volatile("" ::"v"(x))
+#endif
 // entry j of the record of env e in ring slot `slot` (rare per-lane fix-up reads)
 __device__ __forceinline__ float lag_entry(const DevCfg& c, const KArgs& A, long e, int slot, int j) {
     return A.S[(((unsigned)(c.L.lag_ring >> 2) + (unsigned)(slot * c.L.lag_groups + (j >> 2))) * (unsigned)A.N + (unsigned)e) * 4u + (unsigned)(j & 3)];
@@ -880,11 +895,12 @@ __device__ __forceinline__ void early_rows_to_log(const DevCfg& c, const KArgs& 
         }
     }
 }
-__device__ __forceinline__ void early_rows_request(const DevCfg& c, const KArgs& A, long e, float (&rec)[FWG_MAX_OBS]) {
+// (slot: where the episode's record 0 sits -- row-log mode: slot 0 of the one-slot ring; dense batch: `steps` slots behind the current one)
+__device__ __forceinline__ void early_rows_request(const DevCfg& c, const KArgs& A, long e, float (&rec)[FWG_MAX_OBS], int slot = 0) {
 #pragma unroll
-    for (int g = 0; g < FWG_MAX_OBS / 4; ++g) {   // the episode's record 0: slot 0 of the one-slot ring
+    for (int g = 0; g < FWG_MAX_OBS / 4; ++g) {
         if (g < c.L.lag_groups) {
-            const float4 q = CGROUP(A.S, A.N, (c.L.lag_ring >> 2) + g, e);
+            const float4 q = CGROUP(A.S, A.N, (c.L.lag_ring >> 2) + slot * c.L.lag_groups + g, e);
             rec[4 * g] = q.x; rec[4 * g + 1] = q.y; rec[4 * g + 2] = q.z; rec[4 * g + 3] = q.w;
         }
     }
@@ -940,7 +956,9 @@ __device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A,
                     v = backscale_action(c, o.src, T.get(FWG_V_ELEVATOR + o.src)) + noise;
                     if (o.norm) v = (v - o.mean) * o.inv_var;
                 } else {
-                    v = lag_entry(c, A, e, slot0, j) + noise * (o.norm ? o.inv_var : 1.f);
+                    const float q = lag_entry(c, A, e, slot0, j);
+                    FWG_TOUCH(q);   // (waited for HERE, inside the rare branch)
+                    v = q + noise * (o.norm ? o.inv_var : 1.f);
                 }
                 ob.put(r * c.n_obs + j, v);
             }
@@ -950,9 +968,12 @@ __device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A,
                                                : nullptr;
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j)
-                if (j < c.n_obs && c.obs[j].type != FWG_OBS_ACTION)
+                if (j < c.n_obs && c.obs[j].type != FWG_OBS_ACTION) {
                     // (the episode's record 0 sits in the log with its reset-time noise; the clean copy is in the ring slot)
-                    ob.put(r * c.n_obs + j, c.obs_log > 0 ? (lag == t - 1 ? lag_entry(c, A, e, 0, j) : older[j]) : lag_entry(c, A, e, slot, j));
+                    const float q = c.obs_log > 0 ? (lag == t - 1 ? lag_entry(c, A, e, 0, j) : older[j]) : lag_entry(c, A, e, slot, j);
+                    FWG_TOUCH(q);
+                    ob.put(r * c.n_obs + j, q);
+                }
         }
     }
 }
@@ -1005,10 +1026,31 @@ __device__ __forceinline__ void write_obs(const DevCfg& c, float* __restrict__ o
         const float4* all = reinterpret_cast<const float4*>(stage);
         float4* o4 = reinterpret_cast<float4*>(out + env0 * D);
         const int total4 = FWG_WAVE * D / 4;
+#ifdef FWG_ABL_OBS_LOOP
+        if (false) {
+#else
+        if (OB::in_regs) {
+#endif
+            // specialised kernels (D a constant): ALL the reads, then all the stores -- as a loop of read, wait,
+            // store the fifteen 1 KiB rows of a 60-entry batch cost one LDS round trip EACH, ~4k ticks per wave and step
+            constexpr int NQ = (FWG_MAX_OBS * FWG_MAX_ROWS) / 4;
+            float4 buf[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q * 4 < D) buf[q] = all[lane + q * FWG_WAVE];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q * 4 < D) {
+                    const int i = lane + q * FWG_WAVE, l = (4 * i) / D;
+                    if (((lanes >> l) & 1ull) && env0 + l < N) { if (reread) o4[i] = buf[q]; else stream_store4(o4 + i, buf[q]); }
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int i = lane; i < total4; i += FWG_WAVE) {
-            const int l = (4 * i) / D;
-            if (((lanes >> l) & 1ull) && env0 + l < N) { if (reread) o4[i] = all[i]; else stream_store4(o4 + i, all[i]); }
+            for (int i = lane; i < total4; i += FWG_WAVE) {
+                const int l = (4 * i) / D;
+                if (((lanes >> l) & 1ull) && env0 + l < N) { if (reread) o4[i] = all[i]; else stream_store4(o4 + i, all[i]); }
+            }
         }
     } else {
         const int Ds = obs_stage_stride(D);
@@ -1308,15 +1350,6 @@ __device__ __forceinline__ void draw_load_final(const DevCfg& c, const float* __
         D.tprop[k][0] = t.x; D.tprop[k][1] = t.y; D.tprop[k][2] = t.z; D.tprop[k][3] = t.w;
     }
 }
-// Values requested long before their use (a foreseen episode end's prefetches) are "touched" where they have surely landed:
-// the compiler places its s_waitcnt at the touch, where nothing younger is in flight, instead of at the first use -- there,
-// after divergent code that issued a number of stores it cannot count, it falls back to vmcnt(0) and the wave sits through
-// the acknowledgement of every store it has just issued (2-3k ticks on the episode-end path, tools/timeline.py)
-#ifdef FWG_EMU
-#define FWG_TOUCH(x) ((void)(x))
-#else
-#define FWG_TOUCH(x) asm volatile("" ::"v"(x))
-#endif
 __device__ __forceinline__ void touch4(const float4& q) { FWG_TOUCH(q.x); FWG_TOUCH(q.y); FWG_TOUCH(q.z); FWG_TOUCH(q.w); }
 __device__ __forceinline__ void touch_draw(const DevCfg& c, const ResetDraw& D) {
 #pragma unroll
@@ -1401,8 +1434,9 @@ __device__ __forceinline__ unsigned draw_stage_step(const DevCfg& c, DynCfgK& dc
 // The new episode's observation window straight into the row log (row-log mode, k_step2): for an episode end that is known
 // before the integration (time limit) the gym wave does this while its partner integrates -- the window does not depend on
 // how the old episode ends.  Also pushes the episode's clean record 0 (build_row0).  Same arithmetic as reset_finish.
+// (dense: the same rows into the env's record of the dense [N][obs_dim] batch, which the gym wave's staged write then leaves out)
 __device__ __forceinline__ void reset_rows_to_log(const DevCfg& c, const KArgs& A, long e, const ResetDraw& D, const float* ring,
-                                                  int g_lag, long long win) {
+                                                  int g_lag, long long win, bool dense = false) {
     Env R;
     R.steps = 0u;
 #pragma unroll
@@ -1425,7 +1459,7 @@ __device__ __forceinline__ void reset_rows_to_log(const DevCfg& c, const KArgs& 
     for (int r = 0; r < FWG_MAX_ROWS; ++r) {
         if (r >= c.obs_length) continue;
         const float noise = D.row_noise[r];
-        float* dst = log_row(c, A.obs, A.N, e, win + r);
+        float* dst = dense ? A.obs + e * c.obs_dim + r * c.n_obs : log_row(c, A.obs, A.N, e, win + r);
         if ((c.n_obs & 3) == 0) {
 #pragma unroll
             for (int q = 0; q < FWG_MAX_OBS / 4; ++q) {

@@ -6,8 +6,10 @@ Its source is absent from /root/reference, so this file restates the *published*
 (Beard & McLain small-UAV 6-DOF quaternion equations, Gryte et al. 2018 Skywalker X8 aerodynamics with the
 flat-plate stall blend, MIL-F-8785C Dryden turbulence) behind the interface the reference's call sites need
 (SURVEY.md App. B.1).  PARITY UNPINNED versus real PyFly 0.1.2: the reference holds no tests or golden vectors at this
-boundary; the only shipped data touching it are closed-loop PID traces (tests report the distance, they do not gate).
-What IS pinned: the HIP kernels must reproduce THIS file (same fixed-step scheme) to 1e-5 relative in fp32.
+boundary.  What the reference does ship about it -- the converged-airspeed lines hard-coded in its Va target, the per-step
+rewards of its PID and MLP evaluations, the jitter statistics of its turbulence evaluations -- is gated two-sidedly by
+tests/test_simulator_pins.py (CPU, this file) and tests/test_evaluate.py (GPU): DESIGN.md section 2 A-D.
+What IS pinned exactly: the HIP kernels must reproduce THIS file (same fixed-step scheme) to 1e-5 relative in fp32.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 

@@ -173,9 +173,10 @@ def test_replay_check_rejects_a_graph_captured_at_the_other_parity(emu_lib):
     vec.close()
 
 
-def test_two_wave_kernel_through_foreseen_episode_ends_emulated():
-    """k_step2 (two waves per 64 envs) with the row log through time-limit episode ends: the next episode's prepared draw is
-    installed and its observation window written before the integration has finished (reset_rows_to_log), the finished
+@pytest.mark.parametrize("layout", ["row_log", "dense"])
+def test_two_wave_kernel_through_foreseen_episode_ends_emulated(layout):
+    """k_step2 (two waves per 64 envs) through time-limit episode ends, row log and dense batch: the next episode's prepared
+    draw is installed and its observation window written by the physics wave in its tail (reset_rows_to_log), the finished
     episode's accumulators are parked and collected by fwg_finish_episodes.  The configuration is not a preset, so the
     emulation library is specialised for it (tests/emu build_emu_spec, the host counterpart of gym_fixed_wing/jit.py)."""
     from emu.host_backend import build_emu_spec
@@ -186,11 +187,12 @@ def test_two_wave_kernel_through_foreseen_episode_ends_emulated():
     skw = {"turbulence": True, "turbulence_intensity": "moderate"}
     import copy
     ec = EnvConfig(copy.deepcopy(cfg), config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
-    lib = build_emu_spec(ec, auto_reset=True, store_derived=True, obs_log_rows=presets.OBS_LOG_ROWS)
+    rows = presets.OBS_LOG_ROWS if layout == "row_log" else 0
+    lib = build_emu_spec(ec, auto_reset=True, store_derived=True, obs_log_rows=rows)
     n, steps = 5, 150
     vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True,
-                          _backend=HostBackend(), _lib_path=lib)
-    assert vec.spec_index == 0 and vec.obs_log_rows == presets.OBS_LOG_ROWS
+                          _backend=HostBackend(), _lib_path=lib, obs_log_rows=rows)
+    assert vec.spec_index == 0 and vec.obs_log_rows == rows
     orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
     acts = _actions(7, steps, n)
     # (check_views: the derived host views -- field('roll') ... -- must show the NEW episode's state after a foreseen

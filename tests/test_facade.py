@@ -149,6 +149,35 @@ def test_goal_env_reproduces_the_reference_goal_env(backend, form):
     env.close()
 
 
+@pytest.mark.parametrize("form", ["absolute", "potential"])
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_goal_compute_reward_agrees_with_the_kernel_reward(backend, form):
+    """compute_reward is a second reward implementation (host, float64; it has to be: a hindsight buffer calls it with
+    substituted goals long after the step).  Its anchor to the kernel's reward: for the goals a transition really had, it
+    must return the reward the step returned -- every step of an episode, both reward forms.  One documented exception
+    restates the reference: compute_reward takes `steps_count = info["step"]` (fixed_wing.py:1218-1277), one less than the
+    env's counter inside step(), so at the SECOND transition its action-"delta" factor is still switched off
+    (`if steps_count > 1`, :692) while the step's was on; the recorded vectors (g4_goal_*.json) hold exactly that value."""
+    import json
+    from gym_fixed_wing.fixed_wing import FixedWingAircraftGoal
+    with open(os.path.join(os.path.dirname(__file__), "golden", "g4_goal_{}.json".format(form))) as f:
+        rec = json.load(f)
+    env = FixedWingAircraftGoal(rec["config"], **_kw(backend))
+    env.seed(7)
+    env.reset(state=rec["state"], target=rec["target"])
+    prev = [env.simulator.state[s].value for s in env.goal_states]
+    for t, st in enumerate(rec["steps"]):
+        a = np.array(st["action"])
+        o, r, d, _ = env.step(a)
+        got = env.compute_reward(o["achieved_goal"], o["desired_goal"], {"step": t, "action": a, "prev_state": list(prev)})
+        prev = [env.simulator.state[s].value for s in env.goal_states]
+        if t == 1:
+            assert abs(got - r) > 1e-3, "the reference's off-by-one of the delta factor at the second transition is gone"
+        else:
+            assert got == pytest.approx(r, abs=5e-5), (t, got, r)
+    env.close()
+
+
 @pytest.mark.parametrize("fail_prone", [False, True], ids=["time_limit", "failure"])
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_integrator_observations_across_explicit_resets(backend, fail_prone):

@@ -193,6 +193,16 @@ def test_default_layout_is_the_row_log_where_it_applies_emulated():
     noisy = configs.reference_like("cnn")
     noisy["observation"]["noise"] = {"mean": 0, "var": 0.1}
     assert FixedWingVecEnv(noisy, num_envs=3, as_numpy=True, _backend=HostBackend(), _lib_path=build_emu()).obs_log_rows == 0
+    # the same choice by name
+    assert mk("cnn", obs_layout="dense").obs_log_rows == 0
+    assert mk("cnn", obs_layout="row_log").obs_log_rows == presets.OBS_LOG_ROWS
+    assert mk("cnn", obs_layout="auto").obs_log_rows == presets.OBS_LOG_ROWS
+    with pytest.raises(ValueError):
+        mk("cnn", obs_layout="dense", obs_log_rows=8)
+    with pytest.raises(ValueError):
+        mk("examples", obs_layout="row_log")
+    with pytest.raises(ValueError):
+        mk("cnn", obs_layout="sparse")
 
 
 @pytest.mark.parametrize("kind,rows,ckw", [("cnn", 10, {"observation": {"step": 2}, "steps_max": 23}),

@@ -38,7 +38,9 @@ def run():
     from gym_fixed_wing import presets
     from gym_fixed_wing.vec_env import FixedWingVecEnv
     res = {}
-    for wl, log_rows in (("c3", presets.OBS_LOG_ROWS), ("c5", 0)):
+    # TL_WL="c3:dense" etc.: the workloads and observation layouts to run (a one-preset tools/devlib.py build holds one of them)
+    sel = [w.split(":") for w in os.environ.get("TL_WL", "c3:log,c5:dense").split(",")]
+    for wl, log_rows in [(w, presets.OBS_LOG_ROWS if lay == "log" else 0) for w, lay in sel]:
         cfg, ckw, skw, n, desc = presets.workload(wl)
         n = 65536
         vec = FixedWingVecEnv(cfg, num_envs=n, device=0, config_kw=ckw, sim_config_kw=skw, seed=1, derived_views=False,
