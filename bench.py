@@ -179,7 +179,7 @@ def cpu_baseline(wl, seconds, max_procs=0):
     try:   # second CPU number: the product kernel source compiled for the host (tests/emu, lock-step lane
         # emulation, OpenMP over workgroups) through oracle/cpu_native.py, when built
         from oracle import cpu_native
-        nat = cpu_native.measure(wl, min(seconds, 8.0))
+        nat = cpu_native.measure(wl, min(seconds, 8.0), cores=cores)
         if nat is not None:
             out["native"] = nat
     except Exception as e:   # the baseline is optional reporting: never fail the bench line over it

@@ -519,7 +519,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // model), so the gym wave sat through all of them before its first instruction (~6.6k ticks into the kernel instead of
         // ~3.6k) and reached barrier A 1.7k ticks AFTER its partner (tools/timeline.py).  Measured against this, same box:
         // plain streaming loads parked in LDS +0.3 us per step, straight into the record's registers 238 -> 255 VGPRs and
-        // spills, requests from inline assembly (not counted by the compiler, explicit partial wait) +0.15 us.
+        // spills, requests from inline assembly (not counted by the compiler, explicit partial wait) +0.15 us, windows AND rows
+        // by plain loads parked by the wave itself (exact waits, no global_load_lds at all): 256 VGPRs + 8 spills, +0.5 us.
 #ifndef FWG_ABL_NO_LAG
         if (c.obs_log == 0) stream_lag_rows(c, A, e, lds + M.lag);
 #endif

@@ -38,13 +38,24 @@ def _measure(args):
     return n * n_envs / dt, n
 
 
-def measure(wl, seconds=8.0, n_envs=0):
+def measure(wl, seconds=8.0, n_envs=0, cores=0):
+    """cores: OpenMP threads to use -- the CPUs the process really gets (bench._usable_cpus: affinity mask, container quota),
+    not os.cpu_count(), which reports the machine (256 threads on a pod limited to 16 CPUs measure time-slicing)."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    present = os.cpu_count() or 1
+    cores = present if cores <= 0 else min(int(cores), present)
     if n_envs <= 0:   # one 64-env workgroup is the unit of OpenMP work: at least one per core, a few per core on small hosts
         n_envs = 64 * max(cores, 64)
-    with mp.get_context("spawn").Pool(1) as pool:   # a fresh process: OpenMP runtime and emulation state stay out of the bench
-        rate, steps = pool.map(_measure, [(wl, seconds, n_envs)])[0]
-    return {"value": rate, "unit": "env-steps/s", "cores": cores, "cores_present": cores, "kind": "port",
+    saved = os.environ.get("OMP_NUM_THREADS")
+    os.environ["OMP_NUM_THREADS"] = str(cores)   # (inherited by the spawned process, read by its OpenMP runtime at start-up)
+    try:
+        with mp.get_context("spawn").Pool(1) as pool:   # a fresh process: OpenMP runtime and emulation state stay out of the bench
+            rate, steps = pool.map(_measure, [(wl, seconds, n_envs)])[0]
+    finally:
+        if saved is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = saved
+    return {"value": rate, "unit": "env-steps/s", "cores": cores, "cores_present": present, "kind": "port",
             "sample": "product kernel source compiled for the host (g++ -O2, lock-step lane emulation, OpenMP over workgroups), "
                       "{} envs x {} steps in {:.0f} s".format(n_envs, steps, seconds)}
