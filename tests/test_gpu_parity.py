@@ -80,6 +80,23 @@ def test_two_wave_kernel_matches_oracle_through_episode_ends(case):
     vec.close()
 
 
+def test_two_wave_kernel_dense_batch_through_episode_ends():
+    """... and with the dense [N][5][12] batch (obs_layout="dense"): the early-episode padding rows are prepared before the
+    barrier from the lag ring, a foreseen end's next episode is written into the env's record of the batch by the physics
+    wave (the gym wave's staged write leaves that env out), the lagged rows are requested late (round 4)."""
+    name, kind, ckw, skw = [c for c in configs.CASES if c[0] == "cnn_step2_turb"][0]
+    cfg = configs.reference_like(kind)
+    n, steps = 70, 130
+    vec = _vec(cfg, n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True, specialize=True, obs_layout="dense")
+    assert vec.spec_index >= 0 and vec.obs_log_rows == 0
+    orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
+    acts = _actions(5, steps, n, scale=1.3)
+    res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3)
+    assert res["episodes"] >= n
+    print(name, "dense", res)
+    vec.close()
+
+
 @pytest.mark.parametrize("case", [c for c in configs.CASES if c[1] == "cnn"], ids=[c[0] + "_dense" for c in configs.CASES if c[1] == "cnn"])
 def test_gym_rollout_matches_oracle_dense_batch(case):
     """Lagged matrix observations default to the row log (zero-copy window); the dense [N][5][12] batch written by the
