@@ -325,15 +325,32 @@ def _rollouts(vec_factory, fused, n_steps, reps, graph=False, seed=5):
     return out, st, state, obs
 
 
-def _assert_same_rollouts(a, b):
+def _assert_same_rollouts(a, b, what=""):
+    """Bit-for-bit; on a mismatch the message says WHERE (every differing buffer with the number and the first positions of
+    the differing elements) -- a one-in-many-runs difference has to be diagnosable from the one log it leaves."""
     (ra, sa, xa, oa), (rb, sb, xb, ob) = a, b
+    bad = []
+
+    def cmp(name, u, v):
+        u, v = np.asarray(u), np.asarray(v)
+        if u.shape != v.shape:
+            bad.append("{}: shapes {} / {}".format(name, u.shape, v.shape))
+            return
+        ne = ~((u == v) | (np.isnan(u.astype(np.float64)) & np.isnan(v.astype(np.float64))))
+        if ne.any():
+            idx = np.argwhere(ne)
+            first = [tuple(int(x) for x in i) for i in idx[:6]]
+            bad.append("{}: {} of {} differ, first at {}: {} / {}".format(
+                name, int(ne.sum()), ne.size, first, [u[i].item() for i in first[:3]], [v[i].item() for i in first[:3]]))
+
     for rep, (u, v) in enumerate(zip(ra, rb)):
         for k in u:
-            np.testing.assert_array_equal(u[k], v[k], err_msg="rollout {} {}".format(rep, k))
+            cmp("rollout {} {}".format(rep, k), u[k], v[k])
     for k in sa:
-        np.testing.assert_array_equal(np.asarray(sa[k]), np.asarray(sb[k]), err_msg="statistics " + k)
-    np.testing.assert_array_equal(oa, ob)
-    np.testing.assert_array_equal(xa, xb)   # the whole state arena
+        cmp("statistics " + k, sa[k], sb[k])
+    cmp("observation", oa, ob)
+    cmp("state arena", xa, xb)
+    assert not bad, "{} one-launch vs two-launch rollouts differ:\n  ".format(what) + "\n  ".join(bad)
 
 
 def test_fused_launch_equals_two_launches_emulated():
@@ -383,7 +400,20 @@ def test_fused_launch_equals_two_launches_on_gpu():
             return FixedWingVecEnv(cfg, num_envs=n, device=0, derived_views=False, seed=2)
         two = _rollouts(mk, False, steps, reps, graph=graph)
         one = _rollouts(mk, True, steps, reps, graph=graph)
-        _assert_same_rollouts(one, two)
+        what = "n={} steps={} reps={} graph={}:".format(n, steps, reps, graph)
+        try:
+            _assert_same_rollouts(one, two, what)
+        except AssertionError as first:
+            # (seen twice in ~20 runs of the whole GPU suite, never in 1 500 iterations of tests/soak_rollout.py nor in isolation:
+            # say which of the two paths fails to reproduce ITSELF, then fail with everything known)
+            notes = []
+            for name, fused, ref in (("two-launch", False, two), ("one-launch", True, one)):
+                try:
+                    _assert_same_rollouts(_rollouts(mk, fused, steps, reps, graph=graph), ref, name + " path run twice:")
+                    notes.append(name + " path reproduces itself")
+                except AssertionError as again:
+                    notes.append(str(again))
+            raise AssertionError(str(first) + "\n" + "\n".join(notes))
 
 
 @pytest.mark.gpu
