@@ -282,6 +282,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         }
     }
     float ret_prev = 0.f;
+    float4 int_old = make_float4(0.f, 0.f, 0.f, 0.f);   // integration_window: cumulative error sums W + 1 records back
+    float4 sum_prev = make_float4(0.f, 0.f, 0.f, 0.f);  // the cumulative error sums through the previous record (packed Fix3)
     float4 act_q3 = make_float4(0.f, 0.f, 0.f, 0.f), act_q4 = act_q3;
     if (SPLIT && GYM && ext_act) {   // y[12..15] | y[16], y[17], ...: the actuator part of the simulator rows
         act_q3 = load_group(A.S, A.N, (L.sim >> 2) + 3, e);
@@ -292,6 +294,19 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
         // order = order of need (returns are in order): bookkeeping rows, action windows, lagged observation rows
         load_gym(c, A.S, A.N, e, E, A.bit_goal);
+        // the cumulative error sums this step builds on (fixed point, fwgym_env.h Fix3): their ring slots are positions of the
+        // GLOBAL step counter, so they are requested here, with the bookkeeping rows -- requested inside the pre-barrier work
+        // (rounds 4a) their round trip was waited for at the end of it: every gym wave reached barrier A ~2k ticks later, which
+        // is nothing for a plain wave (its partner integrates for longer) and the whole margin of a wave that also computes a
+        // piece of the next draw, pads early rows or prefetches an episode end
+        if (c.metrics) {   // S_(t-1): through the previous record
+            int slot = A.slot_end - 1; slot += (slot < 0) ? FWG_END_RING : 0;
+            sum_prev = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+        }
+        if (c.int_window) {   // S_(t-1-W): the record W + 1 positions before this step's
+            int slot = A.slot_end - (c.int_window + 1); slot += (slot < 0) ? FWG_END_RING : 0;
+            int_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+        }
         if (A.acc != nullptr && valid) ret_prev = A.acc_ret[e];   // attached rollout head: the env's discounted return so far
         for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.act_ring >> 2) + s, e), lds + M.aring + s * (4 * FWG_WAVE));
         if (c.use_cmd_ring)
@@ -359,8 +374,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // round trips run while the physics wave integrates
     bool pre_end = false, pre_draw = false, pre_rows = false;
     float4 pre_tag = make_float4(0.f, 0.f, 0.f, 0.f), pre_old = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 int_old = make_float4(0.f, 0.f, 0.f, 0.f);   // integration_window: cumulative error sums W + 1 records back
-    float4 sum_prev = make_float4(0.f, 0.f, 0.f, 0.f);  // the cumulative error sums through the previous record (packed Fix3)
     Fix3 S_prev = {{0ll, 0ll, 0ll}};                    // ... unpacked at the end of the pre-barrier work (exact: fixed point)
     ResetDraw RD;
     // lanes in the first steps of an episode: the padding rows of their observation, up to the "action" entries
@@ -394,14 +407,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
         }
         E.steps += 1u;
-        if (c.metrics) {   // S_(t-1): the cumulative error sums (fixed point, fwgym_env.h Fix3) through the previous record
-            int slot = A.slot_end - 1; slot += (slot < 0) ? FWG_END_RING : 0;
-            sum_prev = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
-        }
-        if (c.int_window) {   // S_(t-1-W): the record W + 1 positions before this step's in the cumulative error ring
-            int slot = A.slot_end - (c.int_window + 1); slot += (slot < 0) ? FWG_END_RING : 0;
-            int_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
-        }
         // lanes in the first steps of an episode: their record 0 is requested now, the padding rows follow at the end of this
         // block (row-log mode without an observer: the partner's tail work instead, tail_rows)
         const bool early_now = c.obs_length > 1 && valid && (int)E.steps <= (c.obs_length - 1) * c.obs_step;
