@@ -188,6 +188,22 @@ def cpu_baseline(wl, seconds, max_procs=0):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def _busy(dev, seconds=0.03):
+    """~30 ms of unrelated device work (an elementwise pass over 64 MB, repeated) before a measurement.  The phases before one
+    -- env construction, thousands of host-paced resets and single steps in stagger_ages -- leave the device mostly idle, and a
+    box whose power management has clocked it down runs the first milliseconds of the timed region at half speed (one box in
+    five: 23-30 us per step instead of 12.5 for the same launches).  Deliberately NOT more env steps: a fresh VecEnv's episodes
+    run in lock-step, and a ramp of a few thousand steps would put the timed region onto the step where all of them end."""
+    import torch
+    x = torch.ones(1 << 24, device=dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            x.mul_(1.0000001).add_(1e-9)
+        torch.cuda.synchronize(dev)
+    del x
+
+
 def plan_chunks(k):
     """K timed steps -> (chunk length, replays, single eager steps).  Captured chunks hold an even number of steps."""
     even = k - (k % 2)
@@ -411,16 +427,9 @@ def main():
 
         def time_replays(self, c, reps, want_obs=False):
             """ms per step of reps replays of a c-step chunk (captured beforehand), wall clock around a drained device."""
-            # untimed replays first, for at least ~30 ms: the phases before a side measurement (thousands of host-paced resets
-            # and single steps in stagger_ages, env construction) leave the device mostly idle, and a box whose power
-            # management has clocked it down then runs the first milliseconds of the timed region at half speed (seen on one
-            # box in five: 23-30 us per step instead of 12.5 for the same launches)
-            t_ramp = time.perf_counter()
+            _busy(dev)   # (clocks up: see _busy)
             self.run(c, 1, 0, 0, want_obs)
             torch.cuda.synchronize(dev)
-            while time.perf_counter() - t_ramp < 0.03:
-                self.run(c, 2, 0, 0, want_obs)   # (an even number of chunks: the parity of the step count is kept)
-                torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             self.run(c, reps, 0, 0, want_obs)
             torch.cuda.synchronize(dev)
@@ -459,12 +468,10 @@ def main():
     extra = 0
     if graphs:
         pc = chunk if chunk else 2
-        t_ramp = time.perf_counter()   # (... and for at least ~30 ms of device work: see Runner.time_replays)
-        while extra < STEADY_STATE_STEPS or time.perf_counter() - t_ramp < 0.03:
+        _busy(dev)   # (clocks up before anything is timed or warmed up: see _busy)
+        while extra < STEADY_STATE_STEPS:
             R.run(pc, 1, 0, rollout=get_rollout)
             extra += pc
-            if extra >= STEADY_STATE_STEPS:
-                torch.cuda.synchronize(dev)   # (the clock above is the host's: keep it honest about the device)
     R.run(wchunk, wreplays, wsingles, rollout=get_rollout)
     if graphs and (args.warmup % 2) and not fused:   # (one more single: the odd warm-up's last step flipped the parity)
         R.run(0, 0, 1)
