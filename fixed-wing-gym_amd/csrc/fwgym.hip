@@ -189,7 +189,13 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     typedef KernelTypes<SPEC> KT;
     constexpr bool PHYS = ROLE != 2, GYM = ROLE != 1, SPLIT = ROLE != 0;
     const DevCfg& c = SpecCfg<SPEC>::get(cp);
-    const KArgs A = resolve_slots(c, A0);
+    KArgs A_ = resolve_slots(c, A0);
+    // An attached rollout head's running means / return mean / act counter are read through the CONSTANT address space (scalar
+    // loads, §5) although the launch before this one wrote them.  That is sound only if the scalar data cache is clean at kernel
+    // entry; the runtime's acquire at a dispatch does that -- as far as it is documented.  One s_dcache_inv per wave makes it
+    // explicit (the pointers pass through the asm statement, so the compiler cannot hoist their loads above it).
+    if (!HS::enabled && SPLIT && GYM && A_.acc != nullptr) fwg_fresh_scalar_view(A_.acc_mean, A_.acc_ret_mean, A_.acc_ctr);
+    const KArgs& A = A_;
     if (PHYS && A0.slots_out != nullptr && sub == 0 && (threadIdx.x & (FWG_WAVE - 1)) == 0)
         *A0.slots_out = next_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, *A0.slots_in);
 #ifdef FWG_ABL_EMPTY  // FWG_ABL_*: measurement-only switches (tools/ablate.py), never defined in the product build

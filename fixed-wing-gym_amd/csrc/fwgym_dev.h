@@ -59,6 +59,15 @@ typedef const __attribute__((address_space(4))) DynCfg DynCfgK;
 #define FWG_KCONST(T) const __attribute__((address_space(4))) T   /* launch-constant data behind a plain kernel argument */
 #endif
 
+// invalidates the wave's scalar data cache and hands the pointers back through the asm statement (loads through them cannot be
+// issued before it): for launch-constant data that the PREVIOUS launch wrote
+template <class P0, class P1, class P2>
+__device__ __forceinline__ void fwg_fresh_scalar_view(P0*& p0, P1*& p1, P2*& p2) {
+#if !defined(FWG_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(p0), "+s"(p1), "+s"(p2)::"memory");
+#endif
+}
+
 // The constants of the force / moment model, pre-combined from the parameter table (same names and order as the block at
 // the head of DevCfg).  One set for all envs (DevCfg) unless simulator.model re-samples the table per env and episode: then
 // every lane carries its own (arena section L.aero), derived on the device by the same formulas (derive_aero).
