@@ -194,7 +194,14 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // loads, §5) although the launch before this one wrote them.  That is sound only if the scalar data cache is clean at kernel
     // entry; the runtime's acquire at a dispatch does that -- as far as it is documented.  One s_dcache_inv per wave makes it
     // explicit (the pointers pass through the asm statement, so the compiler cannot hoist their loads above it).
-    if (!HS::enabled && SPLIT && GYM && A_.acc != nullptr) fwg_fresh_scalar_view(A_.acc_mean, A_.acc_ret_mean, A_.acc_ctr);
+    if constexpr (!HS::enabled && SPLIT && GYM) {   // (the three live in one ActorStats record: one pointer through the asm)
+        if (A_.acc != nullptr) {
+            const char* st = reinterpret_cast<const char*>(fwg_fresh_scalar_view(A_.acc_mean)) - offsetof(ActorStats, mean);
+            A_.acc_mean = reinterpret_cast<const float*>(st + offsetof(ActorStats, mean));
+            A_.acc_ret_mean = reinterpret_cast<const float*>(st + offsetof(ActorStats, ret_mean));
+            A_.acc_ctr = reinterpret_cast<const unsigned*>(st + offsetof(ActorStats, act_counter));
+        }
+    }
     const KArgs& A = A_;
     if (PHYS && A0.slots_out != nullptr && sub == 0 && (threadIdx.x & (FWG_WAVE - 1)) == 0)
         *A0.slots_out = next_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, *A0.slots_in);

@@ -59,12 +59,20 @@ typedef const __attribute__((address_space(4))) DynCfg DynCfgK;
 #define FWG_KCONST(T) const __attribute__((address_space(4))) T   /* launch-constant data behind a plain kernel argument */
 #endif
 
-// invalidates the wave's scalar data cache and hands the pointers back through the asm statement (loads through them cannot be
-// issued before it): for launch-constant data that the PREVIOUS launch wrote
-template <class P0, class P1, class P2>
-__device__ __forceinline__ void fwg_fresh_scalar_view(P0*& p0, P1*& p1, P2*& p2) {
+// invalidates the wave's scalar data cache and hands the pointer back through the asm statement (loads through it cannot be
+// issued before it): for launch-constant data that the PREVIOUS launch wrote.  (The two halves pass through vector registers
+// -- wherever the compiler keeps the pointer -- and come back as scalars: the loads through it stay scalar loads.)
+template <class P>
+__device__ __forceinline__ P* fwg_fresh_scalar_view(P* p) {
 #if !defined(FWG_EMU) && defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(p0), "+s"(p1), "+s"(p2)::"memory");
+    const unsigned long long x = (unsigned long long)(size_t)p;
+    unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)::"memory");
+    lo = (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+    hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hi);
+    return (P*)(size_t)(((unsigned long long)hi << 32) | lo);
+#else
+    return p;
 #endif
 }
 
