@@ -53,3 +53,30 @@ def test_chunk_plan():
     assert bench.plan_chunks(1) == (0, 0, 1)
     c, r, s = bench.plan_chunks(1022)
     assert c * r + s == 1022 and c % 2 == 0 and c <= bench.MAX_CHUNK
+
+
+def test_cpu_baseline_is_sized_by_the_container_quota(monkeypatch):
+    """The GPU box lists 256 hardware threads and gives the process 16 CPUs (cgroup v2 cpu.max "1600000 100000"): one oracle
+    process per LISTED core measured time-slicing for three rounds (bench._usable_cpus)."""
+    import builtins
+    import io
+    sys.path.insert(0, ROOT)
+    import bench
+    real_open = builtins.open
+
+    def fake_open(path, *a, **kw):
+        if path == "/sys/fs/cgroup/cpu.max":
+            return io.StringIO(fake["cpu.max"])
+        return real_open(path, *a, **kw)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    fake = {"cpu.max": "1600000 100000\n"}
+    assert bench._usable_cpus(256) == (16, 16.0)
+    fake["cpu.max"] = "max 100000\n"
+    assert bench._usable_cpus(256) == (256, None)
+    fake["cpu.max"] = "50000 100000\n"          # half a CPU: still one worker
+    assert bench._usable_cpus(256)[0] == 1
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)), raising=False)
+    fake["cpu.max"] = "1600000 100000\n"
+    assert bench._usable_cpus(256)[0] == 8        # the affinity mask is the tighter bound
