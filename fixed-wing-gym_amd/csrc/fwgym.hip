@@ -44,11 +44,13 @@ FWG_SPEC_LIST(FWG_DEFINE_SPEC)
 template <int SPEC> struct SpecCfg {
     static constexpr int obs_dim = 16;   // (generic kernels never instantiate the fused rollout launch)
     static constexpr bool rollout_ok = false;
+    static constexpr bool one_rk4_step = false;   // (the wave team of k_step2 exists for specialised configurations only)
     static __device__ __forceinline__ const DevCfg& get(const DevCfg* cp) { return *cp; }
 };
 #define FWG_SPEC_GETTER(i)                                                                                \
     template <> struct SpecCfg<i> {                                                                       \
         static constexpr int obs_dim = kSpec##i.obs_dim;                                                  \
+        static constexpr bool one_rk4_step = kSpec##i.nsub == 1;                                          \
         /* the fused head + step launch (k_rollout): dense observation batch within the head's 64 entries */ \
         static constexpr bool rollout_ok = kSpec##i.obs_log == 0 && kSpec##i.obs_dim <= 64;               \
         static __device__ __forceinline__ const DevCfg& get(const DevCfg*) { return kSpec##i; }           \
@@ -168,15 +170,44 @@ __device__ __forceinline__ void step_moments(const DevCfg& c, const KArgs& A, co
 // Synchronisation: workgroup barrier A = state and noise handed over; then a ONE-WAY mark in LDS that only the physics wave
 // raises (1 = its hand-off areas are read, 2 = its rows are in memory) and the gym wave waits for only where it re-uses the
 // former (output staging) or overwrites the latter (an env it re-initialises itself) -- see FWG_FLAG_RAISE / FWG_FLAG_WAIT.
-// k_step2, physics wave: the partner's actuator states, after workgroup barrier A0
+// k_step2, physics wave: the actuator states at t + h/2 and t + h, advanced by the gym wave while this wave evaluates the first
+// stage (a tagged message, see fwg_msg_take: this wave waits only if its partner is late)
 struct PartnerActuators {
     static constexpr bool enabled = true;
     const float* p;
-    __device__ __forceinline__ void fetch(float (&a_half)[5], float (&a_full)[5]) const {
-        __syncthreads();   // barrier A0
-        const float4 q0 = reinterpret_cast<const float4*>(p)[0], q1 = reinterpret_cast<const float4*>(p)[1], q2 = reinterpret_cast<const float4*>(p)[2];
-        a_half[0] = q0.x; a_half[1] = q0.y; a_half[2] = q0.z; a_half[3] = q0.w; a_half[4] = q1.x;
-        a_full[0] = q1.y; a_full[1] = q1.z; a_full[2] = q1.w; a_full[3] = q2.x; a_full[4] = q2.y;
+    // (the stages see the deflections only: the rates at t + h/2 stay with the partner)
+    __device__ __forceinline__ void fetch_half(float (&a_half)[5]) const {
+        const float4 q = fwg_msg_take(p, FWG_TAG_ACTS);
+        a_half[0] = q.x; a_half[1] = q.y; a_half[2] = q.z;
+    }
+    __device__ __forceinline__ void fetch_full(float (&a_full)[5]) const {
+        const float4 q2 = fwg_msg_take(p + 8, FWG_TAG_ACTS);
+        const float4 q1 = reinterpret_cast<const float4*>(p)[1];
+        a_full[0] = q1.x; a_full[1] = q1.y; a_full[2] = q1.z; a_full[3] = q1.w; a_full[4] = q2.x;
+    }
+};
+// measurement builds: a time stamp after every stage of the integration (tools/timeline.py)
+struct StageStamps {
+    const KArgs& A;
+    __device__ __forceinline__ void operator()(int st) const { FWG_TL(A, 26 + st); }
+};
+// k_step2, physics wave: the new state leaves for the gym wave as soon as it exists (sim_step `hand`)
+struct HandToGym {
+    static constexpr bool enabled = true;
+    float* h;   // this lane's hand-off area (FWG_HAND_WORDS)
+    const KArgs* A;
+    __device__ __forceinline__ void state(const float (&yy)[NY], const float (&ea)[5]) const {
+        float4* h4 = reinterpret_cast<float4*>(h);
+        h4[0] = make_float4(yy[4], yy[5], yy[6], yy[7]);
+        h4[1] = make_float4(yy[8], yy[9], yy[10], yy[11]);
+        h4[2] = make_float4(yy[12], yy[13], yy[14], yy[15]);
+        h4[3] = make_float4(ea[0], ea[1], ea[2], ea[3]);
+        fwg_msg_put(h + 16, ea[4], 0.f, 0.f, FWG_TAG_STATE);
+        FWG_TL(*A, 30);
+    }
+    __device__ __forceinline__ void result(float Va, float alpha, float beta, int fail) const {
+        fwg_msg_put(h + 20, Va, alpha, beta, FWG_TAG_RESULT | (unsigned)fail);
+        FWG_TL(*A, 31);
     }
 };
 
@@ -204,7 +235,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     }
     const KArgs& A = A_;
     if (PHYS && A0.slots_out != nullptr && sub == 0 && (threadIdx.x & (FWG_WAVE - 1)) == 0)
-        *A0.slots_out = next_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, *A0.slots_in);
+        *A0.slots_out = next_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, load_slots(A0.slots_in));
 #ifdef FWG_ABL_EMPTY  // FWG_ABL_*: measurement-only switches (tools/ablate.py), never defined in the product build
     return;
 #endif
@@ -222,18 +253,15 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     float* aring = lds + M.aring + lane * 4;   // this lane's entries of the raw-action window [slot][lane][4]
     float* cring = lds + M.cring + lane * 4;   // ... of the constrained-command window (only when observations need it)
     // split kernel hand-off areas, aliasing the output staging area (see lds_map)
-    float* hand = lds + M.stage + lane * FWG_HAND_WORDS;                       // physics -> gym
-    float* noise = lds + M.stage + FWG_WAVE * FWG_HAND_WORDS + lane * 4;       // gym -> physics
-    float* acts = lds + M.stage + FWG_WAVE * (FWG_HAND_WORDS + 4) + lane * FWG_ACT_WORDS;   // gym -> physics
-    float* mark = lds + M.flag;   // the one-way hand-shake mark: cleared by the physics wave before barrier A, raised by it after
-    // FWG_EXT_ACTUATORS (experiment, off): the gym wave advances the actuators for the physics wave, which picks them up
-    // after its first stage.  Measured SLOWER by 1.0-1.2 us per step at 65 536 envs (the extra barrier inside the stage
-    // loop and the two VALU-heavy streams contending on every SIMD cost more than the 16 micro-steps save).
-#ifdef FWG_EXT_ACTUATORS
-    const bool ext_act = SPLIT && c.nsub == 1;
-#else
-    const bool ext_act = false;
-#endif
+    float* hand = lds + M.stage + lane * FWG_HAND_WORDS;                       // physics -> gym (tagged messages, fwgym_dev.h)
+    float* tailm = lds + M.stage + FWG_WAVE * FWG_HAND_WORDS + lane * FWG_TAIL_WORDS;   // gym -> physics
+    float* acts = lds + M.stage + FWG_WAVE * (FWG_HAND_WORDS + FWG_TAIL_WORDS) + lane * FWG_ACT_WORDS;   // gym -> physics
+    float* mark = lds + M.flag;   // the one-way hand-shake mark: cleared by the physics wave before the entry barrier, raised by it later
+    // The gym wave advances the actuators for the physics wave (they depend on the commands and the actuator states only), in
+    // the time it would otherwise wait for its bookkeeping rows; the physics wave picks them up after its first stage.  (Round 2
+    // measured this SLOWER by 1.0-1.2 us with a __syncthreads() inside the stage loop as the hand-over: both waves waited, and
+    // for every store in flight; as a tagged message the physics wave waits for nothing unless its partner is late.)
+    constexpr bool ext_act = SPLIT && SpecCfg<SPEC>::one_rk4_step;
 
     // ---- phase A: issue every load up front.  The action windows stream HBM -> LDS (global_load_lds, no VGPRs, they
     // are addressed by the run-time ring slot); everything else goes to registers.
@@ -241,6 +269,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #pragma unroll
     for (int i = 0; i < 3; ++i) raw[i] = HS::enabled ? act_lds[lane * 4 + i] : A.actions[e * 3 + i];   // [N][3]: a wave reads 768 contiguous bytes
     Env E;
+    float4 act_q3 = make_float4(0.f, 0.f, 0.f, 0.f), act_q4 = act_q3;
+    if (SPLIT && GYM && ext_act) {   // y[12..15] | y[16], y[17], ...: the actuator part of the simulator rows (needed first)
+        act_q3 = load_group(A.S, A.N, (L.sim >> 2) + 3, e);
+        act_q4 = load_group(A.S, A.N, (L.sim >> 2) + 4, e);
+    }
     if (PHYS) load_sim<TURB>(c, A.S, A.N, e, E);
     load_cold(c, A.S, A.N, e, E);
     // per-lane force / moment constants (simulator.model; the generic kernel keeps ONE code path): requested with the
@@ -264,6 +297,88 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     const bool pre_install = SPLIT && !HS::enabled && c.auto_reset && (c.obs_log > 0 || !c.obs_noise) && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 &&
                              A.acc == nullptr && !c.has_int_obs;   // (integrator entries of a reset observation depend on how the old episode ends)
 
+    // k_step2 entry: every wave clears the tags of the messages it is going to WRITE (what a previous workgroup left in this
+    // LDS must not be mistaken for one), then ONE workgroup barrier -- at the point where both waves wait for their first rows
+    // anyway; from here on the two waves meet through tagged messages only
+    if (SPLIT) {
+        if (PHYS) {
+            fwg_msg_put(hand + 16, 0.f, 0.f, 0.f, 0u);
+            fwg_msg_put(hand + 20, 0.f, 0.f, 0.f, 0u);
+            fwg_msg_put(hand + 24, 0.f, 0.f, 0.f, 0u);
+            if (lane == 0) FWG_FLAG_RAISE(mark, 0);
+        } else {
+            fwg_msg_put(acts, 0.f, 0.f, 0.f, 0u);
+            fwg_msg_put(acts + 8, 0.f, 0.f, 0.f, 0u);
+            fwg_msg_put(tailm, 0.f, 0.f, 0.f, 0u);
+        }
+#ifndef FWG_ABL_NO_ENTRY_BARRIER   /* (measurement only: what the entry barrier costs; without it stale tags are possible) */
+        FWG_BLOCK_SYNC_LDS();
+#endif
+    }
+    float ret_prev = 0.f;
+    // The raw-action window (and the constrained-command window where observations use it) BY AGE: wa[k] = the action taken k
+    // steps ago, wa[0] = this step's.  k_step2: plain loads from the arena's ring at the (wave-uniform) slots behind the current
+    // one, straight into registers -- no LDS copy, no run-time slot arithmetic in the consumers, exact waits (behind a
+    // global_load_lds the compiler turns every wait for a vector-memory result into vmcnt(0)).  One-wave kernel: read out of the
+    // LDS copy streamed in at kernel start, once.
+    // (plain float arrays: an array of float4 filled through a reinterpret_cast load ends up in scratch memory)
+    float wa[FWG_MAX_WINDOW][3], wc[FWG_MAX_WINDOW][3];
+    float4 int_old = make_float4(0.f, 0.f, 0.f, 0.f);   // integration_window: cumulative error sums W + 1 records back
+    float4 sum_prev = make_float4(0.f, 0.f, 0.f, 0.f);  // the cumulative error sums through the previous record (packed Fix3)
+    // rows that only the work AFTER the hand-over reads (k_step2: requested when the pre-hand-over work begins, see load_gym)
+    auto late_rows = [&]() {
+#ifndef FWG_ABL_NO_LATE_ROWS
+        if (SPLIT) load_gym(c, A.S, A.N, e, E, A.bit_goal, 2);
+#endif
+        if (c.metrics) {   // S_(t-1): through the previous record
+            int slot = A.slot_end - 1; slot += (slot < 0) ? FWG_END_RING : 0;
+            sum_prev = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+        }
+        if (c.int_window) {   // S_(t-1-W): the record W + 1 positions before this step's
+            int slot = A.slot_end - (c.int_window + 1); slot += (slot < 0) ? FWG_END_RING : 0;
+            int_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+        }
+    };
+    if (GYM) {
+        // (k_step2: behind the arrival of the actuator groups -- the partner's rows, requested at the same moment, are served first)
+#ifndef FWG_ABL_NO_LOAD_PIN
+        if (SPLIT && ext_act) { fwg_pin_mem(act_q4.x); fwg_pin_mem(raw[2]); }
+#endif
+        // second wave of requests: bookkeeping rows to registers, action windows and lagged observation rows HBM -> LDS;
+        // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
+        // order = order of need (returns are in order): bookkeeping rows, action windows, lagged observation rows
+#ifdef FWG_ABL_NO_LATE_ROWS
+        constexpr bool LATE = false;
+#else
+        constexpr bool LATE = SPLIT;
+#endif
+        load_gym(c, A.S, A.N, e, E, A.bit_goal, LATE ? 1 : 3);
+        // the cumulative error sums this step builds on (fixed point, fwgym_env.h Fix3): their ring slots are positions of the
+        // GLOBAL step counter, so they are requested here, with the bookkeeping rows -- requested inside the pre-barrier work
+        // (rounds 4a) their round trip was waited for at the end of it: every gym wave reached barrier A ~2k ticks later, which
+        // is nothing for a plain wave (its partner integrates for longer) and the whole margin of a wave that also computes a
+        // piece of the next draw, pads early rows or prefetches an episode end
+        if (!LATE) late_rows();
+        if (A.acc != nullptr && valid) ret_prev = A.acc_ret[e];   // attached rollout head: the env's discounted return so far
+        // k_step2: the action windows by PLAIN loads, parked in LDS by this wave itself once they have landed (below).  Behind a
+        // global_load_lds the compiler turns every wait for a vector-memory result into vmcnt(0); with plain loads only, the wait
+        // for the actions and the actuator groups (first in the queue) is exact, and the actuators are advanced while the
+        // bookkeeping rows and the windows are still on their way
+        if (SPLIT) {
+#pragma unroll
+            for (int k = 1; k < FWG_MAX_WINDOW; ++k) {
+                if (k < W) {
+                    int slot = A.slot_act - k; slot += (slot < 0) ? W : 0;
+                    const float4 qa = CGROUP(A.S, A.N, (L.act_ring >> 2) + slot, e);
+                    wa[k][0] = qa.x; wa[k][1] = qa.y; wa[k][2] = qa.z;
+                    if (c.use_cmd_ring) {
+                        const float4 qc = CGROUP(A.S, A.N, (L.cmd_ring >> 2) + slot, e);
+                        wc[k][0] = qc.x; wc[k][1] = qc.y; wc[k][2] = qc.z;
+                    }
+                }
+            }
+        }
+    }
     // history["action"].append(action) (fixed_wing.py:345): the raw action enters the window first (HBM copy here, the
     // LDS copy once the streamed window has landed, i.e. after the integration)
     if (GYM && valid) GROUP(A.S, A.N, (L.act_ring >> 2) + A.slot_act, e) = make_float4(raw[0], raw[1], raw[2], 0.f);
@@ -294,51 +409,35 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             for (int i = 0; i < 6; ++i) gust[i] *= E.gust_gain;
         }
     }
-    float ret_prev = 0.f;
-    float4 int_old = make_float4(0.f, 0.f, 0.f, 0.f);   // integration_window: cumulative error sums W + 1 records back
-    float4 sum_prev = make_float4(0.f, 0.f, 0.f, 0.f);  // the cumulative error sums through the previous record (packed Fix3)
-    float4 act_q3 = make_float4(0.f, 0.f, 0.f, 0.f), act_q4 = act_q3;
-    if (SPLIT && GYM && ext_act) {   // y[12..15] | y[16], y[17], ...: the actuator part of the simulator rows
-        act_q3 = load_group(A.S, A.N, (L.sim >> 2) + 3, e);
-        act_q4 = load_group(A.S, A.N, (L.sim >> 2) + 4, e);
-    }
     if (GYM) {
-        // second wave of requests: bookkeeping rows to registers, action windows and lagged observation rows HBM -> LDS;
-        // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
-        // order = order of need (returns are in order): bookkeeping rows, action windows, lagged observation rows
-        load_gym(c, A.S, A.N, e, E, A.bit_goal);
-        // the cumulative error sums this step builds on (fixed point, fwgym_env.h Fix3): their ring slots are positions of the
-        // GLOBAL step counter, so they are requested here, with the bookkeeping rows -- requested inside the pre-barrier work
-        // (rounds 4a) their round trip was waited for at the end of it: every gym wave reached barrier A ~2k ticks later, which
-        // is nothing for a plain wave (its partner integrates for longer) and the whole margin of a wave that also computes a
-        // piece of the next draw, pads early rows or prefetches an episode end
-        if (c.metrics) {   // S_(t-1): through the previous record
-            int slot = A.slot_end - 1; slot += (slot < 0) ? FWG_END_RING : 0;
-            sum_prev = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+        if (SPLIT && ext_act) {   // the partner's actuator states at t + h/2 and t + h (it needs them after its first stage): computed
+            // while the rows requested above are on their way (plain loads: the wait here covers the actions and the two actuator
+            // groups only); the streamed windows are requested afterwards -- behind a global_load_lds every wait is a full drain
+            const float a0[5] = {act_q3.y, act_q3.z, act_q3.w, act_q4.x, act_q4.y};
+            // (two messages: the deflections at t + h/2 leave as soon as they exist -- the partner's second stage asks for them --,
+            // the state at t + h follows; the fourth stage and the end of the step need it)
+            float a_[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) a_[i] = a0[i];
+            sanitize_actuators(c, a_);
+            _Pragma("unroll") for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_, sp);
+            fwg_msg_put(acts, a_[0], a_[1], a_[2], FWG_TAG_ACTS);
+            FWG_TL(A, 24);
+            _Pragma("unroll") for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_, sp);
+            *reinterpret_cast<float4*>(acts + 4) = make_float4(a_[0], a_[1], a_[2], a_[3]);
+            fwg_msg_put(acts + 8, a_[4], 0.f, 0.f, FWG_TAG_ACTS);
+            FWG_TL(A, 25);
         }
-        if (c.int_window) {   // S_(t-1-W): the record W + 1 positions before this step's
-            int slot = A.slot_end - (c.int_window + 1); slot += (slot < 0) ? FWG_END_RING : 0;
-            int_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
+        if (!SPLIT) {
+            for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.act_ring >> 2) + s, e), lds + M.aring + s * (4 * FWG_WAVE));
+            if (c.use_cmd_ring)
+                for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
         }
-        if (A.acc != nullptr && valid) ret_prev = A.acc_ret[e];   // attached rollout head: the env's discounted return so far
-        for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.act_ring >> 2) + s, e), lds + M.aring + s * (4 * FWG_WAVE));
-        if (c.use_cmd_ring)
-            for (int s = 0; s < W; ++s) dma_group(&CGROUP(A.S, A.N, (L.cmd_ring >> 2) + s, e), lds + M.cring + s * (4 * FWG_WAVE));
 #ifndef FWG_ABL_NO_LAG
         // (k_step2: requested by the gym wave once its bookkeeping rows and action windows have landed, see below)
         if (c.obs_log == 0) { if (!SPLIT) stream_lag_rows(c, A, e, lds + M.lag); }
         else log_wrap(c, A.obs, A.N, e, A.gnow, valid, A.log_wrap_now);
 #endif
-    }
-    if (SPLIT && GYM && ext_act) {
-        const float a0[5] = {act_q3.y, act_q3.z, act_q3.w, act_q4.x, act_q4.y};
-        float a_half[5], a_full[5];
-        actuators_over_step(c, a0, sp, a_half, a_full);
-        float4* w = reinterpret_cast<float4*>(acts);
-        w[0] = make_float4(a_half[0], a_half[1], a_half[2], a_half[3]);
-        w[1] = make_float4(a_half[4], a_full[0], a_full[1], a_full[2]);
-        w[2] = make_float4(a_full[3], a_full[4], 0.f, 0.f);
-        __syncthreads();   // barrier A0 (the physics wave passes it after its first stage)
     }
     int fail = 0;
     if (PHYS) {
@@ -346,33 +445,49 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         E.d = derive<TURB>(E.y, E.wind, gust);
 #else
         FWG_TL(A, 1);
-#ifdef FWG_EXT_ACTUATORS
-        if (SPLIT) fail = sim_step<TURB, PartnerActuators>(c, c, E.y, sp, E.wind, gust, E.d, PartnerActuators{acts});
-        else
+        if constexpr (SPLIT) {
+            // the wave team: actuators from the partner (after the first stage), the new state to the partner as soon as it exists,
+            // constraint checks evaluated once after the last stage
+            constexpr bool ONE = SpecCfg<SPEC>::one_rk4_step;
+#ifdef FWG_ABL_NO_DEFER
+            constexpr bool DEF = false;
+#else
+            constexpr bool DEF = ONE;
 #endif
-        if (KT::generic || c.model_n > 0) {
+            typedef typename std::conditional<ONE, PartnerActuators, NoExtActuators>::type EXT;
+#ifdef FWG_TIMELINE
+            typedef StageStamps HOOK;
+#else
+            typedef NoStageHook HOOK;
+#endif
+            if (c.model_n > 0) fail = sim_step<TURB, EXT, Aero, HOOK, HandToGym, DEF>(c, la, E.y, sp, E.wind, gust, E.d, EXT{acts}, HOOK{A}, HandToGym{hand, &A});
+            else fail = sim_step<TURB, EXT, DevCfg, HOOK, HandToGym, DEF>(c, c, E.y, sp, E.wind, gust, E.d, EXT{acts}, HOOK{A}, HandToGym{hand, &A});
+        } else if (KT::generic || c.model_n > 0) {
             fail = sim_step<TURB, NoExtActuators, Aero>(c, la, E.y, sp, E.wind, gust, E.d);
         } else {
             fail = sim_step<TURB>(c, c, E.y, sp, E.wind, gust, E.d);
         }
 #endif
         FWG_TL(A, 2);
-        if (fail != 0) E.d = derive<TURB>(E.y, E.wind, gust);  // state was left untouched: derived values of the last valid state
-    }
-    if (SPLIT && PHYS) {   // hand the committed state to the gym wave
-        float4* h4 = reinterpret_cast<float4*>(hand);
-        h4[0] = make_float4(E.y[4], E.y[5], E.y[6], E.y[7]);
-        h4[1] = make_float4(E.y[8], E.y[9], E.y[10], E.y[11]);
-        h4[2] = make_float4(E.y[12], E.y[13], E.y[14], E.y[15]);
-        h4[3] = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
-        h4[4] = make_float4(E.d.alpha, E.d.beta, u2f((unsigned)fail), 0.f);
-        if (lane == 0) FWG_FLAG_RAISE(mark, 0);   // (LDS executes a wave's accesses in order: cleared before barrier A releases the partner)
+        if (__ballot(fail != 0) != 0ull) {   // (rare) state was left untouched: derived values of the last valid state
+            if (fail != 0) {
+                E.d = derive<TURB>(E.y, E.wind, gust);
+                if (SPLIT) {   // ... which replace, for the partner, what the failing lane sent before it knew
+                    float4* h4 = reinterpret_cast<float4*>(hand);
+                    h4[0] = make_float4(E.y[4], E.y[5], E.y[6], E.y[7]);
+                    h4[1] = make_float4(E.y[8], E.y[9], E.y[10], E.y[11]);
+                    h4[2] = make_float4(E.y[12], E.y[13], E.y[14], E.y[15]);
+                    h4[3] = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
+                    fwg_msg_put(hand + 24, E.d.alpha, E.d.beta, 0.f, FWG_TAG_OLD);
+                }
+            }
+        }
     }
     float n[4] = {0.f, 0.f, 0.f, 0.f};   // the step's four standard normals for the Dryden filter
-    if (TURB && GYM) {   // (counters: the step and episode indices BEFORE this step; independent of the integration)
+    const unsigned steps_before = E.steps;   // (gym wave: the index of this step inside its episode)
+    if (TURB && GYM && !SPLIT) {   // (counters: the step and episode indices BEFORE this step; independent of the integration)
         const u4 b = philox4x32((unsigned)(A.env_base + e), E.steps, E.episode, FWG_STREAM_TURB, A.seed_lo, A.seed_hi);
         box_muller(b, n);
-        if (SPLIT) *reinterpret_cast<float4*>(noise) = make_float4(n[0], n[1], n[2], n[3]);
     }
     // ---- the part of the gym bookkeeping that does not depend on this step's integration (it needs the streamed action
     // windows only): in the split kernel the gym wave does it while the physics wave integrates
@@ -392,33 +507,49 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // lanes in the first steps of an episode: the padding rows of their observation, up to the "action" entries
     bool pre_early = false;
     float early_noise[FWG_MAX_ROWS] = {};
+    unsigned tail_early = 0u;
+    float sdcmd_add = 0.f;   // control variation of this step (added to the episode's sum once its row is here)
     auto gym_prework = [&]() {
+        FWG_TL(A, 16);
+#ifndef FWG_ABL_NO_LATE_ROWS
+        if (SPLIT) late_rows();
+#endif
+        if (!SPLIT) {   // one-wave kernel: the windows out of their LDS copy (landed: dma_wait above), by age
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {   // the own action enters the LDS copy of the windows
-            aring[A.slot_act * (4 * FWG_WAVE) + i] = raw[i];
-            if (c.use_cmd_ring) cring[A.slot_act * (4 * FWG_WAVE) + i] = cmd_c[i];
+            for (int k = 1; k < FWG_MAX_WINDOW; ++k) {
+                if (k < W) {
+                    int slot = A.slot_act - k; slot += (slot < 0) ? W : 0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        wa[k][i] = aring[slot * (4 * FWG_WAVE) + i];
+                        if (c.use_cmd_ring) wc[k][i] = cring[slot * (4 * FWG_WAVE) + i];
+                    }
+                }
+            }
         }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { wa[0][i] = raw[i]; wc[0][i] = cmd_c[i]; }   // the own action enters the windows
         if (c.metrics) {  // control_variation accumulator (fixed_wing.py:1109-1114)
-            if (E.steps > 0u) {   // the previous constrained command is recomputed from the previous raw action in the window
-                int sp_ = A.slot_act - 1; sp_ += (sp_ < 0) ? W : 0;
+            if (E.steps > 0u && W > 1) {   // the previous constrained command is recomputed from the previous raw action in the window
                 float pc[3];
                 if (c.use_cmd_ring) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) pc[i] = cring[sp_ * (4 * FWG_WAVE) + i];
+                    for (int i = 0; i < 3; ++i) pc[i] = wc[1][i];
                 } else {
                     float praw[3], psp[3];
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        const float r_ = aring[sp_ * (4 * FWG_WAVE) + i];
+                        const float r_ = wa[1][i];
                         praw[i] = c.scale_actions ? (c.act_to_high[i] - c.act_to_low[i]) * (fclampf(r_, c.scale_low, c.scale_high) - c.scale_low) *
                                                         c.inv_scale_span + c.act_to_low[i]
                                                   : r_;
                     }
                     constrain_commands(c, praw, pc, psp);
                 }
-                E.sdcmd += fabsf(cmd_c[0] - pc[0]) + fabsf(cmd_c[1] - pc[1]) + fabsf(cmd_c[2] - pc[2]);
+                sdcmd_add = fabsf(cmd_c[0] - pc[0]) + fabsf(cmd_c[1] - pc[1]) + fabsf(cmd_c[2] - pc[2]);
             }
         }
+        FWG_TL(A, 17);
         E.steps += 1u;
         // lanes in the first steps of an episode: their record 0 is requested now, the padding rows follow at the end of this
         // block (row-log mode without an observer: the partner's tail work instead, tail_rows)
@@ -451,6 +582,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 if (c.obs_log > 0) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
             }
         }
+        FWG_TL(A, 18);
 #pragma unroll
         for (int f = 0; f < FWG_MAX_FACTORS; ++f) {
             fval_action[f] = 0.f;
@@ -465,11 +597,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #pragma unroll
                     for (int k = FWG_MAX_WINDOW - 2; k >= 0; --k) {
                         if (k <= W - 2 && k <= m - 2) {
-                            int s_new = A.slot_act - k; s_new += (s_new < 0) ? W : 0;
-                            int s_old = A.slot_act - k - 1; s_old += (s_old < 0) ? W : 0;
 #pragma unroll
-                            for (int i = 0; i < 3; ++i)
-                                val += fabsf(aring[s_new * (4 * FWG_WAVE) + i] - aring[s_old * (4 * FWG_WAVE) + i]);
+                            for (int i = 0; i < 3; ++i) val += fabsf(wa[k][i] - wa[k + 1][i]);
                         }
                     }
                 }
@@ -482,18 +611,21 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
             fval_action[f] = val;
         }
+        FWG_TL(A, 19);
 #pragma unroll
         for (int j = 0; j < FWG_MAX_OBS; ++j) {
             obs_action[j] = 0.f;
             if (j < c.n_obs && c.obs[j].type == FWG_OBS_ACTION)   // E.steps >= 1 here: never the "no action yet" branch
-                obs_action[j] = action_obs(c, c.use_cmd_ring ? cring : aring, c.obs[j].src, c.obs[j].window, E.steps, A.slot_act, 0.f);
+                obs_action[j] = action_obs_win(c, c.use_cmd_ring ? wc : wa, c.obs[j].src, c.obs[j].window, E.steps);
         }
+        FWG_TL(A, 20);
         {   // targets advanced by one step (fixed_wing.py:401-404) for the common case that none is resampled this step
             float keep[3] = {E.tgt[0], E.tgt[1], E.tgt[2]};
             next_targets(c, E);
 #pragma unroll
             for (int k = 0; k < 3; ++k) { tgt_next[k] = E.tgt[k]; E.tgt[k] = keep[k]; }
         }
+        FWG_TL(A, 21);
         if (c.auto_reset) {   // one piece of the NEXT episode's reset draw, for lanes that do not have it yet.  At most ONE
             // kind of piece per wave and step (the least advanced lanes first): a wave whose lanes sit at different stages
             // would otherwise run all the pieces back to back and outlast the integration it hides behind
@@ -517,19 +649,19 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 }
             }
         }
+        FWG_TL(A, 22);
         if (!tail_rows && __ballot(early_now) != 0ull) {
             if (early_now) { pre_early = true; early_rows_pre(c, A, e, E, ob, rec0, early_noise); }
         }
         // foreseen episode end with a valid prepared draw: the partner installs the new episode (see above); this wave only
         // needs to know that it does.  Both waves decide from the same words (stage, tag, generation, episode)
         if (pre_install) pre_rows = pre_draw && f2u(pre_tag.x) == dc.generation && f2u(pre_tag.y) == E.episode + 1u;
-        if (tail_rows || pre_install)   // (every lane) for the partner: this step's index if its rows need padding | install flag
-            *reinterpret_cast<float4*>(acts) = make_float4(u2f((tail_rows && early_now) ? E.steps : 0u), u2f(pre_rows ? 1u : 0u), 0.f, 0.f);
+        tail_early = (tail_rows && early_now) ? E.steps : 0u;   // (for the partner: this step's index if its rows need padding)
         // (unpacked here, in the time this wave waits for its partner anyway, not on the chain after the barrier)
-        if (c.metrics) S_prev = fix3_unpack(sum_prev);
+        if (c.metrics) { S_prev = fix3_unpack(sum_prev); E.sdcmd += sdcmd_add; }
+        FWG_TL(A, 23);
     };
     if (SPLIT && GYM) {
-        FWG_DMA_DRAIN();   // this wave's own streamed action windows have landed (no other wave reads them)
         FWG_TL(A, 1);
         // dense batch: the lagged observation rows (12 KiB per wave, straight from HBM) are requested only NOW and land under the
         // pre-barrier work below, which does not read them.  Requested with the other rows they delay everything: behind a
@@ -562,41 +694,69 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         }
         FWG_TL(A, 2);
     }
-    if (SPLIT) FWG_BLOCK_SYNC_LDS();     // barrier A
-    if (SPLIT && PHYS && TURB) {
-        const float4 q = *reinterpret_cast<const float4*>(noise);
-        n[0] = q.x; n[1] = q.y; n[2] = q.z; n[3] = q.w;
+    // ---- the two waves meet (k_step2).  Gym wave: what its partner's tail work needs leaves first (the step's index for the
+    // turbulence noise, whose rows need padding, whether the partner installs a foreseen end's next episode -- after the touches
+    // above: the terminal observation's lagged rows are in registers before the partner may overwrite their planes); then the
+    // candidate state, whose Euler angles this wave computes while the partner evaluates airspeed, incidence and the checks;
+    // then those.  Physics wave: it waits for the tail message only, and has nothing else to do by then.
+    if (SPLIT && GYM) {
+        // (what the pre-hand-over work produced exists before the wait: left alone, arithmetic whose results are needed only after
+        // the hand-over is sunk below the polling loop -- onto the chain that starts when the partner's state arrives)
+#pragma unroll
+        for (int f = 0; f < FWG_MAX_FACTORS; ++f) if (f < c.n_factors && c.factor[f].cls == FWG_RC_ACTION) fwg_pin(fval_action[f]);
+#pragma unroll
+        for (int j = 0; j < FWG_MAX_OBS; ++j) if (j < c.n_obs && c.obs[j].type == FWG_OBS_ACTION) fwg_pin(obs_action[j]);
+        fwg_pin(tgt_next[0], tgt_next[1], tgt_next[2], E.sdcmd, E.steps, E.sft, E.flags);
+        if (c.metrics) fwg_pin(S_prev.s[0], S_prev.s[1], S_prev.s[2]);
+        fwg_msg_put(tailm, u2f(steps_before), u2f(tail_early), u2f(pre_rows ? 1u : 0u), FWG_TAG_TAIL);
+        const float4 e4 = fwg_msg_take(hand + 16, FWG_TAG_STATE);
+        FWG_TL(A, 25);
+        const float4* h4 = reinterpret_cast<const float4*>(hand);
+        const float4 a = h4[0], b = h4[1], g = h4[2], ea4 = h4[3];
+        FWG_TL(A, 3);
+        E.y[4] = a.x; E.y[5] = a.y; E.y[6] = a.z; E.y[7] = a.w; E.y[8] = b.x; E.y[9] = b.y; E.y[10] = b.z; E.y[11] = b.w;
+        E.y[12] = g.x; E.y[13] = g.y; E.y[14] = g.z; E.y[15] = g.w;
+        const float ea[5] = {ea4.x, ea4.y, ea4.z, ea4.w, e4.x};
+        euler_from_args(ea, E.d);
+        const float4 r = fwg_msg_take(hand + 20, FWG_TAG_RESULT, 0xFF000000u);
+        E.d.Va = r.x; E.d.alpha = r.y; E.d.beta = r.z;
+        fail = (int)(f2u(r.w) & 0xFFu);
+        if (__ballot(fail != 0) != 0ull) {   // (rare) a failed step: the last valid state and its derived values follow
+            const float4 o = fwg_msg_take(hand + 24, FWG_TAG_OLD, 0xFFFFFFFFu, fail != 0);
+            if (fail != 0) {
+                const float4 a2 = h4[0], b2 = h4[1], g2 = h4[2], d2 = h4[3];
+                E.y[4] = a2.x; E.y[5] = a2.y; E.y[6] = a2.z; E.y[7] = a2.w; E.y[8] = b2.x; E.y[9] = b2.y; E.y[10] = b2.z; E.y[11] = b2.w;
+                E.y[12] = g2.x; E.y[13] = g2.y; E.y[14] = g2.z; E.y[15] = g2.w;
+                E.d.roll = d2.x; E.d.pitch = d2.y; E.d.yaw = d2.z; E.d.Va = d2.w; E.d.alpha = o.x; E.d.beta = o.y;
+            }
+        }
     }
-    // physics wave: what its tail work needs from memory is requested first thing after the barrier
+    // physics wave: what its tail work needs from memory is requested first thing after the hand-over
     unsigned steps_p = 0u;
     bool early_p = false, end_p = false;
     float rec0_p[FWG_MAX_OBS];
     ResetDraw RDp;
-    if (SPLIT && PHYS && (tail_rows || pre_install)) {
-        const float4 w = *reinterpret_cast<const float4*>(acts);
-        steps_p = f2u(w.x);
-        end_p = pre_install && valid && f2u(w.y) != 0u;
-        early_p = tail_rows && valid && fail == 0 && steps_p != 0u && !end_p;   // (an ending lane's rows are the partner's)
-        if (__ballot(early_p) != 0ull) {
-            if (early_p) early_rows_request(c, A, e, rec0_p);
-        }
-        if (__ballot(end_p) != 0ull) {
-            if (end_p) draw_load_final(c, A.S, A.N, e, RDp);   // (just read by the partner: served from the cache)
-        }
-    }
-    // hand-shake B, first mark: this wave's hand-off areas are read (LDS executes a wave's accesses in order), the partner may
-    // re-use them as the output staging area
     if (SPLIT && PHYS) {
+        const float4 w = fwg_msg_take(tailm, FWG_TAG_TAIL);
+        if (tail_rows || pre_install) {
+            steps_p = f2u(w.y);
+            end_p = pre_install && valid && f2u(w.z) != 0u;
+            early_p = tail_rows && valid && fail == 0 && steps_p != 0u && !end_p;   // (an ending lane's rows are the partner's)
+            if (__ballot(early_p) != 0ull) {
+                if (early_p) early_rows_request(c, A, e, rec0_p);
+            }
+            if (__ballot(end_p) != 0ull) {
+                if (end_p) draw_load_final(c, A.S, A.N, e, RDp);   // (just read by the partner: served from the cache)
+            }
+        }
+        // hand-shake B, first mark: this wave has read its partner's messages (LDS executes a wave's accesses in order), the
+        // partner may re-use the area as the output staging area
         FWG_EMU_WAVE_SYNC();
         if (lane == 0) FWG_FLAG_RAISE(mark, 1);   // (asm with a memory clobber: the reads above stay above)
-    }
-    if (SPLIT && GYM) {
-        const float4* h4 = reinterpret_cast<const float4*>(hand);
-        const float4 a = h4[0], b = h4[1], g = h4[2], d0 = h4[3], d1 = h4[4];
-        E.y[4] = a.x; E.y[5] = a.y; E.y[6] = a.z; E.y[7] = a.w; E.y[8] = b.x; E.y[9] = b.y; E.y[10] = b.z; E.y[11] = b.w;
-        E.y[12] = g.x; E.y[13] = g.y; E.y[14] = g.z; E.y[15] = g.w;
-        E.d.roll = d0.x; E.d.pitch = d0.y; E.d.yaw = d0.z; E.d.Va = d0.w; E.d.alpha = d1.x; E.d.beta = d1.y;
-        fail = (int)f2u(d1.z);
+        if (TURB) {   // the step's four standard normals for the Dryden filter (counters: the step and episode indices BEFORE this step)
+            const u4 b = philox4x32((unsigned)(A.env_base + e), f2u(w.x), E.episode, FWG_STREAM_TURB, A.seed_lo, A.seed_hi);
+            box_muller(b, n);
+        }
     }
     const bool ok = fail == 0;
     if (PHYS) {
@@ -609,6 +769,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         }
 #ifndef FWG_ABL_NO_SIMSTORE
         // (foreseen episode end: the old episode's final state went to the partner through LDS; the NEXT episode's rows follow below)
+        if (SPLIT && c.store_derived && !(c.con_mask & 0x7u)) {   // the host views' Euler angles: the partner computed its own copy
+            float ea[5];
+            euler_args(E.y, ea);
+            euler_from_args(ea, E.d);
+        }
         if (valid && !end_p) store_sim<TURB>(c, A.S, A.N, e, E);
 #endif
         FWG_TL(A, 3);

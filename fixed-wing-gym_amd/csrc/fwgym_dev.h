@@ -355,6 +355,62 @@ __device__ __forceinline__ unsigned fwg_lds_peek(const void* p) {
     } while (0)
 #define FWG_FLAG_RAISE(p, level) asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(size_t)(p)), "v"((unsigned)(level)) : "memory")
 #endif
+// pins values in front of a wait: an empty asm statement the values pass through.  The compiler orders `asm volatile` statements
+// among themselves, but arithmetic that is not needed until after a polling loop is SUNK below it (the loop is a basic block of
+// its own) -- the physics wave's first stage ended up behind its wait for the partner's actuator message.  Values that passed
+// through fwg_pin() exist before the next asm volatile statement executes.
+#ifdef FWG_EMU
+template <class... T> __device__ __forceinline__ void fwg_pin(T&...) {}
+#else
+__device__ __forceinline__ void fwg_pin() {}
+template <class T, class... R> __device__ __forceinline__ void fwg_pin(T& x, R&... rest) {
+    asm volatile("" : "+v"(x));
+    fwg_pin(rest...);
+}
+#endif
+// the same with a memory clobber: memory operations written after it are issued after the value exists (k_step2, gym wave: its
+// bulk of row requests goes out when its first three have come back -- the CU's vector-memory path serves requests in order, 1 KiB
+// per 16 cycles, and the physics wave's rows, requested at the same moment, are the ones the step's length hangs on)
+template <class T> __device__ __forceinline__ void fwg_pin_mem(T& x) {
+#ifndef FWG_EMU
+    asm volatile("" : "+v"(x)::"memory");
+#endif
+}
+// One-way MESSAGES between the waves of a workgroup: 16-byte groups per lane in LDS whose last word is a tag.  LDS executes a
+// wave's accesses in order, so a message of several groups is written data first, tagged group last; the reader polls the
+// tagged group and then reads the rest.  No barrier: the writer never waits, the reader waits only for what it needs
+// (tools/ub_handoff.hip: ~290-330 ticks from the write to the value in the reader's registers, against ~480 with a separate
+// flag word -- and an s_barrier makes BOTH waves wait).  Tags are cleared by their writer at kernel entry, before the
+// workgroup's entry barrier (a previous workgroup's leftovers in the same LDS cannot be mistaken for a message).
+#define FWG_TAG_ACTS 0x5A000001u     /* gym -> physics: actuator states at t + h/2 and t + h */
+#define FWG_TAG_STATE 0x5A000002u    /* physics -> gym: candidate state + Euler-angle arguments */
+#define FWG_TAG_RESULT 0x5B000000u   /* physics -> gym: Va, alpha, beta | failure code in the low byte */
+#define FWG_TAG_OLD 0x5A000003u      /* physics -> gym: (failed step) the last valid state and its derived values */
+#define FWG_TAG_TAIL 0x5A000004u     /* gym -> physics: what the physics wave's tail work needs (step index, early / install flags) */
+#ifdef FWG_EMU
+__device__ __forceinline__ void fwg_msg_put(float* p, float a, float b, float c, unsigned tag) {
+    p[0] = a; p[1] = b; p[2] = c; reinterpret_cast<unsigned*>(p)[3] = tag;
+}
+// waits (where `need`) until the group carries a tag with (tag & mask) == want; returns the group
+__device__ __forceinline__ float4 fwg_msg_take(const float* p, unsigned want, unsigned mask = 0xFFFFFFFFu, bool need = true) {
+    while (need && (reinterpret_cast<const volatile unsigned*>(p)[3] & mask) != want) emu_yield();
+    return make_float4(p[0], p[1], p[2], p[3]);
+}
+#else
+__device__ __forceinline__ void fwg_msg_put(float* p, float a, float b, float c, unsigned tag) {
+    const fwg_v4f q = {a, b, c, __uint_as_float(tag)};
+    asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)p), "v"(q) : "memory");
+}
+__device__ __forceinline__ float4 fwg_msg_take(const float* p, unsigned want, unsigned mask = 0xFFFFFFFFu, bool need = true) {
+    fwg_v4f q;
+    for (;;) {
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(q) : "v"((unsigned)(size_t)p) : "memory");
+        if (__ballot(need && (__float_as_uint(q.w) & mask) != want) == 0ull) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return make_float4(q.x, q.y, q.z, q.w);
+}
+#endif
 // ordering of LDS traffic between the lanes of ONE wave (k_step2: the other wave of the workgroup is not involved)
 #ifdef FWG_EMU
 #define FWG_WAVE_SYNC() emu_wave_sync()

@@ -49,8 +49,12 @@ struct KArgs {
 #endif
 };
 #ifdef FWG_TIMELINE
+#define FWG_TL_W 32   /* stamps per wave (tools/timeline.py TLW) */
+#ifndef FWG_TL_WPB
+#define FWG_TL_WPB 2  /* waves per workgroup of the traced kernel (k_step2; k_rollout: 8) -- blockDim.x is a memory load + wait per stamp */
+#endif
 #define FWG_TL(A, i) do { if ((A).trace != nullptr) { const long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); \
-        if ((threadIdx.x & 63) == 0) (A).trace[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (i)] = t_; } } while (0)
+        if ((threadIdx.x & 63) == 0) (A).trace[(blockIdx.x * FWG_TL_WPB + (threadIdx.x >> 6)) * FWG_TL_W + (i)] = t_; } } while (0)
 #else
 #define FWG_TL(A, i) do { } while (0)
 #endif
@@ -194,13 +198,26 @@ __device__ __forceinline__ void apply_slots(KArgs& A, const StepSlots& s) {
 #pragma unroll
     for (int r = 0; r < FWG_MAX_ROWS; ++r) A.lag_slots[r] = s.lag_slots[r];
 }
+// (read through the CONSTANT address space: the record of THIS launch is not written during it -- block 0 publishes the next
+// one into the other buffer -- and as scalar loads the positions cost no vector-memory round trip: through a plain pointer the
+// physics wave, which also stores the next record, read them with global_load + s_waitcnt BEFORE requesting its first rows)
+__device__ __forceinline__ StepSlots load_slots(const StepSlots* p) {
+    FWG_KCONST(StepSlots)* q = (FWG_KCONST(StepSlots)*)p;
+    StepSlots s;
+    s.gnow = q->gnow; s.log_win = q->log_win; s.log_wrap_now = q->log_wrap_now;
+    s.slot_act = q->slot_act; s.slot_end = q->slot_end; s.slot_lag = q->slot_lag; s.bit_goal = q->bit_goal;
+    s.gmod_s = q->gmod_s; s.qmod_p = q->qmod_p; s.pad_ = 0;
+#pragma unroll
+    for (int r = 0; r < FWG_MAX_ROWS; ++r) s.lag_slots[r] = q->lag_slots[r];
+    return s;
+}
 __device__ __forceinline__ KArgs resolve_slots(const DevCfg& c, const KArgs& A0) {
     KArgs A = A0;
     if (A0.slots_in != nullptr) {
         if (A0.reset_launch)   // k_reset: positions of the LAST completed step (rare launch: computed from scratch)
-            apply_slots(A, make_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, A0.slots_in->gnow - 1));
+            apply_slots(A, make_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, load_slots(A0.slots_in).gnow - 1));
         else
-            apply_slots(A, *A0.slots_in);
+            apply_slots(A, load_slots(A0.slots_in));
     }
     return A;
 }
@@ -278,9 +295,11 @@ __host__ __device__ inline int obs_stage_stride(int obs_dim) { return obs_vec4(o
 // every hand-off access before it.  The mark itself is a word of its OWN (LdsMap::flag, outside the staging area: the physics
 // wave raises it to 2 long after its partner may have begun staging output records, so it must not alias a staged value).
 // Workgroup residency is bounded by LDS (4 workgroups per CU need <= 40 KiB each; a fifth area would cost a fourth of the chip).
-#define FWG_HAND_WORDS 20   /* y[4..15] | roll pitch yaw Va alpha beta | failure code | pad: five 16-byte LDS accesses per lane */
-#define FWG_ACT_WORDS 12    /* actuator states at t + h/2 and t + h (2 x 5) | pad: three 16-byte LDS accesses per lane (FWG_EXT_ACTUATORS) */
-#define FWG_SPLIT_WORDS (FWG_HAND_WORDS + 4 + FWG_ACT_WORDS)
+#define FWG_HAND_WORDS 28   /* physics -> gym, seven 16-byte groups per lane (odd: conflict-free): y[4..15] | the five Euler-angle arguments, tag |
+                               Va alpha beta, tag + failure code | (failed step) alpha beta of the last valid state, tag */
+#define FWG_TAIL_WORDS 4    /* gym -> physics: step index, padding-row index, install flag, tag */
+#define FWG_ACT_WORDS 12    /* gym -> physics: actuator states at t + h/2 and t + h (2 x 5), tag: three groups per lane */
+#define FWG_SPLIT_WORDS (FWG_HAND_WORDS + FWG_TAIL_WORDS + FWG_ACT_WORDS)
 __host__ __device__ inline LdsMap lds_map(int obs_dim, int n_obs, int window, int use_cmd_ring, bool generic, int obs_log = 0,
                                           bool split = false) {
     LdsMap m;
@@ -382,8 +401,11 @@ struct Env {
 // component w&3.  A wave touching one group of its 64 envs moves 1 KiB with ONE vector-memory instruction -- the per-CU
 // address path costs about the same per instruction whether a lane moves 4 or 16 bytes, so the number of instructions,
 // not the bytes, is what the layout minimises.  32-bit indices (fwg_create guarantees groups*N < 2^28).
-#define GROUP(S, N, g, e) (reinterpret_cast<float4*>(S)[(unsigned)(g) * (unsigned)(N) + (unsigned)(e)])
-#define CGROUP(S, N, g, e) (reinterpret_cast<const float4*>(S)[(unsigned)(g) * (unsigned)(N) + (unsigned)(e)])
+// (address = a wave-uniform base -- arena + group * N * 16, scalar arithmetic -- plus a 32-bit per-lane byte offset e * 16: the
+// form global_load / global_store take as `saddr + voffset`, so that ONE vector register addresses every group of the lane
+// instead of a 64-bit address pair per group held across the kernel)
+#define GROUP(S, N, g, e) (*reinterpret_cast<float4*>(reinterpret_cast<char*>(S) + (size_t)(unsigned)(g) * (size_t)(unsigned)(N) * 16u + (size_t)((unsigned)(e) << 4)))
+#define CGROUP(S, N, g, e) (*reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S) + (size_t)(unsigned)(g) * (size_t)(unsigned)(N) * 16u + (size_t)((unsigned)(e) << 4)))
 // rows written now and read back only some steps later (lag ring, end-error ring): streaming stores, measured -0.3 us
 // per C3 step; FWG_NO_NT_RING_STORES restores plain stores
 __device__ __forceinline__ void store_group_once(float* S, long N, int g, long e, float4 v) {
@@ -488,12 +510,30 @@ __device__ __forceinline__ void store_cold(const DevCfg& c, float* __restrict__ 
 // only when a lane of the wave changed them (running extremes, rise-time latches, the episode's initial errors):
 // 5: emin[0..2] rise0 | 6: emax[0..2] rise1 | 7: rise2 e0[0..2].  8: psh[0..2] (potential rewards only).
 // Then 3 groups of target properties (linear/sinusoidal targets only) and the goal-window ring as 16 plain word rows.
-__device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E, int goal_bit) {
+// `part`: 3 = everything; 1 = what the work BEFORE the hand-over reads (targets, counters, flags, goal word, target properties,
+// reward scalings); 2 = the metric accumulators and the previous shaping terms, read after it (k_step2 requests them when its
+// first work is under way: the rows of a launch are all wanted in its first microsecond, and what is asked for then queues behind
+// everything else that is)
+__device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restrict__ S, long N, long e, Env& E, int goal_bit, int part = 3) {
     const int g0 = c.L.gym >> 2;
     float4 q[9];
 #pragma unroll
     for (int g = 0; g < 9; ++g)
-        if (g < 2 || (g < 8 && c.metrics) || (g == 8 && c.reward_potential)) q[g] = load_group(S, N, g0 + g, e);
+        if (((g < 2) && (part & 1)) || ((part & 2) && ((g >= 2 && g < 8 && c.metrics) || (g == 8 && c.reward_potential)))) q[g] = load_group(S, N, g0 + g, e);
+    if (part & 2) {
+        if (c.metrics) {
+            E.esum[0] = q[2].x; E.esum[1] = q[2].y; E.esum[2] = q[2].z; E.perr[0] = q[2].w;
+            E.eabs[0] = q[3].x; E.eabs[1] = q[3].y; E.eabs[2] = q[3].z; E.perr[1] = q[3].w;
+            E.sdcmd = q[4].x; E.perr[2] = q[4].y; E.settle[0] = f2u(q[4].z); E.settle[1] = f2u(q[4].w);
+            E.emin[0] = q[5].x; E.emin[1] = q[5].y; E.emin[2] = q[5].z; E.rise[0] = f2u(q[5].w);
+            E.emax[0] = q[6].x; E.emax[1] = q[6].y; E.emax[2] = q[6].z; E.rise[1] = f2u(q[6].w);
+            E.rise[2] = f2u(q[7].x); E.e0[0] = q[7].y; E.e0[1] = q[7].z; E.e0[2] = q[7].w;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { E.was_emin[k] = E.emin[k]; E.was_emax[k] = E.emax[k]; E.was_rise[k] = E.rise[k]; }
+        }
+        if (c.reward_potential) { E.psh[0] = q[8].x; E.psh[1] = q[8].y; E.psh[2] = q[8].z; }
+    }
+    if (!(part & 1)) return;
     if (c.randomize_scaling) {
 #pragma unroll
         for (int g = 0; g < FWG_MAX_FACTORS / 4; ++g) {
@@ -506,17 +546,6 @@ __device__ __forceinline__ void load_gym(const DevCfg& c, const float* __restric
     E.tgt[0] = q[0].x; E.tgt[1] = q[0].y; E.tgt[2] = q[0].z;
     E.steps = f2u(q[0].w) & 0xFFFFu; E.sft = f2u(q[0].w) >> 16;
     E.flags = f2u(q[1].x); E.wcnt = f2u(q[1].y); E.gcnt[0] = f2u(q[1].z); E.gcnt[1] = f2u(q[1].w);
-    if (c.metrics) {
-        E.esum[0] = q[2].x; E.esum[1] = q[2].y; E.esum[2] = q[2].z; E.perr[0] = q[2].w;
-        E.eabs[0] = q[3].x; E.eabs[1] = q[3].y; E.eabs[2] = q[3].z; E.perr[1] = q[3].w;
-        E.sdcmd = q[4].x; E.perr[2] = q[4].y; E.settle[0] = f2u(q[4].z); E.settle[1] = f2u(q[4].w);
-        E.emin[0] = q[5].x; E.emin[1] = q[5].y; E.emin[2] = q[5].z; E.rise[0] = f2u(q[5].w);
-        E.emax[0] = q[6].x; E.emax[1] = q[6].y; E.emax[2] = q[6].z; E.rise[1] = f2u(q[6].w);
-        E.rise[2] = f2u(q[7].x); E.e0[0] = q[7].y; E.e0[1] = q[7].z; E.e0[2] = q[7].w;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { E.was_emin[k] = E.emin[k]; E.was_emax[k] = E.emax[k]; E.was_rise[k] = E.rise[k]; }
-    }
-    if (c.reward_potential) { E.psh[0] = q[8].x; E.psh[1] = q[8].y; E.psh[2] = q[8].z; }
     if (c.any_dynamic_target) {
 #pragma unroll
         for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
@@ -737,6 +766,22 @@ __device__ __forceinline__ float action_obs(const DevCfg& c, const float* ring, 
             int s_new = cur_slot - k; s_new += (s_new < 0) ? W : 0;
             int s_old = cur_slot - k - 1; s_old += (s_old < 0) ? W : 0;
             s += fabsf(ring[s_new * (4 * FWG_WAVE) + ai] - ring[s_old * (4 * FWG_WAVE) + ai]);
+        }
+    }
+    return s;
+}
+
+// the same sum over a window held in registers by age (win[k] = the entry of k steps ago, win[0] = this step's), n_act >= 1
+__device__ __forceinline__ float action_obs_win(const DevCfg& c, const float (&win)[FWG_MAX_WINDOW][3], int ai, int w, unsigned n_act) {
+    const int W = c.L.window;
+    const int m = (int)min(n_act, (unsigned)w);
+    float s = 0.f;
+#pragma unroll
+    for (int k = FWG_MAX_WINDOW - 2; k >= 0; --k) {
+        if (k <= W - 2 && k <= m - 2) {
+            const float a = ai == 0 ? win[k][0] : (ai == 1 ? win[k][1] : win[k][2]);
+            const float b = ai == 0 ? win[k + 1][0] : (ai == 1 ? win[k + 1][1] : win[k + 1][2]);
+            s += fabsf(a - b);
         }
     }
     return s;

@@ -18,6 +18,7 @@ PKG = os.path.join(ROOT, "fixed-wing-gym_amd")
 OUT = os.path.join(PKG, "gym_fixed_wing", "_abl")
 LIB = os.path.join(OUT, os.environ.get("TL_LIB", "libfwgym_timeline.so"))
 # (table of phase names kept for reference; the run prints the stamps of each wave relative to the block's start)
+TLW = 32   # stamps per wave (csrc/fwgym_env.h FWG_TL_W)
 NAMES = ["entry->loads issued", "integration (incl. wait for state)", "store sim rows", "wait streamed windows (vmcnt0)",
          "gym logic", "store gym rows", "observation build", "episode-end branch", "outputs issued", "stores acknowledged"]
 
@@ -47,7 +48,7 @@ def run():
                               obs_log_rows=log_rows, _lib_path=LIB)
         assert vec.spec_index >= 0
         vec.reset()
-        trace = torch.zeros((n // 64 * 2, 16), dtype=torch.int64, device="cuda")
+        trace = torch.zeros((n // 64 * 2, TLW), dtype=torch.int64, device="cuda")
         vec._lib.fwg_debug_set_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         vec._lib.fwg_debug_set_trace(vec._handle, ctypes.c_void_p(trace.data_ptr()))
         acts = [torch.rand((n, 3), device="cuda") * 2 - 1 for _ in range(16)]
@@ -74,14 +75,14 @@ def run():
             vec.step_device(acts[rep % 16])
             e1.record()
             torch.cuda.synchronize()
-            t = trace.cpu().numpy().astype(np.float64).reshape(n // 64, 2, 16)
+            t = trace.cpu().numpy().astype(np.float64).reshape(n // 64, 2, TLW)
             rows.append((t, e0.elapsed_time(e1) * 1e3))
         T = np.stack([r[0] for r in rows])                    # [rep][block][wave][16]
         T = np.where(T == 0, np.nan, T)
         t0 = np.nanmin(T[:, :, :, 0], axis=2, keepdims=True)[..., None]     # the block's first stamp
         rel = T - t0                                          # ticks since the block started
         key = "{}{}".format(wl, "_log" if log_rows else "")
-        med = np.nanmedian(rel.reshape(-1, 2, 16), axis=0)    # [wave][stamp]
+        med = np.nanmedian(rel.reshape(-1, 2, TLW), axis=0)    # [wave][stamp]
         start_spread = float(np.nanmedian(np.nanmax(T[:, :, :, 0], axis=(1, 2)) - np.nanmin(T[:, :, :, 0], axis=(1, 2))))
         life = np.nanmedian(np.nanmax(rel, axis=(2, 3)))
         res[key] = {"stamp_ticks_median": [[None if np.isnan(x) else float(x) for x in w] for w in med],
@@ -92,7 +93,7 @@ def run():
         for w in range(2):
             if np.all(np.isnan(med[w])):
                 continue
-            print("   wave {}: ".format(w) + "  ".join("{}:{:.0f}".format(i, med[w][i]) for i in range(11) if not np.isnan(med[w][i])))
+            print("   wave {}: ".format(w) + "  ".join("{}:{:.0f}".format(i, med[w][i]) for i in np.argsort(np.where(np.isnan(med[w]), 1e18, med[w])) if not np.isnan(med[w][i])))
         # the slowest block of the last launch: where did ITS time go?
         last = rel[-1]
         worst = int(np.nanargmax(np.nanmax(last, axis=(1, 2))))

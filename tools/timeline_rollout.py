@@ -26,7 +26,7 @@ for precise in (True, False):
     assert actor.rollout_available(vec)
     nb = (n + 255) // 256
     tr_head = torch.zeros((nb, 8, 16), dtype=torch.int64, device="cuda")
-    tr_step = torch.zeros((nb, 8, 16), dtype=torch.int64, device="cuda")
+    tr_step = torch.zeros((nb, 8, 32), dtype=torch.int64, device="cuda")   # (FWG_TL_W)
     lib.fwg_debug_set_actor_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.fwg_debug_set_actor_trace(actor._handle, ctypes.c_void_p(tr_head.data_ptr()))
     lib.fwg_debug_set_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -44,8 +44,8 @@ for precise in (True, False):
     H, S = np.stack(H), np.stack(S)                     # [rep, block, wave, stamp]
     t0 = H[:, :, :, 0].min(axis=2)[:, :, None, None]     # block start
     h = np.median((H - t0).reshape(-1, 16), axis=0)
-    phys = np.median((S[:, :, :4] - t0).reshape(-1, 16), axis=0)
-    gym = np.median((S[:, :, 4:] - t0).reshape(-1, 16), axis=0)
+    phys = np.median((S[:, :, :4] - t0).reshape(-1, 32), axis=0)
+    gym = np.median((S[:, :, 4:] - t0).reshape(-1, 32), axis=0)
     end = np.median(np.nanmax(np.where(S > 0, S - t0, np.nan), axis=(2, 3)))
     spread = np.median(H[:, :, :, 0].max(axis=(1, 2)) - H[:, :, :, 0].min(axis=(1, 2)))
     print("precise={}: launch {:.2f} us (eager, events); first->last block start {:.0f} ticks; block lifetime (last stamp) {:.0f} ticks".format(
