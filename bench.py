@@ -48,6 +48,14 @@ def workload(name):
     return presets.workload(name)
 
 
+def default_total_envs(world, workload_name, envs, total_envs, emulate):
+    """TOTAL envs of the default multi-GPU run (0 = per-GPU sizing): 65 536 sharded over the ranks for c3 on N > 1 GPUs -- the
+    north-star point of BASELINE.json -- unless a size was given."""
+    if world > 1 and workload_name == "c3" and not envs and not total_envs and not emulate:
+        return 65536
+    return 0
+
+
 def source_hash():
     """Identity of the kernel sources a profile / traffic figure belongs to."""
     h = hashlib.sha256()
@@ -299,6 +307,13 @@ def main():
     if args.emulate and not args.envs and not args.total_envs:
         n_envs = 128
     first = rank * n_envs
+    # N > 1 GPUs, c3, no explicit size: `value` is the NORTH-STAR point of BASELINE.json -- 65 536 envs IN TOTAL sharded over the
+    # ranks (strong scaling: the 1/2/4/8-GPU curve the driver assembles from the per-N lines is then the curve BASELINE.json asks
+    # for, and it meets the N = 1 line at the same 65 536 envs); weak scaling at 65 536 envs per GPU and BASELINE configs[3]
+    # (32 768 per GPU) ride along as side figures
+    north_star_default = default_total_envs(world, args.workload, args.envs, args.total_envs, args.emulate) > 0
+    if north_star_default:
+        args.total_envs = default_total_envs(world, args.workload, args.envs, args.total_envs, args.emulate)
     if args.total_envs:
         first, n_envs = fd.shard(args.total_envs, rank, world)
         scaling = "strong"
@@ -377,7 +392,7 @@ def main():
             """hipGraph of n consecutive fwg_step launches on pool actions (n even) + the chunk's success sums.  A captured
             sequence has the parity of the step counter baked in (double-buffered ring positions): one graph per parity."""
             vec = self.vec
-            key = (n, offset % len(self.pool), vec.global_step & 1, bool(want_obs))
+            key = (n, offset % len(self.pool), vec.global_step & 1, bool(want_obs), getattr(vec, "_graph_obs", "view"))
             if key not in self.graphs:
                 g = torch.cuda.CUDAGraph()
                 parity = vec.capture_begin()
@@ -456,7 +471,7 @@ def main():
 
         def get_rollout(n):
             if n not in rollouts:
-                rollouts[n] = FusedRollout(vec, actor, n, graph=True)
+                rollouts[n] = FusedRollout(vec, actor, n, graph=True, fused="auto")
             return rollouts[n]
 
     if graphs and not fused:
@@ -526,14 +541,26 @@ def main():
             note="episode ages uniform over [0, steps_max) (a random 1/steps_max of the envs reset at every step of an untimed "
                  "steps_max-step run): about {} episode ends per step, scattered over the waves".format(per_step))
         if vec.obs_log_rows:
-            # an observation CONSUMER inside the replayed sequence: every step is followed by the gather of the dense
-            # [N][length][n_obs] batch out of the row log (what a torch policy reads under graph replay), steady state
+            # the observation in a consumer's hands on EVERY step of a replayed graph, steady state.  Route of round 5: the
+            # zero-copy window of the row log -- step_device(want_obs=True) hands out a strided [N][length][n_obs] view per
+            # captured step; the views stay right under replay because the chunk is a whole number of window periods
+            # (FixedWingVecEnv.set_graph_mode(obs="view"), tests/test_obs_log.py).  No copy, no extra launch: what the consumer
+            # then reads is its own traffic, as with any layout.
+            per = vec.obs_window_period
+            if per and sc % per == 0:
+                sides["obs_delivered"] = side_entry(R.time_replays(sc, sreps, want_obs=True), n_envs, route="row_log_view",
+                    window_period_steps=per,
+                    note="steady state with the zero-copy observation window handed out on every step of the replayed graph (views "
+                         "computed at capture, valid under replay: the {}-step chunk is {} window periods).  Rounds 3-4 published "
+                         "the cheaper of a dense copy (obs_layout='dense') and row log + gather under this key: now "
+                         "`obs_delivered_copy`".format(sc, sc // per))
+            # a dense COPY for a consumer that cannot take a strided view: fwg_obs_gather after every step inside the graph
+            vec.set_graph_mode(True, obs="gather")
             sides["obs_gather_row_log"] = side_entry(R.time_replays(sc, sreps, want_obs=True), n_envs,
-                note="steady state + fwg_obs_gather after every step inside the replayed graph: the dense observation batch a "
-                     "torch consumer reads out of a ROW-LOG env (the HIP rollout head reads the log in place instead: c5).  A consumer "
-                     "that needs the dense batch every step is served cheaper by the dense layout (obs_layout='dense'): `obs_delivered`. "
-                     "(Round 4 also built the copy inside the step kernel -- the physics wave moving the lagged rows in its idle "
-                     "tail: 19.4 us, +432 B per env-step of traffic on a kernel that moves 724; not kept.)")
+                note="steady state + fwg_obs_gather after every step inside the replayed graph (set_graph_mode(obs='gather')): a "
+                     "dense copy of the observation batch out of a ROW-LOG env.  A consumer that needs a dense batch every step is "
+                     "served cheaper by the dense layout (obs_layout='dense'): `dense_layout`, `obs_delivered_copy`")
+            vec.set_graph_mode(True, obs="view")
     if side_ok and world == 1 and args.workload == "c3" and not args.stagger and not args.envs and not args.total_envs:
         def side_env(name, wl_cfg, n, rows, alg, note, stag=True, extra=None):
             try:
@@ -564,10 +591,11 @@ def main():
             cands = [c_ for c_ in cands if c_[0]]
             if cands:
                 ms, via = min(cands)
-                sides["obs_delivered"] = side_entry(ms, n_envs, via=via, row_log_gather_ms_per_step=g.get("ms_per_step"),
-                                                    dense_layout_ms_per_step=d.get("steady_state_ms_per_step"),
-                                                    note="the dense [N][5][12] observation batch in a torch consumer's hands after every "
-                                                         "step, episode ages uniform: the cheaper of the dense layout and row log + gather")
+                sides["obs_delivered_copy"] = side_entry(ms, n_envs, via=via, row_log_gather_ms_per_step=g.get("ms_per_step"),
+                                                         dense_layout_ms_per_step=d.get("steady_state_ms_per_step"),
+                                                         note="a dense [N][5][12] COPY of the observation batch after every step, episode ages "
+                                                              "uniform: the cheaper of the dense layout and row log + gather (rounds 3-4 "
+                                                              "published this figure as `obs_delivered`)")
         c2 = workload("c2")
         side_env("c2", c2[:3], c2[3], None, ALG_BYTES["c2"], c2[4] + " (BASELINE configs[1]; 64 workgroups: launch-latency bound)", stag=False)
         import copy as _copy
@@ -614,7 +642,7 @@ def main():
                 torch.manual_seed(0)
                 act = DeviceActor.for_env(S.vec, seed=7, env_id_base=0, precise=precise)
                 act.load_policy(MlpPolicy(S.vec.obs_dim))
-                ro = FusedRollout(S.vec, act, sc, graph=True)
+                ro = FusedRollout(S.vec, act, sc, graph=True, fused="auto")   # (the one-launch step is opt-in: asked for here)
                 for _ in range(3):
                     ro.run()
                 torch.cuda.synchronize(dev)
@@ -638,10 +666,9 @@ def main():
 
         side_c5("c5", True)
         side_c5("c5_bf16", False)
-    if side_ok and world > 1 and args.workload == "c3" and not args.envs and not args.total_envs:
-        # multi-GPU side figures: BASELINE configs[3] (32 768 envs per GPU) and the north-star point (65 536 envs in total)
-        ns_first, ns_n = fd.shard(65536, rank, world)
-        for name, n_side, first_side in (("c4_32768_per_gpu", 32768, rank * 32768), ("north_star_65536_total", ns_n, ns_first)):
+    if side_ok and world > 1 and args.workload == "c3" and north_star_default:
+        # multi-GPU side figures: BASELINE configs[3] (32 768 envs per GPU) and weak scaling at the one-GPU workload (65 536 per GPU)
+        for name, n_side, first_side in (("c4_32768_per_gpu", 32768, rank * 32768), ("weak_65536_per_gpu", 65536, rank * 65536)):
             try:
                 S = Runner(cfg, ckw, skw, n_side, first_side, log_rows)
                 S.enable_graphs()
@@ -653,7 +680,7 @@ def main():
                 tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 ms = float(tt.item()) / (sreps * sc) * 1e3
-                sides[name] = {"ms_per_step": ms, "value": n_side * world / (ms * 1e-3) if name.startswith("c4") else 65536 / (ms * 1e-3),
+                sides[name] = {"ms_per_step": ms, "value": n_side * world / (ms * 1e-3), "scaling": "weak",
                                "unit": "env-steps/s", "envs_per_gpu": n_side, "steps": sreps * sc,
                                "rccl_ranks": dist.get_world_size(), "success_allgather_every": sc}
                 S.vec.close()

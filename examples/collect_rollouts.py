@@ -43,7 +43,7 @@ def main():
     torch.manual_seed(0)                                   # the same random-init policy on every rank
     actor = DeviceActor.for_env(vec, seed=1)               # sampling noise keyed by the global env ids
     actor.load_policy(MlpPolicy(vec.obs_dim))
-    rollout = FusedRollout(vec, actor, args.n_steps, graph=True)
+    rollout = FusedRollout(vec, actor, args.n_steps, graph=True, fused="auto")
     rollout.run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -837,7 +837,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (ok) {
             const Fix3 o = fix3_unpack(int_old);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) wsum[k] = fix_to_float(S_prev.s[k] - ((t - 1 - W >= 0) ? o.s[k] : 0ll));
+            for (int k = 0; k < 3; ++k) wsum[k] = fix_to_float(fix_wrap(S_prev.s[k] - ((t - 1 - W >= 0) ? o.s[k] : 0ll)));
         } else {   // S_(t-2) = S_(t-1) - the previous record's error (E.perr is the very float that was quantised into it)
             Fix3 o2 = {{0ll, 0ll, 0ll}};
             if (t - 2 - W >= 0) {
@@ -845,7 +845,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 o2 = fix3_unpack(CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e));
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) wsum[k] = fix_to_float(S_prev.s[k] - fix_quant(E.perr[k]) - o2.s[k]);
+            for (int k = 0; k < 3; ++k) wsum[k] = fix_to_float(fix_wrap(S_prev.s[k] - fix_quant(E.perr[k]) - o2.s[k]));
         }
 #pragma unroll
         for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
@@ -1071,7 +1071,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                     const Fix3 old = fix3_unpack(pre_old);
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
-                        R.end_sum[k] = fix_to_float(S_prev.s[k] - (R.n_rec > (unsigned)FWG_END_WINDOW ? old.s[k] : 0ll));
+                        R.end_sum[k] = fix_to_float(fix_wrap(S_prev.s[k] - (R.n_rec > (unsigned)FWG_END_WINDOW ? old.s[k] : 0ll)));
                 }
                 if (E.flags & FWG_FLAG_FIN_PENDING) fin_collect_pending(c, A, e);   // (rare) never collected: fold it now
                 fin_store(c, A.S, A.N, e, R);
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(FWG_WAVE) void k_reset(const DevCfg* __restrict__ c
             o = fix3_unpack(CGROUP(A.S, A.N, (c.L.end_ring >> 2) + slot, e));
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) E.int_reset[k] = fix_to_float(Sl.s[k] - fix_quant(perr[k]) - o.s[k]) + (float)(W + 1) * e0[k];
+        for (int k = 0; k < 3; ++k) E.int_reset[k] = fix_to_float(fix_wrap(Sl.s[k] - fix_quant(perr[k]) - o.s[k])) + (float)(W + 1) * e0[k];
         (void)q2;
     }
     if (sel) reset_env<TURB>(c, dc, A, e, E, T, ob, lds + M.aring + lane * 4, A.slot_end, A.slot_lag, A.bit_goal);
@@ -1509,6 +1509,7 @@ struct fwg_handle {
     unsigned* d_mq;               // simulator.model / randomize_scaling: two reset queues [2][1 + N] (by the parity of the step count)
     int model_all_stale;          // every env needs a new prepared set (start, fwg_update_config, fwg_seed): full-grid draw next
     struct fwg_actor* observer;   // attached rollout head (fwg_attach_observer) or null
+    int rollout_lds_granted;      // the one-launch rollout step's dynamic LDS has been asked for (both head variants)
     int split;                    // specialised configurations: the step runs as k_step2 (two waves per 64 envs)
 #ifdef FWG_TIMELINE
     long long* trace;
@@ -1863,6 +1864,7 @@ static void base_args(const fwg_handle* h, KArgs* A) {
 }
 
 static void observer_args(fwg_handle* h, KArgs* A);   // defined with the rollout head below
+static int launch_rollout(fwg_handle* h, fwg_actor* a, const KArgs& A, const ActorArgs& AA, hipStream_t stream, bool probe, bool grant = false);
 // simulator.model: before any launch that may reset an env, every env has the parameter set of its next episode prepared
 static void launch_model_draw(fwg_handle* h, const KArgs& A, hipStream_t stream, bool all) {
     if (h->h.model_n <= 0 && !h->h.randomize_scaling) return;
@@ -2176,6 +2178,10 @@ int fwg_attach_observer(fwg_handle* h, fwg_actor* a) {
     if (a && (a->n_envs != h->n_envs || a->D != h->h.obs_dim || a->device != h->device))
         return fail_with(FWG_ERR_INVALID, "fwg_attach_observer: the head was created for another batch size / observation size / device");
     h->observer = a;
+    // the one-launch rollout step's dynamic LDS (both head variants), asked for here and now: attach is never captured
+    h->rollout_lds_granted = 0;
+    if (a && h->spec >= 0 && h->split && launch_rollout(h, a, KArgs(), ActorArgs(), nullptr, true) == 0)
+        h->rollout_lds_granted = launch_rollout(h, a, KArgs(), ActorArgs(), nullptr, false, true) == 0 ? 1 : 0;
     return FWG_OK;
 }
 
@@ -2351,23 +2357,24 @@ int fwg_actor_act(fwg_actor* a, const float* obs, const float* reward, const uin
 
 }  // extern "C"
 // ---- the head and the env step in one launch
+// grant = true (fwg_attach_observer, never inside a stream capture): asks for the dynamic LDS of BOTH head variants -- more than
+// 64 KiB per workgroup has to be requested per kernel; done eagerly and recorded in the handle, so that no launch (possibly the
+// first one of a variant inside a capture, after fwg_actor_configure) ever has to
 template <bool TURB, int SPEC>
-static int launch_rollout_one(fwg_handle* h, fwg_actor* a, const KArgs& A, const ActorArgs& AA, hipStream_t stream) {
+static int launch_rollout_one(fwg_handle* h, fwg_actor* a, const KArgs& A, const ActorArgs& AA, hipStream_t stream, bool grant) {
     if constexpr (SPEC >= 0) {
         if constexpr (SpecCfg<SPEC>::rollout_ok) {
+            if (grant) {
+                const size_t b3 = (size_t)rollout_lds_floats(h->h, 3) * sizeof(float), b1 = (size_t)rollout_lds_floats(h->h, 1) * sizeof(float);
+                if (b3 > 160 * 1024 || b1 > 160 * 1024) return 1;
+                if (hipFuncSetAttribute((const void*)k_rollout<TURB, SPEC, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b3) != hipSuccess) return 1;
+                if (hipFuncSetAttribute((const void*)k_rollout<TURB, SPEC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b1) != hipSuccess) return 1;
+                return 0;
+            }
             const int hsplit = a->precise ? 3 : 1;
             const size_t bytes = (size_t)rollout_lds_floats(h->h, hsplit) * sizeof(float);
-            if (bytes > 160 * 1024) return 1;
+            if (bytes > 160 * 1024 || !h->rollout_lds_granted) return 1;
             const dim3 grid((unsigned)((h->n_envs + FWG_RO_ENVS - 1) / FWG_RO_ENVS)), block(2 * FWG_RO_ENVS);
-            const void* fn = a->precise ? (const void*)k_rollout<TURB, SPEC, 3> : (const void*)k_rollout<TURB, SPEC, 1>;
-            // more than 64 KiB of dynamic LDS has to be asked for -- once per kernel and device, on the first (never captured:
-            // FusedRollout warms every kernel up outside the capture) launch, not inside a stream capture
-            static size_t granted[2][16] = {};
-            size_t& have = granted[a->precise ? 1 : 0][h->device & 15];
-            if (have < bytes) {
-                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
-                have = bytes;
-            }
             if (a->precise) hipLaunchKernelGGL((k_rollout<TURB, SPEC, 3>), grid, block, bytes, stream, h->d_cfg, h->d_dyn, A, AA);
             else hipLaunchKernelGGL((k_rollout<TURB, SPEC, 1>), grid, block, bytes, stream, h->d_cfg, h->d_dyn, A, AA);
             return 0;
@@ -2375,11 +2382,11 @@ static int launch_rollout_one(fwg_handle* h, fwg_actor* a, const KArgs& A, const
     }
     return 1;
 }
-static int launch_rollout(fwg_handle* h, fwg_actor* a, const KArgs& A, const ActorArgs& AA, hipStream_t stream, bool probe) {
+static int launch_rollout(fwg_handle* h, fwg_actor* a, const KArgs& A, const ActorArgs& AA, hipStream_t stream, bool probe, bool grant) {
     switch (h->spec) {
 #define FWG_SPEC_RO(i) \
     case i: if (probe) return (SpecCfg<i>::rollout_ok && (size_t)rollout_lds_floats(kSpec##i, 3) * sizeof(float) <= 160 * 1024) ? 0 : 1; \
-            return launch_rollout_one<(kSpec##i.turbulence != 0), i>(h, a, A, AA, stream);
+            return launch_rollout_one<(kSpec##i.turbulence != 0), i>(h, a, A, AA, stream, grant);
         FWG_SPEC_LIST(FWG_SPEC_RO)
 #undef FWG_SPEC_RO
         default: break;
@@ -2393,6 +2400,7 @@ int fwg_rollout_available(const fwg_handle* h, const fwg_actor* a) {
     if (!h || !a || h->observer != a || h->spec < 0 || !h->split || h->h.obs_log > 0) return 0;
     if (h->h.model_n > 0 || h->h.randomize_scaling) return 0;   // (the per-env parameter queue launch sits between head and step)
     if (a->act_dim != 3 || a->log_env != nullptr) return 0;
+    if (!h->rollout_lds_granted) return 0;
     return launch_rollout(const_cast<fwg_handle*>(h), const_cast<fwg_actor*>(a), KArgs(), ActorArgs(), nullptr, true) == 0 ? 1 : 0;
 }
 

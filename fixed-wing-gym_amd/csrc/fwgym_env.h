@@ -338,18 +338,24 @@ struct LdsTable {
 // the whole window; integration_window sums likewise.  The sums are 42-bit FIXED POINT (2^-22 resolution, three to a slot): a
 // float32 running sum reaches 10^3 - 10^4 late in a 2 000-step episode and the difference of two of them then carries 1e-4 - 1e-3
 // of absolute error (rounds 1-3); integer sums are exact, so the window sum carries only the 50 quantisation errors of its own
-// terms (< 6e-6, 1e-7 on the mean) whatever the episode length.  |error| < 512 and |sum| < 5e5 by construction.
+// terms (< 6e-6, 1e-7 on the mean) whatever the episode length.  |error| < 512 by the quantiser; the sums wrap modulo 2^42 and
+// every use is a difference reduced back to 42 bits (fix_wrap).
 #define FWG_ESUM_FRAC 22
 #define FWG_ESUM_SCALE 4194304.f
 struct Fix3 { long long s[3]; };
 __device__ __forceinline__ long long fix_quant(float err) {
-#ifdef FWG_EMU
+#ifdef FWG_EMU   /* the device's v_cvt_i32_f32: round to nearest even, saturating, NaN -> 0 */
     const float x = rintf(err * FWG_ESUM_SCALE);
-    return (long long)(x >= 2147483520.f ? 2147483520.f : (x <= -2147483520.f ? -2147483520.f : x));
+    if (!(x == x)) return 0ll;
+    return x >= 2147483648.f ? 2147483647ll : (x <= -2147483648.f ? -2147483648ll : (long long)x);
 #else
     return (long long)__float2int_rn(err * FWG_ESUM_SCALE);   // (v_cvt_i32_f32 saturates)
 #endif
 }
+// A DIFFERENCE of ring values, reduced to the ring's 42 bits: the packed sums wrap modulo 2^42 (|sum| < 2^41 holds for ~1k steps
+// of a saturated error, not for an episode without a step limit), and every window sum is a difference of two of them -- exact
+// in modular arithmetic for any episode length as long as the window's own sum fits (51 terms of < 2^31: it does)
+__device__ __forceinline__ long long fix_wrap(long long d) { return (long long)((unsigned long long)d << 22) >> 22; }
 __device__ __forceinline__ float fix_to_float(long long d) {   // d 2^-22 for |d| < 2^47: two exact conversions and one fma
     const int hi = (int)(d >> 16), lo = (int)(d & 0xFFFFll);
     return ((float)hi * 65536.f + (float)lo) * (1.f / FWG_ESUM_SCALE);

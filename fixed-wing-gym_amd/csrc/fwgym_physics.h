@@ -423,7 +423,8 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, const AP& aero, float (
             }
             acc[NB - 1] += bw * k[NB - 1]; ys[NB - 1] = yb[NB - 1] + aw * k[NB - 1];
         };
-        if (DEFER) {
+        if (DEFER || HAND::enabled) {   // (the team's kernels: straight-line stages -- the rolled loop selected the stage's actuator
+            // state through a scratch-memory pointer)
 #ifdef FWG_ABL_RK1
             stage(0);
 #else

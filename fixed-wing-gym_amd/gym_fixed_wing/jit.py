@@ -83,8 +83,31 @@ def specialised_library(env_config, auto_reset=True, store_derived=True, base_li
     if hipcc is None:
         warnings.warn("hipcc not found: using the generic kernel")
         return None
-    # per-process file names, published with os.replace: several ranks asking for the same key at once each compile their
-    # own copy of the (identical) include and never read a half-written one
+    # ONE build per key on a machine: the ranks of a multi-GPU job all ask for the same library at the same moment; the first
+    # takes the lock and compiles (one to two minutes of hipcc), the others wait for it and find the file
+    lock = None
+    try:
+        import fcntl
+        lock = open(os.path.join(cache, "libfwgym_{}.lock".format(key)), "w")
+        fcntl.flock(lock, fcntl.LOCK_EX)
+    except (ImportError, OSError):
+        lock = None
+    try:
+        if os.path.exists(out):
+            return out
+        return _compile(hipcc, cache, key, words, out)
+    finally:
+        if lock is not None:
+            try:
+                import fcntl
+                fcntl.flock(lock, fcntl.LOCK_UN)
+                lock.close()
+            except OSError:
+                pass
+
+
+def _compile(hipcc, cache, key, words, out):
+    # per-process file names, published with os.replace: a half-written file is never read
     inc = os.path.join(cache, "specs_{}.{}.inc".format(key, os.getpid()))
     # The configuration is frozen TWICE (specs 0 and 1, identical; the handle picks 0).  k_step2 sits at the register limit
     # (255 VGPRs, ~40 scalar registers spilled to vector lanes); compiled as the only instance of the translation unit the
@@ -103,9 +126,20 @@ def specialised_library(env_config, auto_reset=True, store_derived=True, base_li
         f.write("\n".join(lines) + "\n")
     tmp = out + ".tmp{}".format(os.getpid())
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize",
+           "-Rpass-analysis=kernel-resource-usage",
            "-I" + INCLUDE, "-I" + CSRC, '-DFWG_SPECS_FILE="{}"'.format(inc), "-o", tmp, os.path.join(CSRC, "fwgym.hip")]
     try:
-        subprocess.run(cmd, check=True, capture_output=True, text=True)
+        r = subprocess.run(cmd, check=True, capture_output=True, text=True)
+        # (the register report of the build: a specialised step kernel with a scratch frame or spilled vector registers is a
+        # slower kernel -- say so instead of letting a profile find out; tests/test_kernel_resources.py gates the presets)
+        try:
+            bad = [(k, v.get("ScratchSize [bytes/lane]"), v.get("VGPRs Spill")) for k, v in specialize.parse_resource_remarks(r.stderr).items()
+                   if ("k_step2<" in k or "k_rollout<" in k) and ", -1" not in k
+                   and (v.get("ScratchSize [bytes/lane]", 0) or v.get("VGPRs Spill", 0))]
+            if bad:
+                warnings.warn("run-time specialised kernels with a scratch frame / spilled registers: {}".format(bad[:4]), RuntimeWarning)
+        except Exception:
+            pass
         os.replace(tmp, out)
     except (subprocess.CalledProcessError, OSError) as e:
         warnings.warn("kernel specialisation failed ({}): using the generic kernel".format(getattr(e, "stderr", e)))

@@ -108,7 +108,10 @@ SPECIALISED = [
     # the c3 workload with randomised aircraft (bench.py side figure `randomised_aircraft`)
     ("c3_model16_lean_log", "cnn_model16", {"observation": {"step": 2}}, TURB_MODERATE),
 ]
-OBS_LOG_ROWS = 32
+# rows per parity of the observation row log: depth 36 - (5 - 1) = 32 for the 5-row matrix observations, so that the window's
+# position repeats every obs_step x 32 steps and captured chunks of 64 / 128 / 256 steps replay with the views handed out at
+# capture time still right (FixedWingVecEnv.set_graph_mode)
+OBS_LOG_ROWS = 36
 
 
 def workload(name):

@@ -170,7 +170,7 @@ class FusedRollout(object):
     the act that follows step t writes the rollout slice t+1 directly, so nothing is copied except the carried-over
     slice 0.  `graph=True` captures the whole rollout into one hipGraph (n_steps must be even).
 
-    `fused` (default: whenever fwg_rollout_available): act t and env step t run as ONE launch (fwg_rollout_step) -- a rollout is
+    `fused` (opt-in: fused=True, fused="auto" = wherever fwg_rollout_available, or FWGYM_ROLLOUT_FUSED=1): act t and env step t run as ONE launch (fwg_rollout_step) -- a rollout is
     then [env step 0] [act + step] x (n - 1) [act n]: n + 1 launches instead of 2 n, bit-identical buffers.  `tap(t, obs, rew,
     done)` (eager mode only) is called after every env step with the env's raw output tensors (tests, logging)."""
 
@@ -193,12 +193,17 @@ class FusedRollout(object):
         else:
             actor.set_obs_log(vec)
         can_fuse = self._attached and hasattr(actor, "rollout_available") and actor.rollout_available(vec)
+        if fused == "auto":   # the one-launch step wherever it is available
+            fused = bool(can_fuse)
         if fused and not can_fuse:
             raise ValueError("FusedRollout(fused=True): fwg_rollout_step is not available for this env / head (needs a specialised "
                              "kernel, the dense observation batch and an attached head)")
-        # (FWGYM_ROLLOUT_FUSED=0: A/B measurements of the two-launch step against the one-launch step)
+        # OPT-IN (fused=True, or FWGYM_ROLLOUT_FUSED=1 for fused=None): tests/test_rollout.py::test_fused_launch_equals_two_launches_on_gpu
+        # failed twice in ~25 runs of the whole GPU suite in round 4 and the cause was never found (2 000+ clean iterations since,
+        # in isolation and in suite context: profiles/r05_soak.txt) -- until it is, the path whose every launch boundary is a
+        # kernel boundary stays the default and the one-launch step is something a caller asks for (bench.py does, and says so)
         import os
-        self.fused = (can_fuse and os.environ.get("FWGYM_ROLLOUT_FUSED", "1") != "0") if fused is None else bool(fused)
+        self.fused = (can_fuse and os.environ.get("FWGYM_ROLLOUT_FUSED", "0") == "1") if fused is None else bool(fused)
         self.tap = tap
         if graph:
             self._capture()

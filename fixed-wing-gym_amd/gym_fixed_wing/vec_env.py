@@ -251,22 +251,43 @@ class FixedWingVecEnv(object):
             FixedWingVecEnv._preset_cache = cache
         return cache
 
-    def set_graph_mode(self, enable=True):
+    def set_graph_mode(self, enable=True, obs="view"):
         """Keeps the global step counter on the device so that a captured sequence of step launches (hipGraph /
-        torch.cuda.CUDAGraph) can be replayed; see fwg_set_graph_mode in include/fwgym.h for the rules."""
+        torch.cuda.CUDAGraph) can be replayed; see fwg_set_graph_mode in include/fwgym.h for the rules.
+
+        Row-log envs, `obs`: what step()/step_device() hand out while the mode is on.
+        "view" (default): the zero-copy window of the log, as without graphs.  The window's position is a function of the global
+        step with period `obs_window_period` (obs_step x log depth: 64 steps for the default log of a 5 x 12 observation at
+        step 2), so the views handed out during a CAPTURE stay right under replay exactly when every replay starts a whole
+        number of periods after the capture did -- capture chunks whose length is a multiple of the period (the default log
+        depth is chosen so that 64, 128, 256 are); replay_check() raises otherwise.
+        "gather": a dense copy gathered on the device after every step (fwg_obs_gather reads the position on the device:
+        any chunk length; one more launch and ~700 B/env-step more traffic per step)."""
+        if obs not in ("view", "gather"):
+            raise ValueError("obs must be 'view' or 'gather'")
         nat.check(self._lib, self._lib.fwg_set_graph_mode(self._handle, int(bool(enable)), self._mem.stream()))
         self._graph_mode = bool(enable)
-        self._gather_warned = False
+        self._graph_obs = obs
+        self._capturing, self._cap_views, self._cap_gstep = False, False, 0
         self._refresh_obs_view()
+
+    @property
+    def obs_window_period(self):
+        """Row-log envs: the number of steps after which the observation window returns to the same planes of the log."""
+        if not self.obs_log_rows:
+            return 0
+        return int(self._c.obs_step) * (self.obs_log_rows - (int(self._c.obs_length) - 1))
 
     def capture_begin(self):
         """Brackets the step calls issued under stream capture.  Returns the step parity of the capture: the graph may only
         be replayed at that parity (replay_check)."""
         nat.check(self._lib, self._lib.fwg_capture_begin(self._handle))
+        self._capturing, self._cap_views, self._cap_gstep = True, False, self.global_step
         return int(self._lib.fwg_capture_parity(self._handle))
 
     def capture_end(self):
         nat.check(self._lib, self._lib.fwg_capture_end(self._handle))
+        self._capturing = False
 
     @property
     def global_step(self):
@@ -275,10 +296,18 @@ class FixedWingVecEnv(object):
     def replay_check(self, capture_parity):
         """Raises unless a graph captured at `capture_parity` (capture_begin's return value) may be replayed now."""
         nat.check(self._lib, self._lib.fwg_replay_check(self._handle, int(capture_parity)))
+        if self.obs_log_rows and getattr(self, "_cap_views", False):
+            off = (self.global_step - self._cap_gstep) % self.obs_window_period
+            if off != 0:
+                raise RuntimeError("the captured steps handed out zero-copy observation windows of the row log: a replay must start a "
+                                   "whole number of window periods ({} steps) after the capture did, this one starts {} steps past one.  "
+                                   "Capture chunks that are a multiple of the period, or use set_graph_mode(True, obs='gather') / "
+                                   "obs_layout='dense'".format(self.obs_window_period, off))
 
     def note_replayed_steps(self, n_steps):
         nat.check(self._lib, self._lib.fwg_note_replayed_steps(self._handle, int(n_steps)))
-        self._refresh_obs_view(want_obs=False)   # row-log mode, direct calls: the window moved with the replayed steps
+        # row-log mode: the window moved with the replayed steps (view mode: recomputed from the host's count of them)
+        self._refresh_obs_view(want_obs=getattr(self, "_graph_obs", "view") == "view")
 
     @property
     def spec_index(self):
@@ -363,16 +392,14 @@ class FixedWingVecEnv(object):
         stale under replay, so the observation handed out is the dense copy gathered on the device instead."""
         if not self.obs_log_rows:
             return
-        if self._graph_mode:
+        if self._graph_mode and getattr(self, "_graph_obs", "view") == "gather":
             if want_obs:
-                if not getattr(self, "_gather_warned", True):
-                    self._gather_warned = True
-                    warnings.warn("graph mode on a row-log env: every step that hands out observations gathers a dense copy "
-                                  "(fwg_obs_gather).  A consumer that takes the batch on every step is served cheaper by "
-                                  "FixedWingVecEnv(..., obs_layout='dense'); step_device(..., want_obs=False) skips the copy; "
-                                  "the HIP rollout head (DeviceActor) reads the log in place.", RuntimeWarning, stacklevel=3)
                 self._obs = self.obs_dense()
             return
+        if self._graph_mode and not want_obs:
+            return
+        if self._graph_mode and getattr(self, "_capturing", False):
+            self._cap_views = True   # (replay_check: the replays must keep the capture's phase of the window period)
         plane = ctypes.c_int64()
         nat.check(self._lib, self._lib.fwg_obs_window(self._handle, ctypes.byref(plane)))
         win = self._obs_buf[plane.value:plane.value + self._c.obs_length]

@@ -439,7 +439,10 @@ int fwg_actor_act(fwg_actor* a, const float* obs, const float* reward, const uin
  *     fwg_actor_act(head, obs_io, reward_io, done_io, norm_obs_out, action_out, value_out, logp_out, norm_reward_out,
  *                   done_prev_out, deterministic, stream);
  *     fwg_step(env, action_out, obs_io, reward_io, done_io, term_code_out, terminal_obs_out, metrics_out, NULL, stream);
- * bit for bit.  obs_io / reward_io / done_io are IN-OUT: on entry what the env's previous step (or fwg_reset, with
+ * -- the same arithmetic in the same order: the two paths agree bit for bit in every run of tests/test_rollout.py and of the soak
+ * loops (tests/soak_rollout.py, tests/soak_suite_context.py: profiles/r05_soak.txt), with ONE unexplained exception on record: two
+ * runs of the whole GPU suite in round 4 saw a difference that never reproduced.  gym_fixed_wing.rollout.FusedRollout therefore
+ * uses this call only when asked to (fused=True / "auto").  obs_io / reward_io / done_io are IN-OUT: on entry what the env's previous step (or fwg_reset, with
  * reward_io / done_io zeroed) left there, on return this step's results; the four head outputs describe the observation on
  * entry, norm_reward_out / done_prev_out the transition that led to it (each may be NULL).  Needs `head` attached to `env`
  * (fwg_attach_observer: the step phase leaves the batch moments for the NEXT head) and a configuration

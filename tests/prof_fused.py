@@ -12,6 +12,6 @@ vec = FixedWingVecEnv(cfg, num_envs=n, device=0, derived_views=False)
 vec.reset()
 actor = DeviceActor.for_env(vec, seed=1)
 actor.load_policy(MlpPolicy(12))
-ro = FusedRollout(vec, actor, 128, graph=False)
+ro = FusedRollout(vec, actor, 128, graph=False, fused="auto")
 for _ in range(3): ro.run()
 torch.cuda.synchronize()

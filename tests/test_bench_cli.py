@@ -80,3 +80,18 @@ def test_cpu_baseline_is_sized_by_the_container_quota(monkeypatch):
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)), raising=False)
     fake["cpu.max"] = "1600000 100000\n"
     assert bench._usable_cpus(256)[0] == 8        # the affinity mask is the tighter bound
+
+
+def test_multi_gpu_default_is_the_north_star_point():
+    """bench.py --gpus N (N > 1) with no size given measures BASELINE.json's north-star point -- 65 536 envs in total, sharded --
+    so that the driver's 1/2/4/8-GPU lines form the strong-scaling curve the baseline asks for; sizes given on the command line,
+    other workloads and the one-GPU run keep per-GPU sizing."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.default_total_envs(8, "c3", 0, 0, False) == 65536
+    assert bench.default_total_envs(2, "c3", 0, 0, False) == 65536
+    assert bench.default_total_envs(1, "c3", 0, 0, False) == 0
+    assert bench.default_total_envs(8, "c4", 0, 0, False) == 0
+    assert bench.default_total_envs(8, "c3", 32768, 0, False) == 0
+    assert bench.default_total_envs(8, "c3", 0, 131072, False) == 0
+    assert bench.default_total_envs(2, "c3", 0, 0, True) == 0

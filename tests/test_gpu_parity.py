@@ -240,20 +240,42 @@ def test_runtime_specialisation_matches_generic_kernel():
     print("generic {:.1f} us/step, run-time specialised {:.1f} us/step at {} envs".format(rates[0], rates[1], n))
 
 
-def _one_step_errors(vec, spec, raw, turb):
+# Pure relative error, asserted where it means something: 1e-5 on every state whose magnitude is at least a QUARTER of its natural
+# scale (parity.STATE_SCALE), 2e-5 from a tenth of it on (measured, MI355X, G5 states, all kernels: 6.8e-6 / 1.8e-5 / 4e-6 at half
+# the scale / 1.6e-6 at the scale itself).  Below that the scaled bound governs: a body rate of 0.1 rad/s in a manoeuvre of 10 rad/s
+# carries the absolute rounding error of the terms it is the difference of.
+REL_FLOOR = 0.25
+REL_BAR = 1e-5
+REL_FLOOR_LOOSE, REL_BAR_LOOSE = 0.1, 2e-5
+REL_FLOORS = (0.1, 0.25, 0.5, 1.0)   # (printed: the worst pure-relative error by how large a state has to be to count)
+
+
+def _one_step_errors(vec, spec, raw, turb, step=None):
     """One env step on the device vs the oracle from the identical (device) state.  Returns (scaled error [N,18], pure
-    relative error [N,18] where |want| > 1e-3 else nan, oracle ok mask, failure codes, device done flags)."""
+    relative error [N,18] where |want| > REL_FLOOR * scale else nan, oracle ok mask, failure codes, device done flags).
+    `step()` (optional) performs the step itself and returns (raw actions used [N,3], done flags, termination names or None)."""
     n = vec.num_envs
     y0, wind, dry = parity.physics_state(vec)
     gust = parity.device_gust(vec, spec, dry)
+    if step is None:
+        _, _, done, infos = vec.step(raw)
+    else:
+        raw, done, infos = step()
     cmd = parity.scaled_actions(vec, raw)
     want, ok, fail, _, _ = ph.sim_step(spec, y0, cmd, wind, gust)
-    _, _, done, infos = vec.step(raw)
     y1, _, _ = parity.physics_state(vec)
     err = np.abs(y1 - want) / np.maximum(np.abs(want), parity.STATE_SCALE)
     with np.errstate(divide="ignore", invalid="ignore"):
-        rel = np.where(np.abs(want) > 1e-3, np.abs(y1 - want) / np.abs(want), np.nan)
+        rel = np.where(np.abs(want) > REL_FLOOR * parity.STATE_SCALE, np.abs(y1 - want) / np.abs(want), np.nan)
+        live = ok & ~np.asarray(done).astype(bool)
+        for f in REL_FLOORS:
+            m = (np.abs(want) > f * parity.STATE_SCALE) & live[:, None]
+            if m.any():
+                REL_SEEN[f] = max(REL_SEEN.get(f, 0.0), float((np.abs(y1 - want)[m] / np.abs(want)[m]).max()))
     return err, rel, ok, fail, np.asarray(done).astype(bool), infos, y0
+
+
+REL_SEEN = {}
 
 
 G5_N = 4096
@@ -283,12 +305,48 @@ def _g5_states(rng, n):
     return {k: v.astype(np.float32) for k, v in st.items()}
 
 
+def _g5_run(vec, spec, rng, label, steps=30, step_factory=None):
+    """30 consecutive steps from the G5 states with commands jumping by up to the full travel every step: the scaled 1e-5 bar on
+    every state, the PURE relative 1e-5 bar on every state of at least a tenth of its natural scale, identical constraint trips
+    (same lanes, same variable names)."""
+    n = vec.num_envs
+    alive = np.ones(n, dtype=bool)
+    worst, worst_rel, trips, rate_limited, stalled = 0.0, 0.0, {}, 0, 0
+    for t in range(steps):
+        raw = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
+        err, rel, ok, fail, done, infos, y0 = _one_step_errors(vec, spec, raw, None, None if step_factory is None else step_factory(raw))
+        a = alive
+        assert np.array_equal(done[a], ~ok[a]), "constraint trips differ at step {}".format(t)
+        for i in np.nonzero(a & ~ok)[0][:64]:
+            name = ph.VARS[int(fail[i])] if fail[i] < ph.N_VARS else "nan"
+            got = infos[int(i)]["termination"] if not isinstance(infos, np.ndarray) else infos[int(i)]
+            assert got == name, (t, i, got, name)
+            trips[name] = trips.get(name, 0) + 1
+        live = a & ok
+        worst = max(worst, float(err[live].max()))
+        assert err[live].max() <= 1e-5, (t, np.unravel_index(np.argmax(np.where(live[:, None], err, 0)), err.shape), err[live].max())
+        if np.isfinite(rel[live]).any():
+            wr = float(np.nanmax(rel[live]))
+            worst_rel = max(worst_rel, wr)
+            assert wr <= REL_BAR, (t, np.unravel_index(np.nanargmax(np.where(live[:, None], rel, np.nan)), rel.shape), wr)
+        assert REL_SEEN.get(REL_FLOOR_LOOSE, 0.0) <= REL_BAR_LOOSE, (t, REL_SEEN)
+        rate_limited += int((np.abs(np.abs(y0[live][:, 16:18]) - spec.act["elevon_right"]["dot_max"]) < 1e-6).sum())
+        ua, wa = y0[live][:, 10], y0[live][:, 12]
+        stalled += int((np.abs(np.arctan2(wa, ua)) > 0.2).sum())
+        alive = alive & ok          # auto_reset is off: finished envs are outside the contract
+    print("{}: worst scaled {:.2e}, worst pure-relative (|x| > {} x scale) {:.2e}; constraint trips {}; "
+          "rate-limited elevon samples {}, stalled samples {}; pure-relative by floor so far {}".format(
+              label, worst, REL_FLOOR, worst_rel, trips, rate_limited, stalled, {k: "{:.1e}".format(v) for k, v in sorted(REL_SEEN.items())}))
+    return trips, rate_limited, stalled
+
+
 @pytest.mark.parametrize("substeps", [1, 2, 4])
 @pytest.mark.parametrize("turb", [False, True], ids=["calm", "dryden"])
 def test_single_step_parity_on_g5_states(turb, substeps):
     """The 1e-5 bar on targeted states (stall, near-zero / near-limit airspeed, constraint trips, saturated and
     rate-limited actuators, pitch near +-90 deg), 30 consecutive steps each so that the elevons run into their rate limit
-    (commands jump by up to the full travel every step), for RK4 sub-step counts 1, 2 and 4."""
+    (commands jump by up to the full travel every step), for RK4 sub-step counts 1, 2 and 4.  (Generic kernel: the
+    configuration is not a preset and the suite runs with FWGYM_JIT=0; the specialised kernels follow below.)"""
     cfg = configs.reference_like("cnn")
     skw = {"integrator": {"method": "rk4", "substeps": substeps, "actuator_microsteps": 16}}
     if turb:
@@ -299,28 +357,91 @@ def test_single_step_parity_on_g5_states(turb, substeps):
     assert spec.nsub == substeps
     rng = np.random.default_rng(100 + substeps)
     vec.reset(states=_g5_states(rng, n))
-    alive = np.ones(n, dtype=bool)
-    worst, worst_rel, trips, rate_limited, stalled = 0.0, 0.0, {}, 0, 0
-    for t in range(30):
-        raw = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
-        err, rel, ok, fail, done, infos, y0 = _one_step_errors(vec, spec, raw, turb)
-        a = alive
-        assert np.array_equal(done[a], ~ok[a]), "constraint trips differ at step {}".format(t)
-        for i in np.nonzero(a & ~ok)[0][:64]:
-            name = ph.VARS[int(fail[i])] if fail[i] < ph.N_VARS else "nan"
-            assert infos[int(i)]["termination"] == name, (t, i, infos[int(i)]["termination"], name)
-            trips[name] = trips.get(name, 0) + 1
-        live = a & ok
-        worst = max(worst, float(err[live].max()))
-        worst_rel = max(worst_rel, float(np.nanmax(rel[live])))
-        assert err[live].max() <= 1e-5, (t, np.unravel_index(np.argmax(np.where(live[:, None], err, 0)), err.shape), err[live].max())
-        rate_limited += int((np.abs(np.abs(y0[live][:, 16:18]) - spec.act["elevon_right"]["dot_max"]) < 1e-6).sum())
-        ua, wa = y0[live][:, 10], y0[live][:, 12]
-        stalled += int((np.abs(np.arctan2(wa, ua)) > 0.2).sum())
-        alive = alive & ok          # auto_reset is off: finished envs are outside the contract
-    print("substeps={} turb={}: worst scaled {:.2e}, worst pure-relative (|x| > 1e-3) {:.2e}; constraint trips {}; "
-          "rate-limited elevon samples {}, stalled samples {}".format(substeps, turb, worst, worst_rel, trips, rate_limited, stalled))
+    trips, rate_limited, stalled = _g5_run(vec, spec, rng, "generic substeps={} turb={}".format(substeps, turb))
     assert len(trips) >= 1 and sum(trips.values()) >= 10 and rate_limited > 1000 and stalled > 1000
+    vec.close()
+
+
+G5_TEAM_CKW = {"steps_max": 1000, "observation": {"step": 2}}
+G5_TEAM_SKW = {"turbulence": True, "turbulence_intensity": "severe"}
+
+
+def g5_team_jobs():
+    """(config, config_kw, sim_config_kw, derived_views, obs_log_rows, auto_reset) of the run-time specialised kernels the two
+    tests below ask for -- __graft_entry__.build() compiles them ahead of time (gym_fixed_wing/jit.py cache)."""
+    jobs = []
+    for turb in (False, True):
+        for rows in (None, 0):
+            jobs.append((configs.reference_like("cnn"), dict(G5_TEAM_CKW), dict(G5_TEAM_SKW) if turb else None, True, rows, False))
+    jobs.append((configs.reference_like("cnn"), dict(G5_TEAM_CKW), dict(G5_TEAM_SKW), False, 0, True))   # the k_rollout test
+    return jobs
+
+
+@pytest.mark.parametrize("layout", ["row_log", "dense"])
+@pytest.mark.parametrize("turb", [False, True], ids=["calm", "dryden"])
+def test_single_step_parity_on_g5_states_two_wave_kernel(turb, layout):
+    """The same states through the kernels that are benched: the two-wave team (k_step2: physics wave || gym wave, actuators and
+    Euler angles on the gym wave, deferred constraint checks) of a run-time specialised build, row log and dense batch."""
+    import copy
+    from gym_fixed_wing import jit
+    cfg = configs.reference_like("cnn")
+    skw = copy.deepcopy(G5_TEAM_SKW) if turb else None
+    rows = None if layout == "row_log" else 0
+    if jit.prebuild(copy.deepcopy(cfg), copy.deepcopy(G5_TEAM_CKW), copy.deepcopy(skw), True, rows, auto_reset=False) is None:
+        pytest.skip("hipcc not available for the run-time specialisation")
+    n = G5_N
+    vec = _vec(cfg, n, sim_config_kw=skw, seed=5, as_numpy=True, auto_reset=False, config_kw=copy.deepcopy(G5_TEAM_CKW),
+               specialize=True, obs_log_rows=rows)
+    assert vec.spec_index >= 0 and bool(vec.obs_log_rows) == (layout == "row_log")
+    spec = parity.oracle_spec_from_env_config(vec.env_config)
+    rng = np.random.default_rng(300 + int(turb))
+    vec.reset(states=_g5_states(rng, n))
+    trips, rate_limited, stalled = _g5_run(vec, spec, rng, "two-wave {} turb={}".format(layout, turb))
+    assert len(trips) >= 1 and sum(trips.values()) >= 10 and rate_limited > 1000 and stalled > 1000
+    vec.close()
+
+
+def test_single_step_parity_on_g5_states_rollout_launch():
+    """... and through the step phase of the ONE-launch rollout step (k_rollout: head, then the team's env step in the same
+    launch, actions handed over in LDS): a random-init policy with a wide action distribution flies the G5 states; every step
+    is compared with the oracle under the actions the head sampled."""
+    import copy
+    import torch
+    from gym_fixed_wing import jit, _native as nat
+    from gym_fixed_wing.actor import DeviceActor
+    from gym_fixed_wing.rollout import MlpPolicy
+    cfg = configs.reference_like("cnn")
+    if jit.prebuild(copy.deepcopy(cfg), copy.deepcopy(G5_TEAM_CKW), copy.deepcopy(G5_TEAM_SKW), False, 0, auto_reset=True) is None:
+        pytest.skip("hipcc not available for the run-time specialisation")
+    n = G5_N
+    vec = _vec(cfg, n, sim_config_kw=copy.deepcopy(G5_TEAM_SKW), seed=5, config_kw=copy.deepcopy(G5_TEAM_CKW), specialize=True,
+               obs_layout="dense", derived_views=False)
+    assert vec.spec_index >= 0
+    spec = parity.oracle_spec_from_env_config(vec.env_config)
+    rng = np.random.default_rng(77)
+    vec.reset(states=_g5_states(rng, n))
+    torch.manual_seed(3)
+    policy = MlpPolicy(vec.obs_dim)
+    with torch.no_grad():
+        policy.log_std.copy_(torch.tensor([0.0, 0.0, 0.0]))   # sigma 1: commands jump by the full travel
+    actor = DeviceActor.for_env(vec, seed=11)
+    actor.load_policy(policy)
+    actor.attach(vec)
+    assert actor.rollout_available(vec)
+    action = torch.zeros((n, 3), device="cuda")
+
+    def factory(_raw):
+        def step():
+            _, _, d = actor.rollout_step(vec, action=action)
+            torch.cuda.synchronize()
+            names = np.array([nat.term_name(int(c)) for c in vec._term.cpu().numpy()], dtype=object)
+            return action.cpu().numpy().astype(np.float32), d.cpu().numpy(), names
+        return step
+    # (auto-reset is on -- the fused launch exists for rollouts --: a lane that trips is re-initialised, so only the lanes alive at
+    # the start of a step are compared, and the state after a trip is the new episode's, which _g5_run leaves alone)
+    trips, rate_limited, stalled = _g5_run(vec, spec, rng, "one-launch rollout step", steps=12, step_factory=factory)
+    assert sum(trips.values()) >= 5 and stalled > 500
+    actor.close()
     vec.close()
 
 
@@ -341,6 +462,7 @@ def test_hundred_step_rollout_state_parity():
         live = alive & ok
         worst, worst_rel = max(worst, float(err[live].max())), max(worst_rel, float(np.nanmax(rel[live])))
         assert err[live].max() <= 1e-5, (t, err[live].max())
+        assert float(np.nanmax(rel[live])) <= REL_BAR, (t, float(np.nanmax(rel[live])))   # pure relative, |x| >= 0.25 x scale
         alive = live
     print("100-step rollout: worst scaled error {:.2e}, worst pure-relative {:.2e}, {} of {} envs alive".format(worst, worst_rel, int(alive.sum()), n))
     assert alive.sum() > n // 2

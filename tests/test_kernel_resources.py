@@ -1,0 +1,45 @@
+"""Gate on the register budget of the specialised kernels: no preset instance of the two-wave step kernel (k_step2) or of the
+one-launch rollout step (k_rollout) may use scratch memory or spill vector registers.  A scratch_load counts on vmcnt like any
+other load, so every wait after it sits through the acknowledgement of the stores issued before; round 4's
+benched kernel had quietly grown a 20-byte frame.
+
+The figures come from the product build itself: the Makefile compiles libfwgym.so with -Rpass-analysis=kernel-resource-usage and
+__graft_entry__.build() writes gym_fixed_wing/kernel_resources.json (committed, tagged with the hash of the kernel sources it was
+built from -- a report of other sources fails the test instead of passing it)."""
+import json
+import os
+import re
+
+import pytest
+
+from gym_fixed_wing import presets, specialize
+
+
+def _report():
+    if not os.path.exists(specialize.RESOURCES_JSON):
+        pytest.fail("gym_fixed_wing/kernel_resources.json is missing: run __graft_entry__.build()")
+    with open(specialize.RESOURCES_JSON) as f:
+        return json.load(f)
+
+
+def test_report_belongs_to_these_sources():
+    rep = _report()
+    assert rep["source_hash"] == specialize.kernel_source_hash(), \
+        "kernel_resources.json was written for other kernel sources: run __graft_entry__.build() and commit the file"
+    assert rep["presets"] == [e[0] for e in presets.SPECIALISED]
+
+
+def test_no_preset_step_kernel_spills_or_uses_scratch():
+    rep = _report()
+    seen = 0
+    bad = []
+    for name, r in rep["kernels"].items():
+        m = re.match(r"void (k_step2|k_rollout)<(true|false), (-?\d+)", name)
+        if not m or int(m.group(3)) < 0:
+            continue
+        seen += 1
+        if r.get("ScratchSize [bytes/lane]", 0) != 0 or r.get("VGPRs Spill", 0) != 0:
+            bad.append((name, r.get("VGPRs"), r.get("ScratchSize [bytes/lane]"), r.get("VGPRs Spill")))
+        assert r.get("VGPRs", 0) + r.get("AGPRs", 0) <= 256, name   # two waves per SIMD
+    assert seen >= len(presets.SPECIALISED), "the report holds no specialised kernels"
+    assert not bad, "kernels with a scratch frame / spilled vector registers: {}".format(bad)

@@ -160,6 +160,94 @@ def test_log_window_under_graph_replay_on_gpu():
         assert torch.equal(od.reshape(512, 5, 12), log.obs_dense().reshape(512, 5, 12)), "replay {}".format(rep)
 
 
+@pytest.mark.gpu
+def test_zero_copy_windows_stay_right_under_graph_replay_on_gpu():
+    """View mode (the default): the windows handed out while a chunk is CAPTURED are host-side views; they stay right under
+    replay because the chunk (64 steps) is a whole number of window periods (obs_step x depth = 2 x 32 for the default log).
+    A consumer inside the graph copies every step's window into a buffer; seven replays (448 steps, through steps_max = 50 nine
+    times) against the dense layout stepped directly."""
+    import torch
+    from gym_fixed_wing import presets
+    cfg = configs.reference_like("cnn")
+    kw = dict(config_kw={"observation": {"step": 2}, "steps_max": 50}, sim_config_kw=copy.deepcopy(TURB), seed=9)
+    dense = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=512, device=0, obs_log_rows=0, **copy.deepcopy(kw))
+    log = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=512, device=0, **copy.deepcopy(kw))
+    assert log.obs_log_rows == presets.OBS_LOG_ROWS and log.obs_window_period == 64
+    dense.reset(), log.reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    K = 64
+    acts = [torch.rand((512, 3), device="cuda", generator=gen) * 2 - 1 for _ in range(K)]
+    log.set_graph_mode(True)   # obs="view"
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for a in acts[:2]:
+            log.step_device(a)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    for a in acts[:2]:
+        dense.step_device(a)
+    seen = torch.zeros((K, 512, 5, 12), device="cuda")
+    g = torch.cuda.CUDAGraph()
+    parity = log.capture_begin()
+    with torch.cuda.graph(g):
+        for t, a in enumerate(acts):
+            o, _, _ = log.step_device(a)
+            seen[t].copy_(o)          # the consumer: reads the zero-copy window of step t
+    log.capture_end()
+    for rep in range(7):
+        log.replay_check(parity)
+        g.replay(); log.note_replayed_steps(K); torch.cuda.synchronize()
+        for t, a in enumerate(acts):
+            od, _, _ = dense.step_device(a)
+            assert torch.equal(od.reshape(512, 5, 12), seen[t]), "replay {} step {}".format(rep, t)
+        assert torch.equal(od.reshape(512, 5, 12), log._obs.reshape(512, 5, 12))   # the host view after the replay
+    # two direct steps move the phase: the captured views would be stale, and the check says so
+    log.step_device(acts[0]), log.step_device(acts[1])
+    with pytest.raises(RuntimeError, match="window periods"):
+        log.replay_check(parity)
+    dense.close(), log.close()
+
+
+def test_replay_check_guards_the_phase_of_captured_windows_emulated():
+    """The same guard on the host emulation (captured calls execute at once there): a chunk that is not a multiple of the
+    window period may be captured, but not replayed once its views were handed out; gather mode has no such limit."""
+    cfg = configs.reference_like("cnn")
+    vec = _emu_env(cfg, 5, 10, config_kw={"observation": {"step": 2}, "steps_max": 30}, sim_config_kw=copy.deepcopy(TURB))
+    assert vec.obs_window_period == 2 * (10 - 4)
+    vec.reset()
+    a = np.zeros((5, 3), dtype=np.float32)
+    for mode, ok in (("view", False), ("gather", True)):
+        vec.set_graph_mode(True, obs=mode)
+        parity = vec.capture_begin()
+        for _ in range(4):
+            vec.step_device(a)
+        vec.capture_end()
+        vec.replay_check(parity)            # the first replay starts where the capture did
+        vec.note_replayed_steps(4)          # (the emulation executed the captured calls)
+        if ok:
+            vec.replay_check(parity)
+        else:
+            with pytest.raises(RuntimeError, match="window periods"):
+                vec.replay_check(parity)    # 4 steps later: not a whole number of 12-step periods
+        vec.set_graph_mode(False)
+    # a chunk of one period replays for ever, and want_obs=False never pins the phase
+    vec.set_graph_mode(True)
+    parity = vec.capture_begin()
+    for _ in range(12):
+        vec.step_device(a)
+    vec.capture_end()
+    for _ in range(3):
+        vec.replay_check(parity)
+        vec.note_replayed_steps(12)
+    parity = vec.capture_begin()
+    for _ in range(4):
+        vec.step_device(a, want_obs=False)
+    vec.capture_end()
+    for _ in range(3):
+        vec.replay_check(parity)
+        vec.note_replayed_steps(4)
+    vec.close()
+
+
 def test_row_log_env_accepts_curriculum_and_simulator_updates_emulated():
     """set_curriculum_level / set_simulator_attr re-upload the configuration: the row-log layout must survive that
     (the re-compile has to carry obs_log_rows, otherwise fwg_update_config sees another state layout)."""

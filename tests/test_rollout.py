@@ -1,4 +1,6 @@
 """PPO-style rollout collection (BASELINE.json configs[4]): device-resident normalisation + MLP policy + env step."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -414,6 +416,16 @@ def test_fused_launch_equals_two_launches_on_gpu():
                 except AssertionError as again:
                     notes.append(str(again))
             raise AssertionError(str(first) + "\n" + "\n".join(notes))
+
+
+@pytest.mark.gpu
+def test_fused_launch_equals_two_launches_in_suite_context_on_gpu():
+    """A short run of tests/soak_suite_context.py inside the suite: between the two paths of every iteration the device runs
+    what the suite runs around this file (another configuration's step kernel with an attached head, the head on a row-log env,
+    graph replays, allocator churn).  The long runs are recorded in profiles/r05_soak.txt."""
+    import soak_suite_context as soak
+    it, bad = soak.main(45.0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "soak"), quiet=True)
+    assert it >= 3 and bad == 0, (it, bad)
 
 
 @pytest.mark.gpu

@@ -23,7 +23,7 @@ for name, path in libs.items():
     vec.reset()
     actor = DeviceActor.for_env(vec, seed=1)
     actor.load_policy(MlpPolicy(12))
-    ro = FusedRollout(vec, actor, 128, graph=True)
+    ro = FusedRollout(vec, actor, 128, graph=True, fused="auto")
     ro.run(); torch.cuda.synchronize()
     best = 1e9
     for _ in range(5):
