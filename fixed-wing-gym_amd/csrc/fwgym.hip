@@ -265,17 +265,20 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 
     // ---- phase A: issue every load up front.  The action windows stream HBM -> LDS (global_load_lds, no VGPRs, they
     // are addressed by the run-time ring slot); everything else goes to registers.
-    float raw[3];
+    // k_step2 with the actuators on the gym wave: that wave requests NOTHING at kernel entry -- the physics wave's rows, which
+    // the step's length hangs on, have the CU's vector-memory path (64 B per clock, requests served in order: the 4 workgroups'
+    // 36 KiB of simulator rows take ~600 clocks by themselves) to themselves, and the raw action and the actuator states the gym
+    // wave needs first come over from the physics wave through LDS as soon as they have landed there
+    constexpr bool gym_waits = SPLIT && GYM && ext_act;
+    float raw[3] = {0.f, 0.f, 0.f};
+    if (!gym_waits) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) raw[i] = HS::enabled ? act_lds[lane * 4 + i] : A.actions[e * 3 + i];   // [N][3]: a wave reads 768 contiguous bytes
+        for (int i = 0; i < 3; ++i) raw[i] = HS::enabled ? act_lds[lane * 4 + i] : A.actions[e * 3 + i];   // [N][3]: a wave reads 768 contiguous bytes
+    }
     Env E;
     float4 act_q3 = make_float4(0.f, 0.f, 0.f, 0.f), act_q4 = act_q3;
-    if (SPLIT && GYM && ext_act) {   // y[12..15] | y[16], y[17], ...: the actuator part of the simulator rows (needed first)
-        act_q3 = load_group(A.S, A.N, (L.sim >> 2) + 3, e);
-        act_q4 = load_group(A.S, A.N, (L.sim >> 2) + 4, e);
-    }
     if (PHYS) load_sim<TURB>(c, A.S, A.N, e, E);
-    load_cold(c, A.S, A.N, e, E);
+    if (!gym_waits) load_cold(c, A.S, A.N, e, E);
     // per-lane force / moment constants (simulator.model; the generic kernel keeps ONE code path): requested with the
     // simulator rows, so that the first right-hand side does not start by waiting for 13 more round trips
     Aero la;
@@ -305,6 +308,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             fwg_msg_put(hand + 16, 0.f, 0.f, 0.f, 0u);
             fwg_msg_put(hand + 20, 0.f, 0.f, 0.f, 0u);
             fwg_msg_put(hand + 24, 0.f, 0.f, 0.f, 0u);
+            fwg_msg_put(hand + 8, 0.f, 0.f, 0.f, 0u);
             if (lane == 0) FWG_FLAG_RAISE(mark, 0);
         } else {
             fwg_msg_put(acts, 0.f, 0.f, 0.f, 0u);
@@ -314,6 +318,21 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #ifndef FWG_ABL_NO_ENTRY_BARRIER   /* (measurement only: what the entry barrier costs; without it stale tags are possible) */
         FWG_BLOCK_SYNC_LDS();
 #endif
+    }
+    if (SPLIT) FWG_SETPRIO(PHYS ? FWG_PRIO_PHYS_STAGES : FWG_PRIO_GYM_EARLY);
+    if (SPLIT && ext_act) {
+        if (PHYS) {   // (the first thing this wave does with its rows)
+            float4* h4 = reinterpret_cast<float4*>(hand);
+            h4[0] = make_float4(E.y[13], E.y[14], E.y[15], E.y[16]);
+            h4[1] = make_float4(E.y[17], raw[0], raw[1], raw[2]);
+            fwg_msg_put(hand + 8, 0.f, 0.f, 0.f, FWG_TAG_RAW);
+        } else {
+            fwg_msg_take(hand + 8, FWG_TAG_RAW);
+            const float4 q0 = reinterpret_cast<const float4*>(hand)[0], q1 = reinterpret_cast<const float4*>(hand)[1];
+            act_q3 = make_float4(0.f, q0.x, q0.y, q0.z); act_q4 = make_float4(q0.w, q1.x, 0.f, 0.f);
+            raw[0] = q1.y; raw[1] = q1.z; raw[2] = q1.w;
+            load_cold(c, A.S, A.N, e, E);
+        }
     }
     float ret_prev = 0.f;
     // The raw-action window (and the constrained-command window where observations use it) BY AGE: wa[k] = the action taken k
@@ -341,9 +360,6 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     };
     if (GYM) {
         // (k_step2: behind the arrival of the actuator groups -- the partner's rows, requested at the same moment, are served first)
-#ifndef FWG_ABL_NO_LOAD_PIN
-        if (SPLIT && ext_act) { fwg_pin_mem(act_q4.x); fwg_pin_mem(raw[2]); }
-#endif
         // second wave of requests: bookkeeping rows to registers, action windows and lagged observation rows HBM -> LDS;
         // issued only now so that the wait for the simulator state above does not have to drain them (vmcnt is in-order)
         // order = order of need (returns are in order): bookkeeping rows, action windows, lagged observation rows
@@ -426,6 +442,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             _Pragma("unroll") for (int m = 0; m < c.act_per_half; ++m) advance_actuators(c, a_, sp);
             *reinterpret_cast<float4*>(acts + 4) = make_float4(a_[0], a_[1], a_[2], a_[3]);
             fwg_msg_put(acts + 8, a_[4], 0.f, 0.f, FWG_TAG_ACTS);
+            FWG_SETPRIO(FWG_PRIO_GYM_PRE);
             FWG_TL(A, 25);
         }
         if (!SPLIT) {
@@ -469,6 +486,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         }
 #endif
         FWG_TL(A, 2);
+        if (SPLIT) FWG_SETPRIO(FWG_PRIO_PHYS_TAIL);
         if (__ballot(fail != 0) != 0ull) {   // (rare) state was left untouched: derived values of the last valid state
             if (fail != 0) {
                 E.d = derive<TURB>(E.y, E.wind, gust);
@@ -710,6 +728,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (c.metrics) fwg_pin(S_prev.s[0], S_prev.s[1], S_prev.s[2]);
         fwg_msg_put(tailm, u2f(steps_before), u2f(tail_early), u2f(pre_rows ? 1u : 0u), FWG_TAG_TAIL);
         const float4 e4 = fwg_msg_take(hand + 16, FWG_TAG_STATE);
+        FWG_SETPRIO(FWG_PRIO_GYM_POST);
         FWG_TL(A, 25);
         const float4* h4 = reinterpret_cast<const float4*>(hand);
         const float4 a = h4[0], b = h4[1], g = h4[2], ea4 = h4[3];

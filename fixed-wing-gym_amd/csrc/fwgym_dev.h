@@ -376,12 +376,40 @@ template <class T> __device__ __forceinline__ void fwg_pin_mem(T& x) {
     asm volatile("" : "+v"(x)::"memory");
 #endif
 }
+// wave priority for the arbitration of a SIMD's issue slots between its two co-resident waves (priority first, then age: measured
+// with tools/timeline.py, the younger of two busy waves on a SIMD runs at 50-75 % of its speed alone: the first of a CU's four
+// workgroups finished its step in 13.2k ticks, the last in 17.7k -- and the launch lasts as long as its slowest workgroup).  Levels
+// of the phases of k_step2's two waves (same-box A/B, C3, steady state, profiles/r05_priorities.txt): the gym wave's actuator
+// work -- which a physics wave waits for -- above everything, the physics wave's integration above the gym wave's other
+// pre-hand-over work, the gym wave's chain after the hand-over above the physics wave's tail: 12.7 -> 12.0 us per step.
+#if defined(FWG_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+#define FWG_SETPRIO(n) do { } while (0)
+#else
+#define FWG_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+#ifndef FWG_PRIO_PHYS_STAGES
+#define FWG_PRIO_PHYS_STAGES 2
+#endif
+#ifndef FWG_PRIO_PHYS_TAIL
+#define FWG_PRIO_PHYS_TAIL 0
+#endif
+#ifndef FWG_PRIO_GYM_EARLY
+#define FWG_PRIO_GYM_EARLY 3
+#endif
+#ifndef FWG_PRIO_GYM_PRE
+#define FWG_PRIO_GYM_PRE 1
+#endif
+#ifndef FWG_PRIO_GYM_POST
+#define FWG_PRIO_GYM_POST 3
+#endif
 // One-way MESSAGES between the waves of a workgroup: 16-byte groups per lane in LDS whose last word is a tag.  LDS executes a
 // wave's accesses in order, so a message of several groups is written data first, tagged group last; the reader polls the
 // tagged group and then reads the rest.  No barrier: the writer never waits, the reader waits only for what it needs
 // (tools/ub_handoff.hip: ~290-330 ticks from the write to the value in the reader's registers, against ~480 with a separate
 // flag word -- and an s_barrier makes BOTH waves wait).  Tags are cleared by their writer at kernel entry, before the
 // workgroup's entry barrier (a previous workgroup's leftovers in the same LDS cannot be mistaken for a message).
+#define FWG_TAG_RAW 0x5A000007u      /* physics -> gym: the raw action and the actuator states the step starts from (the gym wave requests no
+                                        row before the physics wave's have landed: the CU's vector-memory path serves 64 B per clock, in order) */
 #define FWG_TAG_ACTS 0x5A000001u     /* gym -> physics: actuator states at t + h/2 and t + h */
 #define FWG_TAG_STATE 0x5A000002u    /* physics -> gym: candidate state + Euler-angle arguments */
 #define FWG_TAG_RESULT 0x5B000000u   /* physics -> gym: Va, alpha, beta | failure code in the low byte */

@@ -116,6 +116,22 @@ def run():
                                                         "max": float(life_b[m].max())}
                 print("   {:34s} blocks {:4d}  lifetime median {:.0f}  p90 {:.0f}  max {:.0f}".format(name, int(m.sum()), np.median(life_b[m]),
                                                                                                        np.percentile(life_b[m], 90), life_b[m].max()))
+        # by block index (dispatch order): lifetime and the gym wave's stamp 1 (its first rows consumed) per eighth of the grid
+        nb = last.shape[0]
+        print("   by block index eighth: lifetime median / p90 | gym stamp 1 median / p90 | physics stamp 1 median")
+        for k in range(8):
+            sl = slice(k * nb // 8, (k + 1) * nb // 8)
+            print("      {:4d}..{:4d}: {:6.0f} {:6.0f} | {:6.0f} {:6.0f} | {:6.0f}".format(sl.start, sl.stop - 1, np.nanmedian(life_b[sl]), np.nanpercentile(life_b[sl], 90),
+                  np.nanmedian(last[sl, 1, 1]), np.nanpercentile(last[sl, 1, 1], 90), np.nanmedian(last[sl, 0, 1])) +
+                  " | physics " + " ".join("{}:{:.0f}".format(i, np.nanmedian(last[sl, 0, i])) for i in (27, 29, 30, 31, 2, 3) if not np.all(np.isnan(last[sl, 0, i]))) +
+                  " | gym " + " ".join("{}:{:.0f}".format(i, np.nanmedian(last[sl, 1, i])) for i in (24, 16, 23, 2, 25, 4, 5, 6, 9) if not np.all(np.isnan(last[sl, 1, i]))))
+        # the median stamps of each class of block (where does an ending block lose its time?)
+        for name, m in classes.items():
+            if m.sum() >= 3:
+                cm = np.nanmedian(last[m], axis=0)
+                for w in range(2):
+                    print("      {} wave {}: ".format(name[:12], w) + "  ".join(
+                        "{}:{:.0f}".format(i, cm[w][i]) for i in np.argsort(np.where(np.isnan(cm[w]), 1e18, cm[w])) if not np.isnan(cm[w][i])))
         # which piece of the draw costs what: lifetime and the gym wave's arrival at barrier A (stamp 2) by the stage reached
         g2 = last[:, 1, 2]
         for st in range(1, 7):
@@ -149,7 +165,7 @@ def run():
                 "" if steps_now is None else ", lanes in their first 8 steps: {}".format(int((steps_now[worst * 64:(worst + 1) * 64] <= 8).sum()))))
             for w in range(2):
                 if not np.all(np.isnan(last[worst][w])):
-                    print("      wave {}: ".format(w) + "  ".join("{}:{:.0f}".format(i, last[worst][w][i]) for i in (0, 1, 2, 3, 4, 5, 6, 14, 15, 7, 11, 12, 13, 8, 9, 10) if not np.isnan(last[worst][w][i])))
+                    print("      wave {}: ".format(w) + "  ".join("{}:{:.0f}".format(i, last[worst][w][i]) for i in np.argsort(np.where(np.isnan(last[worst][w]), 1e18, last[worst][w])) if not np.isnan(last[worst][w][i])))
         vec.close()
     print(json.dumps(res))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
