@@ -107,6 +107,13 @@ SPECIALISED = [
     ("c3_hi_lean_log", "cnn", {"observation": {"step": 2}}, dict(TURB_MODERATE, integrator=INTEGRATOR_4X64)),
     # the c3 workload with randomised aircraft (bench.py side figure `randomised_aircraft`)
     ("c3_model16_lean_log", "cnn_model16", {"observation": {"step": 2}}, TURB_MODERATE),
+    # the other configuration files the reference ships, as FixedWingVecEnv(config) constructs them by default (derived views on,
+    # row log where it applies): examples/models/mlp_controller, examples/models/cnn_controller, fixed_wing_config_dev.json --
+    # with these every shipped configuration runs a specialised kernel on a machine without hipcc (the interpreting kernel is 30x
+    # slower; other configurations are compiled at run time, gym_fixed_wing/jit.py)
+    ("ship_mlp", "mlp", None, None),
+    ("ship_cnn_log", "cnn", None, None),
+    ("ship_dev", "dev", None, None),
 ]
 # rows per parity of the observation row log: depth 36 - (5 - 1) = 32 for the 5-row matrix observations, so that the window's
 # position repeats every obs_step x 32 steps and captured chunks of 64 / 128 / 256 steps replay with the views handed out at

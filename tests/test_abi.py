@@ -1,5 +1,6 @@
 """The C-ABI library loads and exports every symbol include/fwgym.h declares; struct sizes agree between the header
 (as compiled into the library) and the ctypes mirror; host-only entry points work without a GPU."""
+import copy
 import ctypes
 import os
 import re
@@ -72,3 +73,26 @@ def test_unsupported_configurations_raise():
     cfg["reward"]["factors"][0]["function_class"] = "quadratic"   # no matching term: the reference raises KeyError too
     with pytest.raises(KeyError):
         EnvConfig(cfg).compile()
+
+
+def test_every_configuration_file_the_reference_ships_is_a_build_time_preset():
+    """gym_fixed_wing/fixed_wing_config.json, fixed_wing_config_dev.json, examples/fixed_wing_config.json and the two
+    examples/models/*_controller configurations, constructed the way FixedWingVecEnv does by default (derived views on, row log
+    where it applies): each lowers to the words of a frozen preset, i.e. runs a constexpr-specialised kernel without hipcc on the
+    machine (the interpreting kernel is ~30x slower, bench.py `generic_kernel`)."""
+    from gym_fixed_wing import presets, specialize
+    from gym_fixed_wing.config import EnvConfig
+    lib = nat.load_library()
+    frozen = []
+    for name, kind, ckw, skw in presets.SPECIALISED:
+        ec = EnvConfig(presets.preset(kind), config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
+        frozen.append(specialize.spec_words(lib, ec, store_derived="_lean" not in name,
+                                            obs_log_rows=presets.OBS_LOG_ROWS if name.endswith("_log") else 0))
+    for kind in ("default", "examples", "mlp", "cnn", "dev"):
+        ec = EnvConfig(presets.preset(kind))
+        ob = ec.cfg["observation"]
+        noise = ob.get("noise", None)
+        noisy = noise is not None and (noise.get("var", 0) != 0 or noise.get("mean", 0) != 0)
+        rows = presets.OBS_LOG_ROWS if (int(ob.get("length", 1)) > 1 and not noisy and len(ob["states"]) % 4 == 0) else 0
+        words = specialize.spec_words(lib, ec, store_derived=True, obs_log_rows=rows)
+        assert words in frozen, kind

@@ -250,6 +250,27 @@ REL_FLOOR_LOOSE, REL_BAR_LOOSE = 0.1, 2e-5
 REL_FLOORS = (0.1, 0.25, 0.5, 1.0)   # (printed: the worst pure-relative error by how large a state has to be to count)
 
 
+def test_default_construction_compiles_a_specialised_kernel(monkeypatch):
+    """The path a user takes: no FWGYM_JIT in the environment (the suite sets it to 0), specialize left at None, a batch of >= 1 024
+    envs and a configuration that is not a preset -- FixedWingVecEnv asks jit.py for a specialised library (found in the cache the
+    build prepared: the same configuration as the test above) and runs it; a batch below 1 024 envs keeps the generic kernel silently."""
+    import warnings
+    from gym_fixed_wing import jit
+    monkeypatch.delenv("FWGYM_JIT", raising=False)
+    if jit.hipcc_path() is None:
+        pytest.skip("no hipcc on this machine")
+    cfg = configs.reference_like("examples")
+    ckw = {"steps_max": 1500, "target": {"on_success": "done", "success_streak_fraction": 1, "success_streak_req": 100}}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        big = _vec(cfg, 4096, config_kw=ckw, seed=2)
+        small = _vec(cfg, 256, config_kw=ckw, seed=2)
+    assert big.spec_index >= 0 and small.spec_index < 0
+    big.reset()
+    big.step_device(big._mem.zeros((4096, 3)))
+    big.close(), small.close()
+
+
 def _one_step_errors(vec, spec, raw, turb, step=None):
     """One env step on the device vs the oracle from the identical (device) state.  Returns (scaled error [N,18], pure
     relative error [N,18] where |want| > REL_FLOOR * scale else nan, oracle ok mask, failure codes, device done flags).
