@@ -299,6 +299,12 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // (dense batch: the same, the new window going into the env's record of the batch -- unless every step re-draws observation noise)
     const bool pre_install = SPLIT && !HS::enabled && c.auto_reset && (c.obs_log > 0 || !c.obs_noise) && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 &&
                              A.acc == nullptr && !c.has_int_obs;   // (integrator entries of a reset observation depend on how the old episode ends)
+    // row-log mode: the lagged rows of such an end's TERMINAL observation never pass through the gym wave -- the partner copies
+    // them, log -> terminal batch, before it writes the new window over their planes (a few lanes: one 4-byte load and store per
+    // ending lane, the wave's lanes taking one word each, where the gym wave spent twelve 16-byte loads before the hand-over
+    // and as many stores on its chain after it).  The gym wave reads them back only in the rare cases that need them in registers
+    // (the last step failed, the prepared draw was stale): the partner then installs nothing and the end takes the unforeseen path
+    const bool partner_rows = pre_install && c.obs_log > 0 && c.obs_length > 1;
 
     // k_step2 entry: every wave clears the tags of the messages it is going to WRITE (what a previous workgroup left in this
     // LDS must not be mistaken for one), then ONE workgroup barrier -- at the point where both waves wait for their first rows
@@ -460,6 +466,13 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     if (PHYS) {
 #ifdef FWG_ABL_NO_SIM
         E.d = derive<TURB>(E.y, E.wind, gust);
+        if constexpr (SPLIT) {   // the partner still waits for its two messages
+            float ea[5];
+            euler_args(E.y, ea);
+            const HandToGym hq{hand, &A};
+            hq.state(E.y, ea);
+            hq.result(E.d.Va, E.d.alpha, E.d.beta, 0);
+        }
 #else
         FWG_TL(A, 1);
         if constexpr (SPLIT) {
@@ -585,7 +598,14 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // an episode that ends at steps_max is known here: everything its episode-end branch reads from memory is requested
         // now -- the prepared draw, the end-error record, the lagged rows of the terminal observation --, so that the round
         // trips run under the rest of this block and the partner's integration
+        bool end_in_wave = false;   // (wave-uniform)
         if (c.auto_reset && c.steps_max > 0 && __ballot(valid && done) != 0ull) {
+            end_in_wave = true;
+#ifndef FWG_ABL_NO_END_PRIO
+            // a wave that hosts an episode end has the longest way to go of all the launch's waves -- the launch ends when the
+            // last of them does: it issues ahead of its SIMD's other wave from here on
+            if (SPLIT) FWG_SETPRIO(FWG_PRIO_GYM_END);
+#endif
             if (valid && done) {
                 pre_end = true;
                 if (draw_stage_of(E.flags) == FWG_DRAW_READY) {
@@ -597,7 +617,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                     int slot = A.slot_end + 1; slot -= (slot >= FWG_END_RING) ? FWG_END_RING : 0;
                     pre_old = CGROUP(A.S, A.N, (L.end_ring >> 2) + slot, e);
                 }
-                if (c.obs_log > 0) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
+                if (c.obs_log > 0 && !partner_rows) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
             }
         }
         FWG_TL(A, 18);
@@ -660,6 +680,9 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #ifdef FWG_ABL_NO_STAGED_DRAW
             m = 0ull;
 #endif
+#ifndef FWG_ABL_DRAW_AT_END
+            if (end_in_wave) m = 0ull;   // (not on top of an episode end's work: the piece waits one step, episodes last hundreds)
+#endif
             if (m != 0ull) {
                 if (work && stage == pick) {
                     const unsigned ns = draw_stage_step(c, dc, A, e, E.episode, stage, T);
@@ -703,7 +726,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             if (pre_end) {   // (only the lanes that requested them: the others' copies are indeterminate)
                 touch4(pre_tag); touch4(pre_old);
                 if (pre_draw) touch_draw(c, RD);
-                if (c.obs_log > 0) {
+                if (c.obs_log > 0 && !partner_rows) {
 #pragma unroll
                     for (int i = 0; i < FWG_MAX_OBS * FWG_MAX_ROWS; ++i)
                         if (i >= c.n_obs && i < c.obs_dim) { const float v = ob.get(i); FWG_TOUCH(v); }
@@ -740,6 +763,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         const float4 r = fwg_msg_take(hand + 20, FWG_TAG_RESULT, 0xFF000000u);
         E.d.Va = r.x; E.d.alpha = r.y; E.d.beta = r.z;
         fail = (int)(f2u(r.w) & 0xFFu);
+        if (partner_rows) pre_rows = pre_rows && fail == 0;   // (a foreseen end whose last step fails: nothing installed, see partner_rows)
         if (__ballot(fail != 0) != 0ull) {   // (rare) a failed step: the last valid state and its derived values follow
             const float4 o = fwg_msg_take(hand + 24, FWG_TAG_OLD, 0xFFFFFFFFu, fail != 0);
             if (fail != 0) {
@@ -752,20 +776,40 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     }
     // physics wave: what its tail work needs from memory is requested first thing after the hand-over
     unsigned steps_p = 0u;
-    bool early_p = false, end_p = false;
+    bool early_p = false, end_p = false, coop_rows = false;
+    unsigned long long end_mask = 0ull;
+    float coop_word[FWG_COOP_ENDS] = {};
     float rec0_p[FWG_MAX_OBS];
     ResetDraw RDp;
     if (SPLIT && PHYS) {
         const float4 w = fwg_msg_take(tailm, FWG_TAG_TAIL);
         if (tail_rows || pre_install) {
             steps_p = f2u(w.y);
-            end_p = pre_install && valid && f2u(w.z) != 0u;
+            end_p = pre_install && valid && f2u(w.z) != 0u && !(partner_rows && fail != 0);
             early_p = tail_rows && valid && fail == 0 && steps_p != 0u && !end_p;   // (an ending lane's rows are the partner's)
             if (__ballot(early_p) != 0ull) {
                 if (early_p) early_rows_request(c, A, e, rec0_p);
             }
-            if (__ballot(end_p) != 0ull) {
+            end_mask = __ballot(end_p);
+            if (end_mask != 0ull) {
                 if (end_p) draw_load_final(c, A.S, A.N, e, RDp);   // (just read by the partner: served from the cache)
+                // partner_rows: the lagged rows of the ending lanes' terminal observations, requested now, stored before the new
+                // window goes over their planes.  Up to FWG_COOP_ENDS ending lanes: lane i takes word i of each one's rows
+                if (partner_rows && A.term_obs != nullptr) {
+                    const int lag_words = (c.obs_length - 1) * c.n_obs;
+                    coop_rows = lag_words <= FWG_WAVE && __popcll(end_mask) <= FWG_COOP_ENDS;
+                    if (coop_rows) {
+                        unsigned long long mm = end_mask;
+#pragma unroll
+                        for (int k = 0; k < FWG_COOP_ENDS; ++k) {
+                            if (mm != 0ull) {
+                                const long el = env0 + (__ffsll((long long)mm) - 1);
+                                mm &= mm - 1ull;
+                                if (lane < lag_words) coop_word[k] = A.obs[((A.log_win + 1) * A.N + el) * c.n_obs + (long)(lane / c.n_obs) * A.N * c.n_obs + lane % c.n_obs];
+                            }
+                        }
+                    }
+                }
             }
         }
         // hand-shake B, first mark: this wave has read its partner's messages (LDS executes a wave's accesses in order), the
@@ -809,7 +853,34 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         // foreseen episode end: the NEXT episode goes into the simulator / cold rows and the row log (the old episode's final
         // state went to the partner through LDS; its terminal observation was requested before barrier A; the lanes are
         // disjoint from the ones the partner re-initialises itself)
-        if (pre_install && __ballot(end_p) != 0ull) {
+        if (pre_install && end_mask != 0ull) {
+            if (partner_rows && A.term_obs != nullptr) {   // the old window's rows -> the terminal batch, before the new window lands on them
+                if (coop_rows) {
+                    const int lag_words = (c.obs_length - 1) * c.n_obs;
+                    unsigned long long mm = end_mask;
+#pragma unroll
+                    for (int k = 0; k < FWG_COOP_ENDS; ++k) {
+                        if (mm != 0ull) {
+                            const long el = env0 + (__ffsll((long long)mm) - 1);
+                            mm &= mm - 1ull;
+                            if (lane < lag_words) A.term_obs[el * c.obs_dim + c.n_obs + lane] = coop_word[k];
+                        }
+                    }
+                } else if (end_p) {   // many ending lanes (synchronised episodes): every lane its own rows, one row at a time
+                    for (int r = 1; r < c.obs_length; ++r) {
+                        const float* src = log_row(c, A.obs, A.N, e, A.log_win + r);
+                        float* dst = A.term_obs + e * c.obs_dim + r * c.n_obs;
+                        if (((c.obs_dim | c.n_obs) & 3) == 0) {   // (rare: no staging of the groups in a register array)
+                            for (int i = 0; 4 * i < c.n_obs; ++i) {
+                                const float4 q = reinterpret_cast<const float4*>(src)[i];
+                                reinterpret_cast<float4*>(dst)[i] = q;
+                            }
+                        } else {
+                            for (int j = 0; j < c.n_obs; ++j) dst[j] = src[j];
+                        }
+                    }
+                }
+            }
             if (end_p) {   // (the partner checked the draw's tag)
                 reset_rows_to_log(c, A, e, RDp, aring, A.slot_lag, A.log_win, c.obs_log == 0);
 #pragma unroll
@@ -1001,7 +1072,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // issue order, so a load issued after them would sit through the acknowledgement of every one of them (2-3k ticks)
     // where this wait costs one round trip.  The same registers as the foreseen end's prefetches: one end branch for both
     const bool late_end = done && valid && !(pre_end && ok);
-    const bool reload = c.obs_log > 0 && (done || !ok) && valid && !pre_end;   // (overwrites what early_rows_pre prepared)
+    // (overwrites what early_rows_pre prepared; a foreseen end whose lagged rows were left to the partner, which then did not take them)
+    const bool reload = c.obs_log > 0 && valid && (pre_end ? (partner_rows && !pre_rows) : (done || !ok));
     if (__ballot(late_end || reload) != 0ull) {
         if (late_end || reload) {
             if (c.metrics && late_end) {
@@ -1017,7 +1089,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             if (reload) log_load_rows(c, A.obs, A.N, e, A.log_win, ob);
             touch4(pre_tag); touch4(pre_old);
             if (pre_draw) touch_draw(c, RD);
-            if (c.obs_log > 0 && (reload || pre_end)) {
+            if (c.obs_log > 0 && (reload || (pre_end && !partner_rows))) {
 #pragma unroll
                 for (int i = 0; i < FWG_MAX_OBS * FWG_MAX_ROWS; ++i)
                     if (i >= c.n_obs && i < c.obs_dim) { const float v = ob.get(i); FWG_TOUCH(v); }
@@ -1101,16 +1173,37 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
         }
         FWG_TL(A, 11);
-        if (A.term_obs != nullptr) {   // a few ending lanes: each stores its own record; many (synchronised episodes): staged, coalesced
-            if ((c.obs_dim & 3) == 0 && __popcll(done_mask) <= 8) {
-                if (done && valid) {
-                    float4* o4 = reinterpret_cast<float4*>(A.term_obs + e * c.obs_dim);
+        if (A.term_obs != nullptr) {
+            // (partner_rows: of an end whose new episode the partner installs only the newest record -- the partner copies the rest)
+            const bool newest_only = partner_rows && done && valid && pre_rows;
+            const unsigned long long part_mask = partner_rows ? __ballot(newest_only) : 0ull;
+            const unsigned long long full_mask = done_mask & ~part_mask;
+            if (part_mask != 0ull) {
+                if (newest_only) {
+                    float* o = A.term_obs + e * c.obs_dim;
+                    if (((c.obs_dim | c.n_obs) & 3) == 0) {
 #pragma unroll
-                    for (int q = 0; q < (FWG_MAX_OBS * FWG_MAX_ROWS) / 4; ++q)
-                        if (q * 4 < c.obs_dim) o4[q] = make_float4(ob.get(4 * q), ob.get(4 * q + 1), ob.get(4 * q + 2), ob.get(4 * q + 3));
+                        for (int q = 0; q < FWG_MAX_OBS / 4; ++q)
+                            if (q * 4 < c.n_obs) reinterpret_cast<float4*>(o)[q] = make_float4(ob.get(4 * q), ob.get(4 * q + 1), ob.get(4 * q + 2), ob.get(4 * q + 3));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < FWG_MAX_OBS; ++j)
+                            if (j < c.n_obs) o[j] = ob.get(j);
+                    }
                 }
-            } else {
-                write_obs<ROLE>(c, A.term_obs, env0, A.N, ob, lds + M.stage, lane, done_mask);
+            }
+            // a few ending lanes: each stores its own record; many (synchronised episodes): staged, coalesced
+            if (full_mask != 0ull) {
+                if ((c.obs_dim & 3) == 0 && __popcll(full_mask) <= 8) {
+                    if (done && valid && !newest_only) {
+                        float4* o4 = reinterpret_cast<float4*>(A.term_obs + e * c.obs_dim);
+#pragma unroll
+                        for (int q = 0; q < (FWG_MAX_OBS * FWG_MAX_ROWS) / 4; ++q)
+                            if (q * 4 < c.obs_dim) o4[q] = make_float4(ob.get(4 * q), ob.get(4 * q + 1), ob.get(4 * q + 2), ob.get(4 * q + 3));
+                    }
+                } else {
+                    write_obs<ROLE>(c, A.term_obs, env0, A.N, ob, lds + M.stage, lane, full_mask);
+                }
             }
         }
         FWG_TL(A, 12);

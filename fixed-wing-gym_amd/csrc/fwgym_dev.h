@@ -402,6 +402,9 @@ template <class T> __device__ __forceinline__ void fwg_pin_mem(T& x) {
 #ifndef FWG_PRIO_GYM_POST
 #define FWG_PRIO_GYM_POST 3
 #endif
+#ifndef FWG_PRIO_GYM_END   // (the gym wave of a group that hosts an episode end, from the moment it knows)
+#define FWG_PRIO_GYM_END 3
+#endif
 // One-way MESSAGES between the waves of a workgroup: 16-byte groups per lane in LDS whose last word is a tag.  LDS executes a
 // wave's accesses in order, so a message of several groups is written data first, tagged group last; the reader polls the
 // tagged group and then reads the rest.  No barrier: the writer never waits, the reader waits only for what it needs

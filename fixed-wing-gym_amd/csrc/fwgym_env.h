@@ -295,6 +295,7 @@ __host__ __device__ inline int obs_stage_stride(int obs_dim) { return obs_vec4(o
 // every hand-off access before it.  The mark itself is a word of its OWN (LdsMap::flag, outside the staging area: the physics
 // wave raises it to 2 long after its partner may have begun staging output records, so it must not alias a staged value).
 // Workgroup residency is bounded by LDS (4 workgroups per CU need <= 40 KiB each; a fifth area would cost a fourth of the chip).
+#define FWG_COOP_ENDS 4   // ending lanes per wave whose terminal rows the wave copies cooperatively (k_step2, partner_rows)
 #define FWG_HAND_WORDS 28   /* physics -> gym, seven 16-byte groups per lane (odd: conflict-free): y[4..15] | the five Euler-angle arguments, tag |
                                Va alpha beta, tag + failure code | (failed step) alpha beta of the last valid state, tag */
 #define FWG_TAIL_WORDS 4    /* gym -> physics: step index, padding-row index, install flag, tag */
@@ -1529,11 +1530,10 @@ __device__ __forceinline__ void reset_rows_to_log(const DevCfg& c, const KArgs& 
     }
 }
 
-// rows_done: the observation window is in the row log already (reset_rows_to_log): ob is left as it is
-template <bool TURB, class TAB, class OB>
-__device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, long e, Env& E, TAB& T, OB& ob, const float* ring,
-                                             int g_end, int g_lag, int g_bit, const ResetDraw& D, bool have_gw = false,
-                                             bool rows_done = false) {
+// The new episode's state and gym-side bookkeeping from its draw; leaves the target errors in `err` and the variable table in T
+template <bool TURB, class TAB>
+__device__ __forceinline__ void reset_state(const DevCfg& c, const KArgs& A, long e, Env& E, TAB& T, int g_end, int g_bit,
+                                            const ResetDraw& D, bool have_gw, float (&err)[3]) {
     if (c.model_n > 0) {   // simulator.model: the set prepared for this episode by k_model_draw becomes the current one
 #pragma unroll
         for (int g = 0; g < FWG_AERO_GROUPS; ++g)
@@ -1571,7 +1571,8 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
         for (int i = 0; i < 4; ++i) E.tprop[k][i] = D.tprop[k][i];
     }
     fill_vars(E, T);
-    float err[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) err[k] = 0.f;
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
         if (k < c.n_targets) {
@@ -1601,7 +1602,15 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
         if (!have_gw) E.gw = reinterpret_cast<const unsigned*>(A.S)[((unsigned)c.L.goal + (unsigned)(g_bit >> 3)) * (unsigned)A.N + (unsigned)e];
         goal_push(c, E, goal_flags(c, err), g_bit, 0u);   // ... and written back by store_gym
     }
-    if (rows_done) return;   // (k_step2, foreseen end: the partner wave wrote the cold and simulator rows as well)
+}
+
+template <bool TURB, class TAB, class OB>
+__device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, long e, Env& E, TAB& T, OB& ob, const float* ring,
+                                             int g_end, int g_lag, int g_bit, const ResetDraw& D, bool have_gw = false,
+                                             bool rows_done = false) {
+    float err[3];
+    reset_state<TURB>(c, A, e, E, T, g_end, g_bit, D, have_gw, err);
+    if (rows_done) return;   // (k_step2, foreseen end: the partner wave wrote the cold and simulator rows and the observation window)
     store_cold(c, A.S, A.N, e, E);
     // ---- observation: every row is the initial record (+ per-row init noise when length > 1)
     float int_pad[3] = {0.f, 0.f, 0.f};

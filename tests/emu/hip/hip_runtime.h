@@ -120,6 +120,7 @@ static inline int atomicOr(int* p, int v) { std::lock_guard<std::mutex> g(emu_at
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 #define __expf(x) expf(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))

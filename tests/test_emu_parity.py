@@ -173,12 +173,15 @@ def test_replay_check_rejects_a_graph_captured_at_the_other_parity(emu_lib):
     vec.close()
 
 
-@pytest.mark.parametrize("layout", ["row_log", "dense"])
-def test_two_wave_kernel_through_foreseen_episode_ends_emulated(layout):
+@pytest.mark.parametrize("layout,n", [("row_log", 5), ("row_log", 3), ("dense", 5)])
+def test_two_wave_kernel_through_foreseen_episode_ends_emulated(layout, n):
     """k_step2 (two waves per 64 envs) through time-limit episode ends, row log and dense batch: the next episode's prepared
     draw is installed and its observation window written by the physics wave in its tail (reset_rows_to_log), the finished
     episode's accumulators are parked and collected by fwg_finish_episodes.  The configuration is not a preset, so the
-    emulation library is specialised for it (tests/emu build_emu_spec, the host counterpart of gym_fixed_wing/jit.py)."""
+    emulation library is specialised for it (tests/emu build_emu_spec, the host counterpart of gym_fixed_wing/jit.py).
+    Row log: the lagged rows of the terminal observations are copied by the physics wave before it writes the new window over
+    them -- the wave's lanes sharing the words of up to FWG_COOP_ENDS (4) ending lanes (n = 3), every ending lane its own
+    rows beyond that (n = 5: the five episodes end in the same step)."""
     from emu.host_backend import build_emu_spec
     from gym_fixed_wing.config import EnvConfig
     from gym_fixed_wing import presets
@@ -189,7 +192,7 @@ def test_two_wave_kernel_through_foreseen_episode_ends_emulated(layout):
     ec = EnvConfig(copy.deepcopy(cfg), config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
     rows = presets.OBS_LOG_ROWS if layout == "row_log" else 0
     lib = build_emu_spec(ec, auto_reset=True, store_derived=True, obs_log_rows=rows)
-    n, steps = 5, 150
+    steps = 150
     vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True,
                           _backend=HostBackend(), _lib_path=lib, obs_log_rows=rows)
     assert vec.spec_index == 0 and vec.obs_log_rows == rows

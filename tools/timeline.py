@@ -61,10 +61,12 @@ def run():
                 vec.reset(indices=np.sort(perm[k::stagger]))
                 for t in range(per):
                     vec.step_device(acts[0] if const else acts[t % 16], want_obs=False)
+                vec.finish_episodes()   # (as a training loop does: an end then never finds its env's last record uncollected)
             if const:
                 acts = [acts[0]] * 16
         for t in range(300):
             vec.step_device(acts[t % 16])
+        vec.finish_episodes()
         torch.cuda.synchronize()
         rows = []
         for rep in range(20):
