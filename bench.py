@@ -259,6 +259,9 @@ def main():
                     help="c5: the rollout head's matrix products: 'split' (default) = every fp32 operand as bf16 hi + lo, three MFMA "
                          "products per tile (~1e-5 of a torch fp32 forward); 'bf16' = one plain bf16 product (~1e-2)")
     ap.add_argument("--eager", action="store_true", help="launch every step from the host instead of replaying hipGraphs")
+    ap.add_argument("--eager-sync", action="store_true",
+                    help="with --eager: drain the device after every step, so that each launch arrives at an idle GPU (profiling: a "
+                         "tracer's per-dispatch duration then holds the kernel alone, not its wait in the queue behind its predecessor)")
     ap.add_argument("--lib", default=None, help="measurement builds (tools/ablate.py): path of an alternative libfwgym.so")
     ap.add_argument("--stagger", type=int, default=0,
                     help="S > 0: before the warm-up, reset 1/S of the envs every steps_max/S steps, so that episode ends (metrics, "
@@ -451,6 +454,8 @@ def main():
                 done_steps += c
             for t in range(s):
                 vec.step_device(self.pool[(offset + done_steps + t) % len(self.pool)], want_obs=want_obs)
+                if args.eager_sync:
+                    torch.cuda.synchronize(dev)
             if s and not r:
                 self.reduce_step(False)
 
