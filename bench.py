@@ -591,6 +591,7 @@ def main():
                 S.run(sc, max(1, STEADY_STATE_STEPS // sc), 0)
                 fresh = S.time_replays(sc, sreps)
                 ent = side_entry(fresh, n, alg, note=note, specialised_kernel=S.vec.spec_index >= 0)
+                ent["kernel_instance"] = int(S.vec.spec_index)   # (-1 generic | i frozen configuration | 1000 + i its shape instance)
                 if stag:
                     S.stagger_ages(int(S.vec.cfg["steps_max"]))
                     st = S.time_replays(sc, sreps)
@@ -626,17 +627,29 @@ def main():
         side_env("integrator_4x64", (cfg, ckw, hi), n_envs, log_rows, alg_b,
                  "the same workload with 4 RK4 sub-steps and 64 exact actuator micro-steps per env step: the first scheme clearly "
                  "more accurate than the reference's adaptive RK45 at rtol 1e-3 (profiles/r02_convergence.json)", stag=False)
-        # the GENERIC kernel (what a configuration outside the presets runs when no specialised kernel can be compiled for it:
-        # no hipcc on the machine, or specialize=False): the same workload with steps_max 1999, which matches no preset
+        # a configuration that differs from the preset in VALUES only (here: steps_max 1999; any scaling, constraint, aircraft
+        # constant ... likewise) and no run-time compiler: the preset's SHAPE instance (structure frozen, values read from memory)
         gk = _copy.deepcopy(ckw or {})
         gk["steps_max"] = 1999
         import warnings as _warnings
         with _warnings.catch_warnings():
             _warnings.simplefilter("ignore")
-            side_env("generic_kernel", (cfg, gk, skw), n_envs, log_rows, alg_b,
-                     "the same workload on the GENERIC kernel (configuration interpreted at run time: scalar loads, LDS tables, scratch), "
-                     "what a non-preset configuration runs without a run-time specialised kernel (FixedWingVecEnv compiles one by "
-                     "default when hipcc is present, and warns either way)", stag=False, extra={"specialize": False})
+            side_env("shape_instance", (cfg, gk, skw), n_envs, log_rows, alg_b,
+                     "the same workload with steps_max 1999 -- no frozen configuration -- and specialize=False: the preset's SHAPE "
+                     "instance (every count / type / flag frozen as in the preset's kernel, every value a scalar load from the "
+                     "configuration in memory); what a configuration that differs from a preset in values only runs, nothing compiled "
+                     "at run time", stag=False, extra={"specialize": False})
+            # the GENERIC kernel (what is left when the STRUCTURE matches no preset either and no specialised kernel can be
+            # compiled: no hipcc on the machine, or specialize=False): the same configuration with the shape instances switched off
+            os.environ["FWGYM_SHAPE"] = "0"
+            try:
+                side_env("generic_kernel", (cfg, gk, skw), n_envs, log_rows, alg_b,
+                         "the same configuration on the GENERIC kernel (configuration interpreted at run time: scalar loads, LDS tables, "
+                         "scratch; FWGYM_SHAPE=0), what a configuration whose structure matches no preset runs without a run-time "
+                         "specialised kernel (FixedWingVecEnv compiles one by default when hipcc is present, and warns either way)",
+                         stag=False, extra={"specialize": False})
+            finally:
+                os.environ.pop("FWGYM_SHAPE", None)
         from gym_fixed_wing import presets as _pr
         try:   # every env flies its own aircraft (16 parameters re-sampled at every reset); gentle actions: random full-scale
             # actions crash the randomised aircraft within a few dozen steps and the run then measures failure ends
@@ -655,11 +668,11 @@ def main():
     if side_ok and world == 1 and args.workload == "c3" and not args.stagger and not args.envs and not args.total_envs:
         # BASELINE configs[4]: the PPO rollout loop (VecNormalize + 64-64 MlpPolicy + sampling + env step, end to end), 128-step
         # rollouts replayed as hipGraphs; head and env step in ONE launch per step where fwg_rollout_step applies
-        def side_c5(name, precise):
+        def side_c5(name, precise, wl="c5", what="BASELINE configs[4]"):
             try:
                 from gym_fixed_wing.actor import DeviceActor
                 from gym_fixed_wing.rollout import FusedRollout, MlpPolicy
-                c5 = workload("c5")
+                c5 = workload(wl)
                 S = Runner(c5[0], c5[1], c5[2], c5[3], 0, 0)
                 torch.manual_seed(0)
                 act = DeviceActor.for_env(S.vec, seed=7, env_id_base=0, precise=precise)
@@ -674,9 +687,9 @@ def main():
                     S.reduce_step(False)
                 torch.cuda.synchronize(dev)
                 ms = (time.perf_counter() - t1) / (sreps * sc) * 1e3
-                sides[name] = side_entry(ms, c5[3], ALG_BYTES["c5"], specialised_kernel=S.vec.spec_index >= 0,
+                sides[name] = side_entry(ms, c5[3], ALG_BYTES[wl], specialised_kernel=S.vec.spec_index >= 0,
                     launches_per_step=1 if ro.fused else 2,
-                    note=c5[4] + " (BASELINE configs[4]): rollout head (VecNormalize statistics + 64-64 MlpPolicy on bf16 MFMA, " +
+                    note=c5[4] + " (" + what + "): rollout head (VecNormalize statistics + 64-64 MlpPolicy on bf16 MFMA, " +
                          ("operands split hi + lo: three products per tile, ~1e-5 of a torch fp32 forward" if precise else
                           "ONE plain bf16 product per tile, ~1e-2") + " + sampling) and env step, " +
                          ("ONE launch per rollout step (fwg_rollout_step)" if ro.fused else "two launches per rollout step") +
@@ -688,6 +701,8 @@ def main():
 
         side_c5("c5", True)
         side_c5("c5_bf16", False)
+        # what the user of a SMALL batch runs: policy + env step in one launch at BASELINE configs[1]'s 4 096 envs
+        side_c5("c2_rollout", True, "c2", "BASELINE configs[1] under the rollout loop: 16 workgroups of 256 envs, launch-latency bound")
     if side_ok and world > 1 and args.workload == "c3" and north_star_default:
         # multi-GPU side figures: BASELINE configs[3] (32 768 envs per GPU) and weak scaling at the one-GPU workload (65 536 per GPU)
         for name, n_side, first_side in (("c4_32768_per_gpu", 32768, rank * 32768), ("weak_65536_per_gpu", 65536, rank * 65536)):

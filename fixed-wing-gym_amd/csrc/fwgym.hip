@@ -39,6 +39,10 @@ static_assert(sizeof(SpecWords) == sizeof(DevCfg), "DevCfg must be made of 32-bi
 #else
 #define FWG_SPEC_LIST(X)
 #endif
+#ifndef FWG_SHAPE_LIST   /* the frozen configurations that are ALSO built as shape instances (structure frozen, values from memory) */
+#define FWG_SHAPE_LIST(X)
+#endif
+#define FWG_SHAPE_BASE FWG_INSTANCE_SHAPE   /* kernel instance FWG_SHAPE_BASE + i = the shape instance of frozen configuration i */
 #define FWG_DEFINE_SPEC(i) static constexpr DevCfg kSpec##i = __builtin_bit_cast(DevCfg, kSpecWords##i);
 FWG_SPEC_LIST(FWG_DEFINE_SPEC)
 template <int SPEC> struct SpecCfg {
@@ -56,6 +60,22 @@ template <int SPEC> struct SpecCfg {
         static __device__ __forceinline__ const DevCfg& get(const DevCfg*) { return kSpec##i; }           \
     };
 FWG_SPEC_LIST(FWG_SPEC_GETTER)
+// Shape instances: what a configuration outside the frozen ones runs on when only its VALUES differ from one of them (a
+// reward scaling, a constraint, the time limit, an aircraft constant, a noise level ...) and no run-time compiler is at hand:
+// the kernel computes with the frozen object's STRUCTURE (kShape: every loop bound, branch and index folds as in the frozen
+// kernel) and reads every VALUE member through V(c) from the configuration in memory (fwgym_dev.h cfg_values): scalar loads at
+// the point of use.  (Measured dead ends: a kernel-local merged copy of the object -- a 3 KB alloca the compiler does not split,
+// 45 000 spilled registers; the memory configuration + __builtin_assume on its structure words -- not propagated, as generic.)
+#define FWG_SHAPE_OBJECT(i) static constexpr DevCfg kShape##i = as_shape(kSpec##i);
+FWG_SHAPE_LIST(FWG_SHAPE_OBJECT)
+#define FWG_SHAPE_GETTER(i)                                                                               \
+    template <> struct SpecCfg<FWG_SHAPE_BASE + i> {                                                      \
+        static constexpr int obs_dim = kSpec##i.obs_dim;                                                  \
+        static constexpr bool one_rk4_step = kSpec##i.nsub == 1;                                          \
+        static constexpr bool rollout_ok = false;   /* (the fused rollout launch: frozen configurations only) */ \
+        static __device__ __forceinline__ const DevCfg& get(const DevCfg*) { return kShape##i; }          \
+    };
+FWG_SHAPE_LIST(FWG_SHAPE_GETTER)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // step kernel
@@ -76,6 +96,8 @@ template <int SPEC> struct KernelTypes {  // generic kernel: lane-private LDS co
         static __device__ __forceinline__ Obs obs(float*, const LdsMap&, int) { return Obs(); }               \
     };
 FWG_SPEC_LIST(FWG_SPEC_TYPES)
+#define FWG_SHAPE_TYPES(i) template <> struct KernelTypes<FWG_SHAPE_BASE + i> : KernelTypes<i> {};
+FWG_SHAPE_LIST(FWG_SHAPE_TYPES)
 
 // Attached rollout head (fwg_attach_observer): this wave's batch moments of the observation records and discounted
 // returns it produced, added to the head's accumulators (fwgym_env.h "batch-moment accumulators").  Called by all lanes.
@@ -297,7 +319,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // (HS::enabled -- the fused rollout launch -- has an observer attached by construction)
     const bool tail_rows = SPLIT && !HS::enabled && c.obs_log > 0 && c.obs_length > 1 && A.acc == nullptr;
     // (dense batch: the same, the new window going into the env's record of the batch -- unless every step re-draws observation noise)
-    const bool pre_install = SPLIT && !HS::enabled && c.auto_reset && (c.obs_log > 0 || !c.obs_noise) && c.steps_max > (c.obs_length - 1) * c.obs_step + 1 &&
+    const bool pre_install = SPLIT && !HS::enabled && c.auto_reset && (c.obs_log > 0 || !c.obs_noise) && V(c).steps_max > (c.obs_length - 1) * c.obs_step + 1 &&
                              A.acc == nullptr && !c.has_int_obs;   // (integrator entries of a reset observation depend on how the old episode ends)
     // row-log mode: the lagged rows of such an end's TERMINAL observation never pass through the gym wave -- the partner copies
     // them, log -> terminal batch, before it writes the new window over their planes (a few lanes: one 4-byte load and store per
@@ -411,8 +433,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     for (int i = 0; i < 3; ++i) {
         cmd[i] = raw[i];
         if (c.scale_actions)
-            cmd[i] = (c.act_to_high[i] - c.act_to_low[i]) * (fclampf(raw[i], c.scale_low, c.scale_high) - c.scale_low) *
-                         c.inv_scale_span + c.act_to_low[i];
+            cmd[i] = (V(c).act_to_high[i] - V(c).act_to_low[i]) * (fclampf(raw[i], V(c).scale_low, V(c).scale_high) - V(c).scale_low) *
+                         V(c).inv_scale_span + V(c).act_to_low[i];
     }
     float cmd_c[3], sp[3];
     constrain_commands(c, cmd, cmd_c, sp);
@@ -491,11 +513,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             typedef NoStageHook HOOK;
 #endif
             if (c.model_n > 0) fail = sim_step<TURB, EXT, Aero, HOOK, HandToGym, DEF>(c, la, E.y, sp, E.wind, gust, E.d, EXT{acts}, HOOK{A}, HandToGym{hand, &A});
-            else fail = sim_step<TURB, EXT, DevCfg, HOOK, HandToGym, DEF>(c, c, E.y, sp, E.wind, gust, E.d, EXT{acts}, HOOK{A}, HandToGym{hand, &A});
+            else fail = sim_step<TURB, EXT, DevCfg, HOOK, HandToGym, DEF>(c, V(c), E.y, sp, E.wind, gust, E.d, EXT{acts}, HOOK{A}, HandToGym{hand, &A});
         } else if (KT::generic || c.model_n > 0) {
             fail = sim_step<TURB, NoExtActuators, Aero>(c, la, E.y, sp, E.wind, gust, E.d);
         } else {
-            fail = sim_step<TURB>(c, c, E.y, sp, E.wind, gust, E.d);
+            fail = sim_step<TURB>(c, V(c), E.y, sp, E.wind, gust, E.d);
         }
 #endif
         FWG_TL(A, 2);
@@ -571,8 +593,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const float r_ = wa[1][i];
-                        praw[i] = c.scale_actions ? (c.act_to_high[i] - c.act_to_low[i]) * (fclampf(r_, c.scale_low, c.scale_high) - c.scale_low) *
-                                                        c.inv_scale_span + c.act_to_low[i]
+                        praw[i] = c.scale_actions ? (V(c).act_to_high[i] - V(c).act_to_low[i]) * (fclampf(r_, V(c).scale_low, V(c).scale_high) - V(c).scale_low) *
+                                                        V(c).inv_scale_span + V(c).act_to_low[i]
                                                   : r_;
                     }
                     constrain_commands(c, praw, pc, psp);
@@ -594,12 +616,12 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             }
         }
         E.sft += 1u;
-        if (c.steps_max > 0 && E.steps >= (unsigned)c.steps_max) { done = true; term = FWG_TERM_STEPS; }
+        if (V(c).steps_max > 0 && E.steps >= (unsigned)V(c).steps_max) { done = true; term = FWG_TERM_STEPS; }
         // an episode that ends at steps_max is known here: everything its episode-end branch reads from memory is requested
         // now -- the prepared draw, the end-error record, the lagged rows of the terminal observation --, so that the round
         // trips run under the rest of this block and the partner's integration
         bool end_in_wave = false;   // (wave-uniform)
-        if (c.auto_reset && c.steps_max > 0 && __ballot(valid && done) != 0ull) {
+        if (c.auto_reset && V(c).steps_max > 0 && __ballot(valid && done) != 0ull) {
             end_in_wave = true;
 #ifndef FWG_ABL_NO_END_PRIO
             // a wave that hosts an episode end has the longest way to go of all the launch's waves -- the launch ends when the
@@ -626,6 +648,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             fval_action[f] = 0.f;
             if (f >= c.n_factors) continue;
             const DevFactor& F = c.factor[f];
+            const DevFactor& FV = V(c).factor[f];   // (its values: fwgym_dev.h cfg_values)
             if (F.cls != FWG_RC_ACTION) continue;
             float val = 0.f;
             if (F.type == FWG_RT_VALUE) val = fabsf(raw[0]) + fabsf(raw[1]) + fabsf(raw[2]);
@@ -643,8 +666,8 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
             } else {  // bound
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    val += raw[i] > c.act_bound_max[i] ? raw[i] - c.act_bound_max[i] : 0.f;
-                    val += raw[i] < c.act_bound_min[i] ? c.act_bound_min[i] - raw[i] : 0.f;
+                    val += raw[i] > V(c).act_bound_max[i] ? raw[i] - V(c).act_bound_max[i] : 0.f;
+                    val += raw[i] < V(c).act_bound_min[i] ? V(c).act_bound_min[i] - raw[i] : 0.f;
                 }
             }
             fval_action[f] = val;
@@ -951,7 +974,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (c.goal_enabled) {
             g = goal_flags(c, err);
             goal_push(c, E, g, A.bit_goal, rec);
-            if (E.sft >= (unsigned)c.streak_req && window_count(E, 3) >= (unsigned)c.streak_min_count) {
+            if (E.sft >= (unsigned)c.streak_req && window_count(E, 3) >= (unsigned)V(c).streak_min_count) {
                 achieved_now = !(E.flags & FWG_FLAG_GOAL_ACHIEVED);
                 E.flags |= FWG_FLAG_GOAL_ACHIEVED;
                 if (c.on_success == FWG_ON_SUCCESS_DONE) { done = true; term = FWG_TERM_SUCCESS; }
@@ -964,6 +987,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         for (int f = 0; f < FWG_MAX_FACTORS; ++f) {
             if (f >= c.n_factors) continue;
             const DevFactor& F = c.factor[f];
+            const DevFactor& FV = V(c).factor[f];   // (its values: fwgym_dev.h cfg_values)
             float val = 0.f;
             if (F.cls == FWG_RC_ACTION) {
                 val = fval_action[f];
@@ -973,26 +997,26 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 else
                     val = (F.type == FWG_RT_VALUE) ? T.get(F.src) : (F.src == 0 ? err[0] : (F.src == 1 ? err[1] : err[2]));
             } else if (F.cls == FWG_RC_SUCCESS) {
-                val = achieved_now ? (F.value_is_timesteps ? (float)(c.steps_max - (int)E.steps) : F.value) : 0.f;
+                val = achieved_now ? (F.value_is_timesteps ? (float)(V(c).steps_max - (int)E.steps) : FV.value) : 0.f;
             } else if (F.cls == FWG_RC_STEP) {
-                val = F.value;
+                val = FV.value;
             } else {  // goal
                 if (F.type == FWG_RT_PER_STATE) {
 #pragma unroll
                     for (int k = 0; k < FWG_MAX_TARGETS; ++k)
-                        if (k < c.n_targets && c.target[k].has_bound && ((g >> k) & 1u)) val += F.value / (float)c.n_targets;
+                        if (k < c.n_targets && c.target[k].has_bound && ((g >> k) & 1u)) val += FV.value / (float)c.n_targets;
                 } else {
-                    val = (g & 8u) ? F.value : 0.f;
+                    val = (g & 8u) ? FV.value : 0.f;
                 }
             }
-            const float inv_scaling = c.randomize_scaling ? E.fscale[f] : F.inv_scaling;   // per env and episode / fixed
+            const float inv_scaling = c.randomize_scaling ? E.fscale[f] : FV.inv_scaling;   // per env and episode / fixed
             if (F.fclass == FWG_FC_LINEAR) {
                 val = fabsf(val) * inv_scaling;
-                if (F.has_max) val = fminf(val, F.max);
+                if (F.has_max) val = fminf(val, FV.max);
             } else {
                 val = val * val * inv_scaling;
             }
-            val *= F.sign;
+            val *= FV.sign;
             const int fc = F.fclass;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -1017,11 +1041,11 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
                 }
                 E.psh[fc] = sh[fc];
                 E.flags |= 1u << (FWG_FLAG_PREV_VALID_SHIFT + fc);
-                reward += c.term_weight[fc] * v;
+                reward += V(c).term_weight[fc] * v;
             }
         }
         // ---- target resampling / propagation (fixed_wing.py:397-404)
-        if (resample || (c.resample_every > 0 && E.sft >= (unsigned)c.resample_every)) {
+        if (resample || (V(c).resample_every > 0 && E.sft >= (unsigned)V(c).resample_every)) {
             sample_targets(c, dc, A, e, E, T, nullptr);
             next_targets(c, E);
         } else {
@@ -1035,7 +1059,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
 #pragma unroll
             for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
                 if (k >= c.n_targets) continue;
-                const float lo_lim = fabsf(c.rise_low * E.e0[k]), hi_lim = fabsf(c.rise_high * E.e0[k]);
+                const float lo_lim = fabsf(V(c).rise_low * E.e0[k]), hi_lim = fabsf(V(c).rise_high * E.e0[k]);
                 const float pa = fabsf(E.perr[k]), ca = fabsf(err[k]);
                 if ((E.rise[k] & 0xFFFFu) == 0xFFFFu && pa >= lo_lim && ca < lo_lim) E.rise[k] = (E.rise[k] & 0xFFFF0000u) | (rec - 1u);
                 if ((E.rise[k] >> 16) == 0xFFFFu && pa >= hi_lim && ca < hi_lim) E.rise[k] = (E.rise[k] & 0xFFFFu) | ((rec - 1u) << 16);
@@ -1055,7 +1079,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     } else {
         done = true;
         if (c.int_window) E.flags |= FWG_FLAG_LAST_FAILED;
-        reward = c.step_fail_timesteps ? (float)((int)E.steps - c.steps_max) : c.step_fail_value;
+        reward = c.step_fail_timesteps ? (float)((int)E.steps - V(c).steps_max) : V(c).step_fail_value;
         term = FWG_TERM_VAR0 + (unsigned)(fail - 1);
     }
 #pragma unroll
@@ -1405,7 +1429,7 @@ __device__ __forceinline__ void model_draw_env(const DevCfg& c, const DynCfg* dp
                 float v[4];
                 for (int i = 0; i < 4; ++i) {
                     const int f = 4 * g + i;
-                    v[i] = f < c.n_factors ? c.factor[f].inv_scaling : 1.f;
+                    v[i] = f < c.n_factors ? V(c).factor[f].inv_scaling : 1.f;
                     if (f < c.n_factors && dp->fs_hi[f] > dp->fs_lo[f]) {
                         const u4 b = philox4x32(env_id, episode_new, (unsigned)f, FWG_STREAM_REWARD_SCALE, A.seed_lo, A.seed_hi);
                         v[i] = 1.f / (dp->fs_lo[f] + (dp->fs_hi[f] - dp->fs_lo[f]) * u01(b.x));
@@ -1852,10 +1876,24 @@ static int lower_config(const fwg_config& c, DevCfg* d, DynCfg* dy, std::string*
 // frozen configurations compiled into this library (host copies for matching)
 #define FWG_SPEC_HOST(i) &kSpecWords##i,
 static const SpecWords* const kSpecTable[] = {FWG_SPEC_LIST(FWG_SPEC_HOST) nullptr};
+static int match_shape(const DevCfg& d) {
+    // a shape instance whose structure is this configuration's?  (merging d's values into the instance gives d back bit for bit)
+#ifndef FWG_EMU   /* (the host emulation reads V(c) as c: frozen and generic kernels only) */
+#define FWG_SHAPE_MATCH(i) { const DevCfg m = merge_values(kSpec##i, &d); if (memcmp(&m, &d, sizeof(DevCfg)) == 0) return FWG_SHAPE_BASE + i; }
+    FWG_SHAPE_LIST(FWG_SHAPE_MATCH)
+#undef FWG_SHAPE_MATCH
+#endif
+    return -1;
+}
 static int match_spec(const DevCfg& d) {
+    // FWGYM_SHAPE=0: never a shape instance (the generic kernel instead, for A/B measurements); =force: the shape instance
+    // even where a frozen configuration matches (tests: the two must agree)
+    const char* env = getenv("FWGYM_SHAPE");
+    if (env != nullptr && env[0] == 'f') { const int s = match_shape(d); if (s >= 0) return s; }
     for (int i = 0; kSpecTable[i] != nullptr; ++i)
         if (memcmp(kSpecTable[i], &d, sizeof(DevCfg)) == 0) return i;
-    return -1;
+    if (env != nullptr && env[0] == '0') return -1;
+    return match_shape(d);
 }
 
 template <bool IS_STEP>
@@ -2174,6 +2212,18 @@ int fwg_num_specs(void) {
     return n;
 }
 
+int fwg_config_instance(const fwg_config* cfg) {
+    if (!cfg) return fail_with(FWG_ERR_INVALID, "null argument");
+    if (cfg->abi_version != FWG_ABI_VERSION || cfg->struct_bytes != sizeof(fwg_config))
+        return fail_with(FWG_ERR_ABI, "fwg_config version/size mismatch");
+    DevCfg d;
+    DynCfg dy;
+    std::string why;
+    if (lower_config(*cfg, &d, &dy, &why) != 0) return fail_with(FWG_ERR_INVALID, why);
+    const int i = match_spec(d);
+    return i < 0 ? FWG_INSTANCE_GENERIC : i;
+}
+
 int fwg_dump_spec(const fwg_config* cfg, uint32_t* words_out, int64_t capacity) {
     if (!cfg || !words_out) return fail_with(FWG_ERR_INVALID, "null argument");
     if (cfg->abi_version != FWG_ABI_VERSION || cfg->struct_bytes != sizeof(fwg_config))
@@ -2196,14 +2246,14 @@ static void launch_one(const fwg_handle* h, const KArgs& A, hipStream_t stream) 
     const size_t lds_bytes = (size_t)lds_map(h->h.obs_dim, h->h.n_obs, h->h.L.window, h->h.use_cmd_ring, SPEC < 0, h->h.obs_log).total * sizeof(float);
     if (IS_STEP) {
 #ifndef FWG_NO_SPLIT
-        if (SPEC >= 0 && h->split) {
+        if (SPEC >= 0 && (h->split || SPEC >= FWG_SHAPE_BASE)) {   // (shape instances exist as the two-wave kernel only)
             const size_t lds2 = (size_t)lds_map(h->h.obs_dim, h->h.n_obs, h->h.L.window, h->h.use_cmd_ring, false, h->h.obs_log, true).total * sizeof(float);
             hipLaunchKernelGGL((k_step2<TURB, (SPEC >= 0 ? SPEC : 0)>), grid, dim3(2 * FWG_WAVE), lds2, stream, h->d_cfg, h->d_dyn, A);
             return;
         }
 #endif
 #ifndef FWG_DEV_FAST_BUILD   /* tools/isa.py -DFWG_DEV_FAST_BUILD: only the two-wave / fused kernels of the frozen configuration */
-        hipLaunchKernelGGL((k_step<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
+        if constexpr (SPEC < FWG_SHAPE_BASE) hipLaunchKernelGGL((k_step<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
 #endif
     } else hipLaunchKernelGGL((k_reset<TURB, SPEC>), grid, block, lds_bytes, stream, h->d_cfg, h->d_dyn, A);
 }
@@ -2214,6 +2264,9 @@ static void launch(const fwg_handle* h, const KArgs& A, hipStream_t stream) {
 #define FWG_SPEC_CASE(i) \
     case i: launch_one<IS_STEP, (kSpec##i.turbulence != 0), i>(h, A, stream); return;
         FWG_SPEC_LIST(FWG_SPEC_CASE)
+#define FWG_SHAPE_CASE(i) \
+    case FWG_SHAPE_BASE + i: launch_one<IS_STEP, (kSpec##i.turbulence != 0), FWG_SHAPE_BASE + i>(h, A, stream); return;
+        FWG_SHAPE_LIST(FWG_SHAPE_CASE)
         default: break;
     }
 #ifndef FWG_DEV_FAST_BUILD

@@ -174,8 +174,77 @@ struct DevCfg {
     float rise_low, rise_high;
     int model_n;   // > 0: simulator.model -- per-env force/moment constants (L.aero), re-sampled at every reset
     int randomize_scaling;   // reward.randomize_scaling -- per-env reward scalings (L.fscale), re-sampled at every reset
+    // shape instances only (see merge_values below): non-zero in the frozen object of a shape instance -- its VALUE members are
+    // not the ones to compute with; zero everywhere else (values and structure in one object).  Second word: reserved.
+    unsigned values_elsewhere, reserved_;
     fwg_layout L;
 };
+// VALUE members are read through V(c): the object itself -- or, in a shape instance, the configuration in device memory, i.e.
+// what the kernel's FIRST argument points at (every kernel that is instantiated per configuration takes the DevCfg pointer
+// first).  The pointer is re-read from the kernel-argument segment here rather than handed down through every signature: a
+// scalar load of a launch constant, and what is read through it is launch-constant too (constant address space: scalar loads
+// at the point of use).  In a frozen or generic kernel the test folds / is one comparison and V(c) is c.
+__device__ __forceinline__ const DevCfg& cfg_values(const DevCfg& c) {
+#if defined(FWG_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+    return c;
+#else
+    if (c.values_elsewhere == 0u) return c;
+    typedef const __attribute__((address_space(4))) unsigned long long* karg_ptr;
+    typedef const __attribute__((address_space(4))) DevCfg* cfg_ptr;
+    const unsigned long long first_arg = *(karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(const DevCfg*)(cfg_ptr)first_arg;
+#endif
+}
+#define V(c) cfg_values(c)
+__host__ __device__ constexpr DevCfg as_shape(DevCfg d) { d.values_elsewhere = 1u; return d; }
+
+// ---- "Shape" instances (fwgym.hip "Specialisation"): a kernel frozen on a configuration's STRUCTURE -- every integer member:
+// counts, types, sources, flags, the arena layout -- that reads the configuration's VALUES -- every float member, and the few
+// integers that are only ever compared (the time limit, the resampling period, the goal-window count) -- from memory.  The
+// function below defines the split: it returns the frozen instance with the value members taken from `r`.  A configuration runs
+// on a shape instance iff merging it into the instance reproduces it bit for bit (match_spec); the kernel itself reads the
+// configuration from memory and is TOLD that its structure words are the instance's (assume_structure, fwgym.hip) -- computing
+// with the merged object instead loads every value up front and keeps them all alive: 45 000 spilled registers, measured.
+// (Keep in step with DevCfg / DevObs / DevTarget / DevFactor: the size check below fails when a member is added.)
+template <class R>
+__host__ __device__ constexpr DevCfg merge_values(DevCfg m, const R* r) {
+    static_assert(sizeof(DevObs) == 24 && sizeof(DevTarget) == 24 && sizeof(DevFactor) == 48, "merge_values: member list out of date");
+    static_assert(sizeof(DevCfg) == 4 * (4 + 2 + 49 + 4 * FWG_N_VARS + 1 + 13 + 1 + FWG_N_DRYDEN * FWG_N_DRYDEN + FWG_N_DRYDEN * 4 + 6 * FWG_N_DRYDEN + 4 +
+                                         6 + 2 + 6 * FWG_MAX_OBS + 1 + 3 + 9 + 1 + 6 + 7 + 6 * FWG_MAX_TARGETS + 2 + 1 + 3 + 3 + 1 + 12 * FWG_MAX_FACTORS +
+                                         4 + 1 + 2 + 1 + 1 + 2) + sizeof(fwg_layout),
+                  "merge_values: member list out of date");
+    m.dt = r->dt; m.h = r->h; m.half_h = r->half_h; m.h_sixth = r->h_sixth;
+#define FWG_MERGE_AERO(n) m.n = r->n;
+    FWG_AERO_LIST(FWG_MERGE_AERO)
+#undef FWG_MERGE_AERO
+    for (int i = 0; i < FWG_N_VARS; ++i) { m.con_min[i] = r->con_min[i]; m.con_max[i] = r->con_max[i]; m.val_min[i] = r->val_min[i]; m.val_max[i] = r->val_max[i]; }
+    for (int a = 0; a < 2; ++a) {
+        for (int i = 0; i < 4; ++i) m.act_phi[a][i] = r->act_phi[a][i];
+        m.act_travel[a] = r->act_travel[a]; m.dot_max[a] = r->dot_max[a];
+    }
+    m.act_ethr = r->act_ethr;
+    for (int i = 0; i < FWG_N_DRYDEN * FWG_N_DRYDEN; ++i) m.dryA[i] = r->dryA[i];
+    for (int i = 0; i < FWG_N_DRYDEN * 4; ++i) m.dryB[i] = r->dryB[i];
+    for (int i = 0; i < 6 * FWG_N_DRYDEN; ++i) m.dryC[i] = r->dryC[i];
+    m.steps_max = r->steps_max;
+    m.obs_noise_mean = r->obs_noise_mean; m.obs_noise_std = r->obs_noise_std;
+    for (int j = 0; j < FWG_MAX_OBS; ++j) { m.obs[j].mean = r->obs[j].mean; m.obs[j].inv_var = r->obs[j].inv_var; }
+    m.scale_low = r->scale_low; m.scale_high = r->scale_high; m.inv_scale_span = r->inv_scale_span;
+    for (int i = 0; i < 3; ++i) {
+        m.act_to_low[i] = r->act_to_low[i]; m.act_to_high[i] = r->act_to_high[i]; m.inv_act_span[i] = r->inv_act_span[i];
+        m.act_bound_min[i] = r->act_bound_min[i]; m.act_bound_max[i] = r->act_bound_max[i];
+        m.term_weight[i] = r->term_weight[i];
+    }
+    m.resample_every = r->resample_every; m.streak_min_count = r->streak_min_count;
+    for (int k = 0; k < FWG_MAX_TARGETS; ++k) m.target[k].bound = r->target[k].bound;
+    m.step_fail_value = r->step_fail_value;
+    for (int f = 0; f < FWG_MAX_FACTORS; ++f) {
+        m.factor[f].sign = r->factor[f].sign; m.factor[f].inv_scaling = r->factor[f].inv_scaling;
+        m.factor[f].max = r->factor[f].max; m.factor[f].value = r->factor[f].value;
+    }
+    m.rise_low = r->rise_low; m.rise_high = r->rise_high;
+    return m;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // math helpers (fp32, gfx950)

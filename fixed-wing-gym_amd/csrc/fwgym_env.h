@@ -627,7 +627,7 @@ __device__ __forceinline__ unsigned goal_flags(const DevCfg& c, const float (&er
 #pragma unroll
     for (int k = 0; k < FWG_MAX_TARGETS; ++k) {
         if (k < c.n_targets && c.target[k].has_bound) {
-            const bool ok = fabsf(err[k]) <= c.target[k].bound;
+            const bool ok = fabsf(err[k]) <= V(c).target[k].bound;
             g |= ok ? (1u << k) : 0u;
             all = all && ok;
         }
@@ -659,7 +659,7 @@ __device__ __forceinline__ void goal_push(const DevCfg& c, Env& E, unsigned g, i
             E.wcnt += (f - ((old >> r) & 1u)) << (8 * r);   // per-byte add/subtract; each byte stays within [0, 128]
             E.gcnt[r >> 1] += f << (16 * (r & 1));
             if (c.metrics && pack16_get(E.settle, r) == 0xFFFFu && n_rec >= (unsigned)c.streak_req &&
-                window_count(E, r) >= (unsigned)c.streak_min_count)
+                window_count(E, r) >= (unsigned)V(c).streak_min_count)
                 pack16_set(E.settle, r, rec_index);
         }
     }
@@ -736,13 +736,13 @@ __device__ __forceinline__ void next_targets(const DevCfg& c, Env& E) {
                 const float va_end = 28.434f - 40.0841f * pt;
                 float slope = 0.f;
                 if (va <= va_end) slope = 7.f * fmaxf(0.f, (va < va_end * 0.95f) ? 1.f : 1.f - va / (va_end * 1.5f));
-                nt[k] = va + (slope * (-pitch_tgt) - 0.25f) * c.dt;
+                nt[k] = va + (slope * (-pitch_tgt) - 0.25f) * V(c).dt;
             } else if (pt >= 0.08726646259971647f) {  // radians(5)
                 const float va_end = 26.27f - 41.2529f * pt;
                 if (va > va_end) nt[k] = (E.sft < 750u) ? va + (va_end - va) * (1.f / 150.f) : va_end;
             }
         } else if (c.any_dynamic_target && t.cls == FWG_TGT_LINEAR) {
-            if (E.tprop[k][1] >= 0.f) nt[k] = E.tgt[k] + E.tprop[k][0] * c.dt;
+            if (E.tprop[k][1] >= 0.f) nt[k] = E.tgt[k] + E.tprop[k][0] * V(c).dt;
         } else if (c.any_dynamic_target && t.cls == FWG_TGT_SINUSOIDAL) {
             if (E.tprop[k][1] >= 0.f)
                 nt[k] = E.tprop[k][0] * sinf(FWG_TWO_PI / E.tprop[k][1] * ((float)E.steps + E.tprop[k][2])) + E.tprop[k][3];
@@ -758,7 +758,7 @@ __device__ __forceinline__ void next_targets(const DevCfg& c, Env& E) {
 // `ring` = this lane's entry of the LDS action window [slot][lane][4] (streamed in with 16-byte global_load_lds).
 __device__ __forceinline__ float backscale_action(const DevCfg& c, int ai, float actuator) {
     if (c.scale_actions)
-        return (c.scale_high - c.scale_low) * (actuator - c.act_to_low[ai]) * c.inv_act_span[ai] + c.scale_low;
+        return (V(c).scale_high - V(c).scale_low) * (actuator - V(c).act_to_low[ai]) * V(c).inv_act_span[ai] + V(c).scale_low;
     return actuator;
 }
 __device__ __forceinline__ float action_obs(const DevCfg& c, const float* ring, int ai, int w, unsigned n_act, int cur_slot,
@@ -806,7 +806,7 @@ __device__ __forceinline__ void build_row0(const DevCfg& c, const KArgs& A, long
     for (int j = 0; j < FWG_MAX_OBS; ++j) {
         padv[j] = 0.f;
         if (j < c.n_obs) {
-            const DevObs& o = c.obs[j];
+            const DevObs& o = c.obs[j]; const DevObs& ov = V(c).obs[j];
             float v;
             if (o.type == FWG_OBS_STATE) v = T.get(o.src);
             else if (o.type == FWG_OBS_TARGET_RELATIVE) v = T.get(FWG_TAB_ERR + o.src);
@@ -815,7 +815,7 @@ __device__ __forceinline__ void build_row0(const DevCfg& c, const KArgs& A, long
             else v = pre_action != nullptr ? pre_action[j]   // already summed while the integration ran (step kernel)
                                            : action_obs(c, ring, o.src, o.window, E.steps, act_slot, T.get(FWG_V_ELEVATOR + o.src));
             float vp = (int_pad != nullptr && o.type == FWG_OBS_TARGET_INTEGRATOR) ? int_pad[o.src] : v;
-            if (o.norm) { v = (v - o.mean) * o.inv_var; vp = (vp - o.mean) * o.inv_var; }
+            if (o.norm) { v = (v - ov.mean) * ov.inv_var; vp = (vp - ov.mean) * ov.inv_var; }
             ob.put(j, v);
             padv[j] = vp;
         }
@@ -912,7 +912,7 @@ __device__ __forceinline__ void early_row_noise(const DevCfg& c, const KArgs& A,
 #pragma unroll
     for (int r = 0; r < FWG_MAX_ROWS; ++r) {
         row_noise[r] = 0.f;
-        if (r >= 1 && r < c.obs_length && r * c.obs_step >= (int)steps) row_noise[r] = rounded((2.f * u01(bits[r]) - 1.f) * c.dt);
+        if (r >= 1 && r < c.obs_length && r * c.obs_step >= (int)steps) row_noise[r] = rounded((2.f * u01(bits[r]) - 1.f) * V(c).dt);
     }
 }
 // the padding rows of one env from its record 0 and the per-row noise, straight into the row log (k_step2, physics wave,
@@ -927,12 +927,12 @@ __device__ __forceinline__ void early_rows_to_log(const DevCfg& c, const KArgs& 
 #pragma unroll
         for (int j = 0; j < FWG_MAX_OBS; ++j) {
             if (j >= c.n_obs) continue;
-            const DevObs& o = c.obs[j];
+            const DevObs& o = c.obs[j]; const DevObs& ov = V(c).obs[j];
             if (o.type == FWG_OBS_ACTION) {
                 v[j] = backscale_action(c, o.src, actuator[o.src]) + noise;
-                if (o.norm) v[j] = (v[j] - o.mean) * o.inv_var;
+                if (o.norm) v[j] = (v[j] - ov.mean) * ov.inv_var;
             } else {
-                v[j] = rec[j] + noise * (o.norm ? o.inv_var : 1.f);
+                v[j] = rec[j] + noise * (o.norm ? ov.inv_var : 1.f);
             }
         }
         float* dst = log_row(c, A.obs, A.N, e, win + r);
@@ -967,12 +967,12 @@ __device__ __forceinline__ void early_rows_pre(const DevCfg& c, const KArgs& A, 
     for (int r = 1; r < FWG_MAX_ROWS; ++r) {
         row_noise[r] = 0.f;
         if (r >= c.obs_length || r * c.obs_step < t) continue;
-        const float noise = rounded((2.f * u01(bits[r]) - 1.f) * c.dt);
+        const float noise = rounded((2.f * u01(bits[r]) - 1.f) * V(c).dt);
         row_noise[r] = noise;
 #pragma unroll
         for (int j = 0; j < FWG_MAX_OBS; ++j)
             if (j < c.n_obs && c.obs[j].type != FWG_OBS_ACTION)
-                ob.put(r * c.n_obs + j, rec[j] + noise * (c.obs[j].norm ? c.obs[j].inv_var : 1.f));
+                ob.put(r * c.n_obs + j, rec[j] + noise * (c.obs[j].norm ? V(c).obs[j].inv_var : 1.f));
     }
 }
 template <class TAB, class OB>
@@ -990,27 +990,27 @@ __device__ __forceinline__ void fix_lagged_rows(const DevCfg& c, const KArgs& A,
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j) {
                 if (j >= c.n_obs || c.obs[j].type != FWG_OBS_ACTION) continue;
-                const DevObs& o = c.obs[j];
+                const DevObs& o = c.obs[j]; const DevObs& ov = V(c).obs[j];
                 float v = backscale_action(c, o.src, T.get(FWG_V_ELEVATOR + o.src)) + pre_noise[r];
-                if (o.norm) v = (v - o.mean) * o.inv_var;
+                if (o.norm) v = (v - ov.mean) * ov.inv_var;
                 ob.put(r * c.n_obs + j, v);
             }
         } else if (lag >= t) {
-            const float noise = rounded((2.f * u01(bits[r]) - 1.f) * c.dt);
+            const float noise = rounded((2.f * u01(bits[r]) - 1.f) * V(c).dt);
             int slot0 = A.slot_lag - t; slot0 += (slot0 < 0) ? depth : 0;  // ring slot of the episode's record 0
             if (c.obs_log > 0) slot0 = 0;   // row-log mode: the ring has one slot and holds exactly that record
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j) {
                 if (j >= c.n_obs) continue;
-                const DevObs& o = c.obs[j];
+                const DevObs& o = c.obs[j]; const DevObs& ov = V(c).obs[j];
                 float v;
                 if (o.type == FWG_OBS_ACTION) {
                     v = backscale_action(c, o.src, T.get(FWG_V_ELEVATOR + o.src)) + noise;
-                    if (o.norm) v = (v - o.mean) * o.inv_var;
+                    if (o.norm) v = (v - ov.mean) * ov.inv_var;
                 } else {
                     const float q = lag_entry(c, A, e, slot0, j);
                     FWG_TOUCH(q);   // (waited for HERE, inside the rare branch)
-                    v = q + noise * (o.norm ? o.inv_var : 1.f);
+                    v = q + noise * (o.norm ? ov.inv_var : 1.f);
                 }
                 ob.put(r * c.n_obs + j, v);
             }
@@ -1043,7 +1043,7 @@ __device__ __forceinline__ void add_obs_noise(const DevCfg& c, const KArgs& A, l
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = blk * 4 + i;
-            if (k < c.obs_dim) ob.put(k, ob.get(k) + c.obs_noise_mean + c.obs_noise_std * n[i]);
+            if (k < c.obs_dim) ob.put(k, ob.get(k) + V(c).obs_noise_mean + V(c).obs_noise_std * n[i]);
         }
     }
 }
@@ -1172,7 +1172,7 @@ __device__ __forceinline__ void finish_metrics(const DevCfg& c, const FinRec& R,
         mt[FWG_M_AVG_ERROR + k] = fabsf(R.e0[k]) >= 0.01f ? fabsf(fast_div(R.esum[k], (float)R.n_rec * R.e0[k])) : NAN;
         mt[FWG_M_END_ERROR + k] = fabsf(fast_div(R.end_sum[k], (float)end_cnt));
     }
-    mt[FWG_M_CONTROL_VARIATION] = fast_div(R.sdcmd, 3.f * c.dt * (float)(R.steps - 1u));
+    mt[FWG_M_CONTROL_VARIATION] = fast_div(R.sdcmd, 3.f * V(c).dt * (float)(R.steps - 1u));
     if (c.goal_enabled) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1272,10 +1272,10 @@ __device__ __forceinline__ void draw_state(const DevCfg& c, const float (&v0)[FW
 #pragma unroll
     for (int i = 0; i < 9; ++i) D.y[4 + i] = v0[FWG_V_OMEGA_P + i];
     {
-        const float el = fclampf(v0[FWG_V_ELEVATOR], c.val_min[FWG_V_ELEVATOR], c.val_max[FWG_V_ELEVATOR]);
-        const float ai = fclampf(v0[FWG_V_AILERON], c.val_min[FWG_V_AILERON], c.val_max[FWG_V_AILERON]);
+        const float el = fclampf(v0[FWG_V_ELEVATOR], V(c).val_min[FWG_V_ELEVATOR], V(c).val_max[FWG_V_ELEVATOR]);
+        const float ai = fclampf(v0[FWG_V_AILERON], V(c).val_min[FWG_V_AILERON], V(c).val_max[FWG_V_AILERON]);
         D.y[13] = el - ai; D.y[14] = el + ai;
-        D.y[15] = fclampf(v0[FWG_V_THROTTLE], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
+        D.y[15] = fclampf(v0[FWG_V_THROTTLE], V(c).val_min[FWG_V_THROTTLE], V(c).val_max[FWG_V_THROTTLE]);
         D.y[16] = 0.f; D.y[17] = 0.f;
     }
 #pragma unroll
@@ -1334,7 +1334,7 @@ __device__ __forceinline__ void draw_row_noise(const DevCfg& c, const KArgs& A, 
 #pragma unroll
     for (int r = 0; r < FWG_MAX_ROWS; ++r) {
         D.row_noise[r] = 0.f;
-        if (c.obs_length > 1 && r < c.obs_length) D.row_noise[r] = (2.f * u01(bits[r]) - 1.f) * c.dt;
+        if (c.obs_length > 1 && r < c.obs_length) D.row_noise[r] = (2.f * u01(bits[r]) - 1.f) * V(c).dt;
     }
 }
 
@@ -1518,14 +1518,14 @@ __device__ __forceinline__ void reset_rows_to_log(const DevCfg& c, const KArgs& 
                 if (4 * q < c.n_obs) {
                     float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = row.get(4 * q + i) + noise * (c.obs[4 * q + i].norm ? c.obs[4 * q + i].inv_var : 1.f);
+                    for (int i = 0; i < 4; ++i) v[i] = row.get(4 * q + i) + noise * (c.obs[4 * q + i].norm ? V(c).obs[4 * q + i].inv_var : 1.f);
                     reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j)
-                if (j < c.n_obs) dst[j] = row.get(j) + noise * (c.obs[j].norm ? c.obs[j].inv_var : 1.f);
+                if (j < c.n_obs) dst[j] = row.get(j) + noise * (c.obs[j].norm ? V(c).obs[j].inv_var : 1.f);
         }
     }
 }
@@ -1635,7 +1635,7 @@ __device__ __forceinline__ void reset_finish(const DevCfg& c, const KArgs& A, lo
             const float noise = D.row_noise[r];
 #pragma unroll
             for (int j = 0; j < FWG_MAX_OBS; ++j)
-                if (j < c.n_obs) ob.put(r * c.n_obs + j, ob.get(j) + noise * (c.obs[j].norm ? c.obs[j].inv_var : 1.f));
+                if (j < c.n_obs) ob.put(r * c.n_obs + j, ob.get(j) + noise * (c.obs[j].norm ? V(c).obs[j].inv_var : 1.f));
         }
     }
     if (c.obs_noise) add_obs_noise(c, A, e, E, ob);

@@ -38,7 +38,7 @@ __device__ __forceinline__ Air airspeed(const Rot& R, float u, float v, float w,
 
 __device__ __forceinline__ void check_var(const DevCfg& c, int& fail, int var, float x) {
     if (c.con_mask & (1u << var)) {
-        const bool bad = (x < c.con_min[var]) | (x > c.con_max[var]);
+        const bool bad = (x < V(c).con_min[var]) | (x > V(c).con_max[var]);
         fail = (fail == 0 && bad) ? var + 1 : fail;
     }
 }
@@ -79,16 +79,16 @@ struct DeferredChecks {
         for (int var = 0; var < FWG_CHK_VARS; ++var) {
             if (!(c.con_mask & (1u << var))) continue;
             const int first = var < FWG_V_OMEGA_P ? FWG_CHK_POINTS - 1 : 0;   // Euler angles: end of the step only
-            if (c.con_min[var] == -c.con_max[var]) {
+            if (V(c).con_min[var] == -V(c).con_max[var]) {
                 float m = fabsf(v[first][var]);
 #pragma unroll
                 for (int k = first + 1; k < FWG_CHK_POINTS; ++k) m = fmaxf(m, fabsf(v[k][var]));
-                any = any || (m > c.con_max[var]);
+                any = any || (m > V(c).con_max[var]);
             } else {
                 float hi = v[first][var], lo = v[first][var];
 #pragma unroll
                 for (int k = first + 1; k < FWG_CHK_POINTS; ++k) { hi = fmaxf(hi, v[k][var]); lo = fminf(lo, v[k][var]); }
-                any = any || (hi > c.con_max[var]) || (lo < c.con_min[var]);
+                any = any || (hi > V(c).con_max[var]) || (lo < V(c).con_min[var]);
             }
         }
         int fail = 0;
@@ -144,7 +144,7 @@ __device__ __forceinline__ RhsFree rhs_free(const DevCfg& c, const AP& a_, const
         ck.put(c, FWG_V_BETA, a.beta);
     }
     ck.next();
-    const float Va = fclampf(a.Va, c.val_min[FWG_V_VA], c.val_max[FWG_V_VA]);
+    const float Va = fclampf(a.Va, V(c).val_min[FWG_V_VA], V(c).val_max[FWG_V_VA]);
     float pa = p, qa = q, ra = r;
     if (TURB) { pa -= gust[3]; qa -= gust[4]; ra -= gust[5]; }
 
@@ -227,48 +227,48 @@ __device__ __forceinline__ void advance_actuators(const DevCfg& c, float (&a)[5]
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 spv = {sp[0], sp[1]}, val = {a[0], a[1]}, rate = {a[3], a[4]};
     const f2 x0 = val - spv;
-    const f2 p0 = {c.act_phi[0][0], c.act_phi[1][0]}, p1 = {c.act_phi[0][1], c.act_phi[1][1]};
-    const f2 p2 = {c.act_phi[0][2], c.act_phi[1][2]}, p3 = {c.act_phi[0][3], c.act_phi[1][3]};
+    const f2 p0 = {V(c).act_phi[0][0], V(c).act_phi[1][0]}, p1 = {V(c).act_phi[0][1], V(c).act_phi[1][1]};
+    const f2 p2 = {V(c).act_phi[0][2], V(c).act_phi[1][2]}, p3 = {V(c).act_phi[0][3], V(c).act_phi[1][3]};
     const f2 v = spv + p0 * x0 + p1 * rate;
     const f2 d = p2 * x0 + p3 * rate;
-    const f2 trav = {c.act_travel[0], c.act_travel[1]};
+    const f2 trav = {V(c).act_travel[0], V(c).act_travel[1]};
     const f2 lo = val - trav, hi = val + trav;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        a[3 + k] = fclampf(d[k], -c.dot_max[k], c.dot_max[k]);
-        a[k] = fclampf(fclampf(v[k], lo[k], hi[k]), c.val_min[FWG_V_ELEVON_RIGHT + k], c.val_max[FWG_V_ELEVON_RIGHT + k]);
+        a[3 + k] = fclampf(d[k], -V(c).dot_max[k], V(c).dot_max[k]);
+        a[k] = fclampf(fclampf(v[k], lo[k], hi[k]), V(c).val_min[FWG_V_ELEVON_RIGHT + k], V(c).val_max[FWG_V_ELEVON_RIGHT + k]);
     }
 #else
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float x0 = a[k] - sp[k], x1 = a[3 + k];
-        float v = sp[k] + c.act_phi[k][0] * x0 + c.act_phi[k][1] * x1;
-        float d = c.act_phi[k][2] * x0 + c.act_phi[k][3] * x1;
-        d = fclampf(d, -c.dot_max[k], c.dot_max[k]);
-        v = fclampf(v, a[k] - c.act_travel[k], a[k] + c.act_travel[k]);
-        a[k] = fclampf(v, c.val_min[FWG_V_ELEVON_RIGHT + k], c.val_max[FWG_V_ELEVON_RIGHT + k]);
+        float v = sp[k] + V(c).act_phi[k][0] * x0 + V(c).act_phi[k][1] * x1;
+        float d = V(c).act_phi[k][2] * x0 + V(c).act_phi[k][3] * x1;
+        d = fclampf(d, -V(c).dot_max[k], V(c).dot_max[k]);
+        v = fclampf(v, a[k] - V(c).act_travel[k], a[k] + V(c).act_travel[k]);
+        a[k] = fclampf(v, V(c).val_min[FWG_V_ELEVON_RIGHT + k], V(c).val_max[FWG_V_ELEVON_RIGHT + k]);
         a[3 + k] = d;
     }
 #endif
-    a[2] = fclampf(sp[2] + c.act_ethr * (a[2] - sp[2]), c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
+    a[2] = fclampf(sp[2] + V(c).act_ethr * (a[2] - sp[2]), V(c).val_min[FWG_V_THROTTLE], V(c).val_max[FWG_V_THROTTLE]);
 }
 
 __device__ __forceinline__ void sanitize_actuators(const DevCfg& c, float (&a)[5]) {
-    a[0] = fclampf(a[0], c.val_min[FWG_V_ELEVON_RIGHT], c.val_max[FWG_V_ELEVON_RIGHT]);
-    a[1] = fclampf(a[1], c.val_min[FWG_V_ELEVON_LEFT], c.val_max[FWG_V_ELEVON_LEFT]);
-    a[2] = fclampf(a[2], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
-    a[3] = fclampf(a[3], -c.dot_max[0], c.dot_max[0]);
-    a[4] = fclampf(a[4], -c.dot_max[1], c.dot_max[1]);
+    a[0] = fclampf(a[0], V(c).val_min[FWG_V_ELEVON_RIGHT], V(c).val_max[FWG_V_ELEVON_RIGHT]);
+    a[1] = fclampf(a[1], V(c).val_min[FWG_V_ELEVON_LEFT], V(c).val_max[FWG_V_ELEVON_LEFT]);
+    a[2] = fclampf(a[2], V(c).val_min[FWG_V_THROTTLE], V(c).val_max[FWG_V_THROTTLE]);
+    a[3] = fclampf(a[3], -V(c).dot_max[0], V(c).dot_max[0]);
+    a[4] = fclampf(a[4], -V(c).dot_max[1], V(c).dot_max[1]);
 }
 
 // elevator/aileron/throttle commands -> constrained inputs (the "command" history of the reference,
 // fixed_wing.py:828,1110) and the elevon/throttle set-points of the actuator dynamics
 __device__ __forceinline__ void constrain_commands(const DevCfg& c, const float (&cmd)[3], float (&cmd_c)[3], float (&sp)[3]) {
-    const float e = fclampf(cmd[0], c.val_min[FWG_V_ELEVATOR], c.val_max[FWG_V_ELEVATOR]);
-    const float a = fclampf(cmd[1], c.val_min[FWG_V_AILERON], c.val_max[FWG_V_AILERON]);
-    const float t = fclampf(cmd[2], c.val_min[FWG_V_THROTTLE], c.val_max[FWG_V_THROTTLE]);
-    const float er = fclampf(e - a, c.val_min[FWG_V_ELEVON_RIGHT], c.val_max[FWG_V_ELEVON_RIGHT]);
-    const float el = fclampf(e + a, c.val_min[FWG_V_ELEVON_LEFT], c.val_max[FWG_V_ELEVON_LEFT]);
+    const float e = fclampf(cmd[0], V(c).val_min[FWG_V_ELEVATOR], V(c).val_max[FWG_V_ELEVATOR]);
+    const float a = fclampf(cmd[1], V(c).val_min[FWG_V_AILERON], V(c).val_max[FWG_V_AILERON]);
+    const float t = fclampf(cmd[2], V(c).val_min[FWG_V_THROTTLE], V(c).val_max[FWG_V_THROTTLE]);
+    const float er = fclampf(e - a, V(c).val_min[FWG_V_ELEVON_RIGHT], V(c).val_max[FWG_V_ELEVON_RIGHT]);
+    const float el = fclampf(e + a, V(c).val_min[FWG_V_ELEVON_LEFT], V(c).val_max[FWG_V_ELEVON_LEFT]);
     cmd_c[0] = 0.5f * (er + el); cmd_c[1] = 0.5f * (el - er); cmd_c[2] = t;
     sp[0] = er; sp[1] = el; sp[2] = t;
 }
@@ -413,8 +413,8 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, const AP& aero, float (
             const float th = (st == 0) ? a[2] : ((st == 3) ? a_full[2] : a_half[2]);
             rhs_act(aero, f, er, el, th, k);
             if (s == 0) hook(st);
-            const float bw = (st == 0 || st == 3) ? c.h_sixth : 2.f * c.h_sixth;
-            const float aw = (st == 2) ? c.h : c.half_h;
+            const float bw = (st == 0 || st == 3) ? V(c).h_sixth : 2.f * V(c).h_sixth;
+            const float aw = (st == 2) ? V(c).h : V(c).half_h;
 #pragma unroll
             for (int i = 0; i + 1 < NB; i += 2) {   // the update on pairs (NB is odd: the last state alone)
                 const f2 kk = mk2(k[i], k[i + 1]);
@@ -490,7 +490,7 @@ __device__ __forceinline__ int sim_step(const DevCfg& c, const AP& aero, float (
 // is block structured -- states u(0) | v,r(1..3) | w,q(4..6) | p(7), one noise channel per block -- so only the
 // non-zero blocks of the dense matrices are evaluated (config.py dryden_matrices / oracle physics.dryden_continuous).
 __device__ __forceinline__ void dryden_output(const DevCfg& c, const float (&x)[FWG_N_DRYDEN], float (&gust)[6]) {
-    const float* C = c.dryC;
+    const float* C = V(c).dryC;
     gust[0] = C[0 * 8 + 0] * x[0];
     gust[1] = C[1 * 8 + 1] * x[1] + C[1 * 8 + 2] * x[2] + C[1 * 8 + 3] * x[3];
     gust[2] = C[2 * 8 + 4] * x[4] + C[2 * 8 + 5] * x[5] + C[2 * 8 + 6] * x[6];
@@ -499,8 +499,8 @@ __device__ __forceinline__ void dryden_output(const DevCfg& c, const float (&x)[
     gust[5] = C[5 * 8 + 1] * x[1] + C[5 * 8 + 2] * x[2] + C[5 * 8 + 3] * x[3];
 }
 __device__ __forceinline__ void dryden_advance(const DevCfg& c, float (&x)[FWG_N_DRYDEN], const float (&n)[4]) {
-    const float* A = c.dryA;
-    const float* B = c.dryB;
+    const float* A = V(c).dryA;
+    const float* B = V(c).dryB;
     float xn[FWG_N_DRYDEN];
     xn[0] = A[0] * x[0] + B[0 * 4 + 0] * n[0];
 #pragma unroll

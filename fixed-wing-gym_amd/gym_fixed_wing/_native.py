@@ -143,11 +143,15 @@ class NativeError(RuntimeError):
     pass
 
 
+INSTANCE_SHAPE = 1000       # include/fwgym.h FWG_INSTANCE_SHAPE: fwg_spec_index / fwg_config_instance values from here on are shape instances
+INSTANCE_GENERIC = 100000   # FWG_INSTANCE_GENERIC (fwg_config_instance only)
+
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libfwgym.so")
 EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fwg_update_config", "fwg_seed",
            "fwg_reset", "fwg_step", "fwg_check_actions", "fwg_reduce_success", "fwg_global_step", "fwg_last_error",
-           "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index", "fwg_set_graph_mode", "fwg_note_replayed_steps",
+           "fwg_dump_spec", "fwg_num_specs", "fwg_spec_index", "fwg_config_instance", "fwg_set_graph_mode", "fwg_note_replayed_steps",
            "fwg_capture_begin", "fwg_capture_end", "fwg_capture_parity", "fwg_replay_check", "fwg_finish_episodes", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
            "fwg_actor_set_stats", "fwg_actor_get_stats", "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe",
            "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window", "fwg_reduce_success_device",
@@ -193,6 +197,8 @@ def load_library(path=None):
     lib.fwg_dump_spec.argtypes = [C.POINTER(Config), C.POINTER(C.c_uint32), i64]
     lib.fwg_dump_spec.restype = C.c_int
     lib.fwg_num_specs.restype = C.c_int
+    lib.fwg_config_instance.argtypes = [C.POINTER(Config)]
+    lib.fwg_config_instance.restype = C.c_int
     lib.fwg_spec_index.argtypes = [vp]
     lib.fwg_spec_index.restype = C.c_int
     lib.fwg_set_graph_mode.argtypes = [vp, C.c_int, vp]

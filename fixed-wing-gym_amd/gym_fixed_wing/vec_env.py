@@ -141,22 +141,27 @@ class FixedWingVecEnv(object):
             obs_log_rows = _presets.OBS_LOG_ROWS if self._row_log_applies() else 0
         self.obs_log_rows = int(obs_log_rows)
         self._c = ec.compile(auto_reset=auto_reset, store_derived=self.derived_views, obs_log_rows=self.obs_log_rows)
-        # Configurations outside the build-time presets run the GENERIC kernel -- it interprets the configuration (scalar
-        # loads, LDS tables, ~4 KB of scratch per lane) and takes about five times as long per step -- unless a specialised
-        # copy of the library is compiled for them (jit.py: hipcc, one to two minutes once per distinct configuration, cached
-        # by content hash).  Default: compile whenever hipcc is on the machine; specialize=False / FWGYM_JIT=0 keep the
-        # generic kernel (FWGYM_JIT=1 insists).  Either way the choice is announced: nobody should find out from a profile.
+        # Three tiers (include/fwgym.h fwg_spec_index): a configuration that IS one of the build-time presets runs its frozen
+        # kernel; one that differs from a preset in VALUES only (scalings, normalisation, constraints, aircraft constants, noise,
+        # the time limit ...) runs that preset's SHAPE instance, ~1.1x the frozen kernel's step time, nothing to compile; anything
+        # else -- another observation layout, another set of reward factors -- runs the GENERIC kernel, which interprets the
+        # configuration (scalar loads, LDS tables, ~4 KB of scratch per lane: ~35x per step at 65 536 envs) unless a specialised
+        # copy of the library is compiled for it (jit.py: hipcc, one to two minutes once per distinct configuration, cached by
+        # content hash).  Default: compile whenever hipcc is on the machine and only the generic kernel is left; specialize=True /
+        # FWGYM_JIT=1 compile for a shape-instance configuration too (the last 10 %); specialize=False / FWGYM_JIT=0 never
+        # compile.  The generic kernel is announced either way: nobody should find out from a profile.
         # (Batches below 1 024 envs -- the single-env class, unit tests -- are bound by launch and host overhead whatever the
         # kernel: they keep the generic kernel silently unless asked.)
         big = self.num_envs >= 1024
+        insist = specialize is True
         if specialize is None:
             env_jit = os.environ.get("FWGYM_JIT")
             if env_jit is not None:
-                specialize = env_jit == "1"
+                specialize = insist = env_jit == "1"
             else:
                 from . import jit as _jit
                 specialize = big and _jit.hipcc_path() is not None
-        if _lib_path is None and (specialize or big) and not self._preset_matches():
+        if _lib_path is None and (specialize or big) and not self._preset_matches(shape_ok=not insist):
             path = None
             if specialize:
                 from . import jit
@@ -230,26 +235,13 @@ class FixedWingVecEnv(object):
         self.env_config.set_curriculum_level(level)
         self._upload()
 
-    def _preset_matches(self):
-        import ctypes as C
-        n = self._lib.fwg_num_specs()
-        if n == 0:
-            return False
-        from . import specialize as sp
-        return sp.spec_words(self._lib, self.env_config, self.auto_reset, self.derived_views, self.obs_log_rows) in self._preset_words()
-
-    def _preset_words(self):
-        cache = FixedWingVecEnv.__dict__.get("_preset_cache")
-        if cache is None:
-            import copy
-            from . import presets, specialize as sp
-            cache = []
-            for name, kind, ckw, skw in presets.SPECIALISED:
-                ec = EnvConfig(presets.preset(kind), config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
-                cache.append(sp.spec_words(self._lib, ec, True, "_lean" not in name,
-                                           presets.OBS_LOG_ROWS if name.endswith("_log") else 0))
-            FixedWingVecEnv._preset_cache = cache
-        return cache
+    def _preset_matches(self, shape_ok=True):
+        """Does this library hold a kernel instance for the configuration: a frozen one, or (shape_ok) a shape instance?"""
+        import ctypes
+        inst = int(self._lib.fwg_config_instance(ctypes.byref(self._c)))
+        if inst < 0:
+            nat.check(self._lib, inst)
+        return inst < (nat.INSTANCE_SHAPE if not shape_ok else nat.INSTANCE_GENERIC)
 
     def set_graph_mode(self, enable=True, obs="view"):
         """Keeps the global step counter on the device so that a captured sequence of step launches (hipGraph /

@@ -349,9 +349,20 @@ int fwg_reduce_success_device(fwg_handle* h, float* out_dev, void* stream);
  * build freezes such word lists into constexpr objects, see csrc/fwgym.hip "Specialisation").  Returns the number of
  * words, or a negative fwg_status. */
 int fwg_dump_spec(const fwg_config* cfg_host, uint32_t* words_out_host, int64_t capacity);
-/* Number of frozen configurations compiled into this library, and the one a handle runs (-1 = generic kernel). */
+/* Number of frozen configurations compiled into this library, and the kernel instance a handle runs: -1 = the generic
+ * kernel (configuration interpreted at run time), i in [0, fwg_num_specs()) = frozen configuration i, FWG_INSTANCE_SHAPE + i =
+ * the SHAPE instance of frozen configuration i -- the same structure (every count, type, source, flag: the integer members of
+ * the lowered configuration) with the configuration's own VALUES (reward scalings, normalisation, constraints, aircraft
+ * constants, noise levels, the time limit ...) read from memory: what a configuration that differs from a frozen one in values
+ * only runs without any run-time compilation, ~1.1x the frozen kernel's step time (the generic kernel: ~35x). */
 int fwg_num_specs(void);
 int fwg_spec_index(const fwg_handle* h);
+#define FWG_INSTANCE_SHAPE 1000
+#define FWG_INSTANCE_GENERIC 100000
+/* The instance fwg_create would pick for this configuration (pure host function): as fwg_spec_index, but FWG_INSTANCE_GENERIC
+ * for the generic kernel, so that negative values stay fwg_status codes.  Replaces nothing in the reference (its env is
+ * interpreted Python throughout); lets a host decide whether compiling a specialised kernel at run time is worth it. */
+int fwg_config_instance(const fwg_config* cfg_host);
 
 /* hipGraph support.  The ring positions of a launch depend on the global step counter; in graph mode that counter
  * lives on the device (each step launch publishes counter+1), so a captured sequence of fwg_step launches can be

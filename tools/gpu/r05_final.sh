@@ -11,7 +11,7 @@ timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r05f/bench_defaul
 timeout 900 python bench.py > gpurun_out/r05f/bench_noflags.json 2> gpurun_out/r05f/bench_noflags.err
 timeout 300 python bench.py --workload c5 --steps 20 --warmup 4 --no-cpu-baseline > gpurun_out/r05f/bench_c5.json 2> gpurun_out/r05f/bench_c5.err
 timeout 300 python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-side > gpurun_out/r05f/bench_2000.json 2> gpurun_out/r05f/bench_2000.err
-TL_LIB=libfwgym_e4_tl.so TL_WL=c3:log TL_STAGGER=2000 TL_PERM=1 timeout 300 python tools/timeline.py run 2>&1 | grep -v "Warn\|^/\|return fnb" > gpurun_out/r05f/timeline_log.txt
+TL_LIB=libfwgym_final_tl.so TL_WL=c3:log TL_STAGGER=2000 TL_PERM=1 timeout 300 python tools/timeline.py run 2>&1 | grep -v "Warn\|^/\|return fnb" > gpurun_out/r05f/timeline_log.txt
 timeout 700 python tests/soak_suite_context.py 600 gpurun_out/r05f/soak 2>&1 | grep -v Warn | tail -5 > gpurun_out/r05f/soak.txt
 cat gpurun_out/r05f/soak.txt
 ls -la gpurun_out/prof_r05 gpurun_out/prof_r05_dense gpurun_out/prof_fused 2>/dev/null | head -30
