@@ -525,6 +525,10 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         if (__ballot(fail != 0) != 0ull) {   // (rare) state was left untouched: derived values of the last valid state
             if (fail != 0) {
                 E.d = derive<TURB>(E.y, E.wind, gust);
+                if (TURB) {   // (air data: as the last committed step left them -- derived with its gust, see store_sim)
+                    const float4 q = CGROUP(A.S, A.N, (c.L.derived >> 2) + 1, e);
+                    E.d.alpha = q.x; E.d.beta = q.y; E.d.Va = q.z;
+                }
                 if (SPLIT) {   // ... which replace, for the partner, what the failing lane sent before it knew
                     float4* h4 = reinterpret_cast<float4*>(hand);
                     h4[0] = make_float4(E.y[4], E.y[5], E.y[6], E.y[7]);

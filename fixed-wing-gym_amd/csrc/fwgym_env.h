@@ -502,10 +502,11 @@ __device__ __forceinline__ void store_sim(const DevCfg& c, float* __restrict__ S
 #pragma unroll
     for (int g = 0; g < 8; ++g)
         if (g < (TURB ? (c.turb_increment ? 8 : 7) : 5)) GROUP(S, N, g0 + g, e) = make_float4(f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
-    if (c.store_derived) {  // derived values of the committed state: only for host views (controllers, rendering)
-        GROUP(S, N, (c.L.derived >> 2), e) = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
-        GROUP(S, N, (c.L.derived >> 2) + 1, e) = make_float4(E.d.alpha, E.d.beta, 0.f, 0.f);
-    }
+    // derived values of the committed state: for host views (controllers, rendering) -- and, with turbulence, the air data for
+    // the kernel itself: after a FAILED step the simulator's Va / alpha / beta stay what the last committed step left (PyFly does
+    // not touch its state objects then), i.e. values derived with THAT step's gust, which is gone by the time the failure is known
+    if (c.store_derived) GROUP(S, N, (c.L.derived >> 2), e) = make_float4(E.d.roll, E.d.pitch, E.d.yaw, E.d.Va);
+    if (c.store_derived || TURB) GROUP(S, N, (c.L.derived >> 2) + 1, e) = make_float4(E.d.alpha, E.d.beta, E.d.Va, 0.f);
 }
 __device__ __forceinline__ void store_cold(const DevCfg& c, float* __restrict__ S, long N, long e, const Env& E) {
     GROUP(S, N, (c.L.cold >> 2), e) = make_float4(E.wind[0], E.wind[1], E.wind[2], u2f(E.episode));

@@ -205,6 +205,34 @@ def test_two_wave_kernel_through_foreseen_episode_ends_emulated(layout, n):
     vec.close()
 
 
+def test_failed_steps_under_turbulence_keep_the_committed_air_data(emu_lib):
+    """A failed simulator step leaves PyFly's state objects untouched: Va / alpha / beta in the terminal observation are the
+    values the last COMMITTED step derived -- with that step's gust, not the failed step's.  (Rounds 1-5 re-derived them with the
+    current gust: 0.06-0.15 m/s off in Va whenever a step failed under turbulence; found by the first oracle test that combined
+    tight rate constraints, Dryden turbulence and an airspeed observation.)  The kernel keeps the three values with the simulator
+    rows (store_sim) and reads them back in the failure branch."""
+    cfg = configs.reference_like("cnn")
+    ckw = {"observation": {"step": 2}, "steps_max": 45, "simulator": {"states": {6: {"constraint_min": -60, "constraint_max": 60}}}}
+    skw = {"turbulence": True, "turbulence_intensity": "moderate"}
+    n, steps = 70, 60
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1.3, 1.3, (steps, n, 3)).astype(np.float32)
+    import copy
+    from emu.host_backend import build_emu_spec
+    from gym_fixed_wing.config import EnvConfig
+    from gym_fixed_wing import presets
+    ec = EnvConfig(copy.deepcopy(cfg), config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
+    two_wave = build_emu_spec(ec, auto_reset=True, store_derived=True, obs_log_rows=presets.OBS_LOG_ROWS)   # k_step2: the OLD message carries them
+    for rows, lib in ((0, emu_lib), (12, emu_lib), (presets.OBS_LOG_ROWS, two_wave)):
+        vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True, _backend=HostBackend(),
+                              _lib_path=lib, obs_log_rows=rows)
+        assert (vec.spec_index == 0) == (lib is two_wave)
+        orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
+        res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3)
+        assert res["episodes"] >= n and res["terminations"].get("omega_p", 0) >= 10, res["terminations"]
+        vec.close()
+
+
 def test_uncollected_episode_records_are_folded_not_lost(emu_lib):
     """Episode ends park a record; fwg_finish_episodes / fwg_reduce_success* turn it into metrics and success sums.  An env
     that ends a SECOND episode before any collection folds the first record itself (fin_collect_pending): the sums of a run

@@ -24,7 +24,15 @@ def _emu_env(cfg, n, rows, **kw):
 
 
 def _gpu_env(cfg, n, rows, **kw):
-    return FixedWingVecEnv(copy.deepcopy(cfg), num_envs=n, device=0, as_numpy=True, obs_log_rows=rows, seed=3, **kw)
+    # (bitwise comparison of the two layouts ON THE SAME KERNEL TIER: the dense variant of these configurations differs from a
+    # preset in values only and would land on its shape instance, the 32-row log on the generic kernel; both generic here --
+    # the frozen kernels' layouts are compared in test_log_window_specialised_kernel_on_gpu)
+    import os
+    os.environ["FWGYM_SHAPE"] = "0"
+    try:
+        return FixedWingVecEnv(copy.deepcopy(cfg), num_envs=n, device=0, as_numpy=True, obs_log_rows=rows, seed=3, **kw)
+    finally:
+        os.environ.pop("FWGYM_SHAPE", None)
 
 
 def run_log_vs_dense(mk, n, rows, steps, config_kw, sim_kw=None, auto_reset=True, scale=1.0, burst=2.5):
@@ -129,9 +137,10 @@ def test_log_window_specialised_kernel_on_gpu():
 
 
 @pytest.mark.gpu
-def test_log_window_under_graph_replay_on_gpu():
+def test_log_window_under_graph_replay_on_gpu(monkeypatch):
     """Row-log positions come from the device-resident step counter under hipGraph replay; the host view follows."""
     import torch
+    monkeypatch.setenv("FWGYM_SHAPE", "0")   # (bitwise comparison: both layouts on the generic kernel, see _gpu_env)
     cfg = configs.reference_like("cnn")
     kw = dict(config_kw={"observation": {"step": 2}, "steps_max": 50}, sim_config_kw=copy.deepcopy(TURB), seed=9)
     dense = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=512, device=0, obs_log_rows=0, **copy.deepcopy(kw))

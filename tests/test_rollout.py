@@ -238,13 +238,14 @@ def test_fused_rollout_on_a_row_log_env_equals_the_dense_one():
 
 
 @pytest.mark.gpu
-def test_graphed_rollout_on_row_log_env_matches_dense_over_replays_on_gpu():
+def test_graphed_rollout_on_row_log_env_matches_dense_over_replays_on_gpu(monkeypatch):
     """A captured rollout on a row-log env must keep reading the CURRENT window on every replay: the window position has
     period obs_step * (L - length + 1) = 56 steps for L = 32, the captured chunk is 10 steps, so replays 2.. would read
     stale planes if the position were baked in at capture time.  The head reads it on the device (fwg_actor_set_obs_log)."""
     import copy
     from gym_fixed_wing.actor import DeviceActor
     from gym_fixed_wing.rollout import FusedRollout
+    monkeypatch.setenv("FWGYM_SHAPE", "0")   # (both layouts on the same kernel tier: the dense one would land on a shape instance)
     cfg = configs.reference_like("cnn")
     turb = {"turbulence": True, "turbulence_intensity": "moderate"}
     runs = []
