@@ -2,7 +2,7 @@
 # trace, bench lines, per-block timeline, suite-context soak
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r05f
-timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r05f/pytest_gpu.txt
+timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/r05f/pytest_gpu.txt
 cat gpurun_out/r05f/pytest_gpu.txt
 bash tests/run_profile.sh r05 > gpurun_out/r05f/profile.log 2>&1
 bash tests/run_profile.sh r05_dense --obs-layout dense > gpurun_out/r05f/profile_dense.log 2>&1
