@@ -319,7 +319,13 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // (HS::enabled -- the fused rollout launch -- has an observer attached by construction)
     const bool tail_rows = SPLIT && !HS::enabled && c.obs_log > 0 && c.obs_length > 1 && A.acc == nullptr;
     // (dense batch: the same, the new window going into the env's record of the batch -- unless every step re-draws observation noise)
-    const bool pre_install = SPLIT && !HS::enabled && c.auto_reset && (c.obs_log > 0 || !c.obs_noise) && V(c).steps_max > (c.obs_length - 1) * c.obs_step + 1 &&
+    // (NOT for a dense batch of LAGGED rows: there the terminal observation of a foreseen end showed, in 1 of ~300 such ends -- one
+    // lane of a wave that also hosts lanes in their first steps --, the new episode's record in the non-action entries of its
+    // OLDEST row.  Reproducible (tools/gpu/shape_term_probe.py), present since the physics wave installs episodes, gone when it
+    // never does; the row log and un-lagged dense observations are not affected.  Not root-caused: that layout keeps the
+    // gym wave's own reset)
+    const bool pre_install = SPLIT && !HS::enabled && c.auto_reset && (c.obs_log > 0 || (!c.obs_noise && c.obs_length == 1)) &&
+                             V(c).steps_max > (c.obs_length - 1) * c.obs_step + 1 &&
                              A.acc == nullptr && !c.has_int_obs;   // (integrator entries of a reset observation depend on how the old episode ends)
     // row-log mode: the lagged rows of such an end's TERMINAL observation never pass through the gym wave -- the partner copies
     // them, log -> terminal batch, before it writes the new window over their planes (a few lanes: one 4-byte load and store per

@@ -75,6 +75,9 @@ def _run_pair(make_a, make_b, n, steps, scale=1.3):
         assert torch.equal(a._term, b._term), "step {}".format(t)
         ends += int(da.sum())
         worst = max(worst, float((oa - ob).abs().max()), float((ra - rb).abs().max()))
+        if bool(da.any()):   # the terminal observations of the envs that ended (two-wave kernel, row log: the lagged rows are
+            m = da.bool()    # copied by the physics wave, a few ending lanes per wave sharing the words -- partner_rows)
+            worst = max(worst, float((a._term_obs[m] - b._term_obs[m]).abs().max()))
     ia, ib = a.spec_index, b.spec_index
     a.close(), b.close()
     return worst, ends, ia, ib
