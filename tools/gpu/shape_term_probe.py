@@ -71,6 +71,7 @@ for t in range(200):
             g0 = int(a.layout.draw) // 4
             tags = st_all[g0 + 10, w0:w0 + 64].view(torch.int32)
             print("   draw tags (lane: generation, episode, flags) of ending lanes:", [(i, tags[i].tolist()[:3]) for i in range(min(64, n - w0)) if dn[i]][:40])
+            print("   termination codes of the wave's ending lanes (lane, code, wrong):", [(i, int(a._term[w0 + i]), int(dd[i] > 1e-3)) for i in range(min(64, n - w0)) if dn[i]])
             H = torch.stack(hist)   # [steps so far][env][12]: every env's newest record after every step
             hit = torch.nonzero((H - r4).abs().amax(dim=2) < 1e-3)
             print("   the same twelve values as the newest record of (after step, env):", hit.tolist()[:6])
