@@ -319,12 +319,10 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
     // (HS::enabled -- the fused rollout launch -- has an observer attached by construction)
     const bool tail_rows = SPLIT && !HS::enabled && c.obs_log > 0 && c.obs_length > 1 && A.acc == nullptr;
     // (dense batch: the same, the new window going into the env's record of the batch -- unless every step re-draws observation noise)
-    // (NOT for a dense batch of LAGGED rows: there the terminal observation of a foreseen end showed, in 1 of ~300 such ends -- one
-    // lane of a wave that also hosts lanes in their first steps --, the new episode's record in the non-action entries of its
-    // OLDEST row.  Reproducible (tools/gpu/shape_term_probe.py), present since the physics wave installs episodes, gone when it
-    // never does; the row log and un-lagged dense observations are not affected.  Not root-caused: that layout keeps the
-    // gym wave's own reset)
-    const bool pre_install = SPLIT && !HS::enabled && c.auto_reset && (c.obs_log > 0 || (!c.obs_noise && c.obs_length == 1)) &&
+    // (a foreseen end whose LAST STEP FAILS is not installed by the physics wave, in either layout: the failed step's terminal
+    // observation takes lagged rows from one record further back -- in the dense layout out of the very lag-ring slot the install
+    // pushes the new episode's record 0 into; rounds 4-5 installed regardless there: 1 of ~300 time-limit ends)
+    const bool pre_install = SPLIT && !HS::enabled && c.auto_reset && (c.obs_log > 0 || !c.obs_noise) &&
                              V(c).steps_max > (c.obs_length - 1) * c.obs_step + 1 &&
                              A.acc == nullptr && !c.has_int_obs;   // (integrator entries of a reset observation depend on how the old episode ends)
     // row-log mode: the lagged rows of such an end's TERMINAL observation never pass through the gym wave -- the partner copies
@@ -796,7 +794,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         const float4 r = fwg_msg_take(hand + 20, FWG_TAG_RESULT, 0xFF000000u);
         E.d.Va = r.x; E.d.alpha = r.y; E.d.beta = r.z;
         fail = (int)(f2u(r.w) & 0xFFu);
-        if (partner_rows) pre_rows = pre_rows && fail == 0;   // (a foreseen end whose last step fails: nothing installed, see partner_rows)
+        if (pre_install) pre_rows = pre_rows && fail == 0;   // (a foreseen end whose last step fails: nothing installed, the unforeseen path)
         if (__ballot(fail != 0) != 0ull) {   // (rare) a failed step: the last valid state and its derived values follow
             const float4 o = fwg_msg_take(hand + 24, FWG_TAG_OLD, 0xFFFFFFFFu, fail != 0);
             if (fail != 0) {
@@ -818,7 +816,7 @@ __device__ __forceinline__ void step_wave(const DevCfg* __restrict__ cp, const D
         const float4 w = fwg_msg_take(tailm, FWG_TAG_TAIL);
         if (tail_rows || pre_install) {
             steps_p = f2u(w.y);
-            end_p = pre_install && valid && f2u(w.z) != 0u && !(partner_rows && fail != 0);
+            end_p = pre_install && valid && f2u(w.z) != 0u && fail == 0;
             early_p = tail_rows && valid && fail == 0 && steps_p != 0u && !end_p;   // (an ending lane's rows are the partner's)
             if (__ballot(early_p) != 0ull) {
                 if (early_p) early_rows_request(c, A, e, rec0_p);
