@@ -185,16 +185,33 @@ static void emu_run_block(const std::function<void()>& body, unsigned b, dim3 bl
         emu_wave_live[w] = last - first; emu_wave_wait[w] = 0;
     }
     emu_block_live = block.x; emu_block_wait = 0;
+    // Wave order of a scheduling pass (FWG_EMU_ORDER, read once): 0 = waves in index order (default); 1 = reverse order (the
+    // gym wave of a two-wave step runs until it needs its partner BEFORE the physics wave starts); r<seed> = a pseudo-random
+    // order per pass.  The hardware promises no order between the waves of a workgroup: what one wave may only read before /
+    // after its partner writes must be ordered by a message, a mark or a barrier, and a protocol that merely happens to hold in
+    // index order fails under another one (tests/test_emu_coverage.py runs the steady-state test under all three).
+    const char* order_env = getenv("FWG_EMU_ORDER");   // (per block: a test may change it between launches)
+    const int mode = order_env == nullptr ? 0 : (order_env[0] == 'r' ? 2 : atoi(order_env));
+    unsigned long long lcg = 0x9E3779B97F4A7C15ull * (b + 1) + (mode == 2 ? strtoull(order_env + 1, nullptr, 10) : 0ull);
     for (;;) {
         unsigned alive = 0;
-        for (unsigned t = 0; t < block.x; ++t) {
-            if (emu_lanes[t].state == 2) continue;
-            ++alive;
-            emu_cur = t;
-            threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; blockDim = {block.x, 1, 1};
-            emu_lanes[t].state = 0;
-            swapcontext(&emu_sched_ctx, &emu_lanes[t].ctx);
-        }
+        unsigned worder[16];
+        for (unsigned w = 0; w < emu_nwaves; ++w) worder[w] = mode == 1 ? emu_nwaves - 1 - w : w;
+        if (mode == 2)
+            for (unsigned w = emu_nwaves; w > 1; --w) {
+                lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                const unsigned k = (unsigned)((lcg >> 33) % w), tmp = worder[w - 1];
+                worder[w - 1] = worder[k]; worder[k] = tmp;
+            }
+        for (unsigned wi = 0; wi < emu_nwaves; ++wi)
+            for (unsigned t = worder[wi] * 64; t < worder[wi] * 64 + 64 && t < block.x; ++t) {
+                if (emu_lanes[t].state == 2) continue;
+                ++alive;
+                emu_cur = t;
+                threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; blockDim = {block.x, 1, 1};
+                emu_lanes[t].state = 0;
+                swapcontext(&emu_sched_ctx, &emu_lanes[t].ctx);
+            }
         if (!alive) break;
     }
 }
