@@ -1555,28 +1555,10 @@ __global__ void k_check_nan(const float* __restrict__ a, long n, int* flag) {
     if (i < n && a[i] != a[i]) atomicOr(flag, 1);
 }
 
-// fwg_reduce_success_device: fixed-point sums -> floats, accumulators cleared (one tiny launch, stream-ordered)
-__global__ void k_reduce_take(unsigned long long* __restrict__ acc, float* __restrict__ out) {
-    const int i = threadIdx.x;
-    if (i < FWG_N_REDUCE) {
-        const long long q = (long long)acc[i];
-        out[i] = i < 5 ? (float)q : (float)((double)q / (double)FWG_ACC_SCALE);
-        acc[i] = 0ull;
-    }
-}
-
 // fwg_finish_episodes: finished-episode records not yet collected -> metrics block + success sums (per-wave reduction by
 // shuffles, one atomic per value per wave: the per-GPU part of the success reduction of examples/train_rl_controller.py:51-66,
 // 80-85); the pending mark is cleared.  One lane per env; a wave without a pending record leaves after one 16-byte load.
-__global__ __launch_bounds__(FWG_WAVE) void k_finish(const DevCfg* __restrict__ cp, const KArgs A) {
-    const DevCfg& c = *cp;
-    const int lane = threadIdx.x;
-    const long e0 = (long)blockIdx.x * FWG_WAVE + lane;
-    const bool valid = e0 < A.N;
-    const long e = valid ? e0 : A.N - 1;
-    const float4 fl = CGROUP(A.S, A.N, (c.L.gym >> 2) + 1, e);
-    const bool pending = valid && (f2u(fl.x) & FWG_FLAG_FIN_PENDING);
-    if (__ballot(pending) == 0ull) return;
+__device__ __forceinline__ void finish_wave(const DevCfg& c, const KArgs& A, long e, int lane, bool pending, float4 fl) {
     float red[FWG_N_REDUCE];
 #pragma unroll
     for (int i = 0; i < FWG_N_REDUCE; ++i) red[i] = 0.f;
@@ -1596,6 +1578,68 @@ __global__ __launch_bounds__(FWG_WAVE) void k_finish(const DevCfg* __restrict__ 
     for (int i = 0; i < 32; ++i) v32[i] = i < FWG_N_REDUCE ? red[i] : 0.f;
     const float tot = wave_totals32(v32, lane);   // lane l holds the total of value l & 31
     if (lane < FWG_N_REDUCE && tot != 0.f) atomicAdd(A.reduce + lane, reduce_fixed(lane, tot));
+}
+// TAKE (fwg_reduce_success_device): the same launch also hands the sums out and clears them -- the block that finishes LAST
+// (a device-wide ticket, A.reduce[FWG_N_REDUCE]) exchanges the 16 accumulators for zero and writes the floats; rounds 1-5 ran a
+// second one-wave launch (k_reduce_take) behind this one, 3-4 us per chunk of a replayed graph for nothing but its launch.
+template <bool TAKE>
+__global__ __launch_bounds__(FWG_WAVE) void k_finish(const DevCfg* __restrict__ cp, const KArgs A, float* __restrict__ take_out) {
+    const DevCfg& c = *cp;
+    const int lane = threadIdx.x;
+    const long e0 = (long)blockIdx.x * FWG_WAVE + lane;
+    const bool valid = e0 < A.N;
+    const long e = valid ? e0 : A.N - 1;
+    const float4 fl = CGROUP(A.S, A.N, (c.L.gym >> 2) + 1, e);
+    const bool pending = valid && (f2u(fl.x) & FWG_FLAG_FIN_PENDING);
+    if (__ballot(pending) != 0ull) finish_wave(c, A, e, lane, pending, fl);
+    if (TAKE) {
+        __threadfence();   // this block's atomics are performed before its ticket
+        unsigned ticket = 0u;
+        if (lane == 0) ticket = atomicAdd(reinterpret_cast<unsigned*>(A.reduce + FWG_N_REDUCE), 1u);
+        const bool last = __ballot(lane == 0 && ticket == gridDim.x - 1u) != 0ull;
+        if (last) {
+            __threadfence();
+            if (lane < FWG_N_REDUCE) {
+                const long long q = (long long)atomicExch(A.reduce + lane, 0ull);
+                take_out[lane] = lane < 5 ? (float)q : (float)((double)q / (double)FWG_ACC_SCALE);
+            }
+            if (lane == 0) *reinterpret_cast<unsigned*>(A.reduce + FWG_N_REDUCE) = 0u;   // (the next launch is stream-ordered behind this one)
+        }
+    }
+}
+
+// fwg_gae: generalised advantage estimation over a rollout stored step-major ([T][N], as fwg_rollout_step / fwg_actor_act
+// fill it) -- the backward loop of PPO2's runner behind examples/train_rl_controller.py:231-232 (`PPO2(...).learn`):
+//   delta_t = r_t + gamma V_(t+1) (1 - done_t) - V_t,  A_t = delta_t + gamma lambda (1 - done_t) A_(t+1),  R_t = A_t + V_t
+// with done_t the flag the env returned for step t (the observation behind V_(t+1) then belongs to the next episode) and V_T
+// the value of the observation after the last step.  One lane per env: consecutive lanes read consecutive floats of a
+// step's row (coalesced); the recurrence is two FMAs per step, the loads of eight steps are in flight ahead of it.
+// HBM-bound: 17 B per stored transition (4 + 4 + 1 read, 4 + 4 written).
+__global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, const float* __restrict__ val, const unsigned char* __restrict__ done,
+                                             const float* __restrict__ last_value, float gamma, float lam, float* __restrict__ adv,
+                                             float* __restrict__ ret, long T, long N) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    float next_v = last_value[e], run = 0.f;
+    for (long t0 = T; t0 > 0; t0 -= 8) {
+        float r[8], v[8], nt[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long t = t0 - 1 - k;
+            if (t >= 0) { r[k] = rew[t * N + e]; v[k] = val[t * N + e]; nt[k] = done[t * N + e] ? 0.f : 1.f; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long t = t0 - 1 - k;
+            if (t >= 0) {
+                const float delta = r[k] + gamma * next_v * nt[k] - v[k];
+                run = delta + gamma * lam * nt[k] * run;
+                adv[t * N + e] = run;
+                ret[t * N + e] = run + v[k];
+                next_v = v[k];
+            }
+        }
+    }
 }
 
 // known-answer hook for the device Philox4x32-10 (fwg_selftest_philox): in[i] = counter[4] | key[2]
@@ -1944,13 +1988,13 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     HIP_TRY(hipMalloc((void**)&h->d_cfg, sizeof(DevCfg)));
     HIP_TRY(hipMalloc((void**)&h->d_dyn, sizeof(DynCfg)));
     HIP_TRY(hipMemcpy(h->d_dyn, &h->hd, sizeof(DynCfg), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void**)&h->d_reduce, sizeof(unsigned long long) * FWG_N_REDUCE));
+    HIP_TRY(hipMalloc((void**)&h->d_reduce, sizeof(unsigned long long) * (FWG_N_REDUCE + 1)));   // (+ the ticket of k_finish<true>)
     HIP_TRY(hipMalloc((void**)&h->d_flag, sizeof(int)));
     HIP_TRY(hipMalloc((void**)&h->d_slots, 2 * sizeof(StepSlots)));
     HIP_TRY(hipMemset(h->d_slots, 0, 2 * sizeof(StepSlots)));
     h->graph_mode = 0;
     HIP_TRY(hipMemcpy(h->d_cfg, &h->h, sizeof(DevCfg), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(h->d_reduce, 0, sizeof(unsigned long long) * FWG_N_REDUCE));
+    HIP_TRY(hipMemset(h->d_reduce, 0, sizeof(unsigned long long) * (FWG_N_REDUCE + 1)));
     HIP_TRY(hipMemset(h->d_flag, 0, sizeof(int)));
     h->d_mq = nullptr;
     h->model_all_stale = 1;
@@ -2099,6 +2143,16 @@ int fwg_obs_gather(const fwg_handle* h, const float* obs_log, float* obs_out, vo
     return FWG_OK;
 }
 
+int fwg_gae(int64_t n_steps, int64_t n_envs, const float* rewards, const float* values, const uint8_t* dones, const float* last_value,
+            float gamma, float lam, float* adv_out, float* ret_out, void* stream) {
+    if (!rewards || !values || !dones || !last_value || !adv_out || !ret_out) return fail_with(FWG_ERR_INVALID, "fwg_gae: null argument");
+    if (n_steps < 1 || n_envs < 1) return fail_with(FWG_ERR_INVALID, "fwg_gae: n_steps and n_envs must be positive");
+    hipLaunchKernelGGL(k_gae, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, values, dones, last_value,
+                       gamma, lam, adv_out, ret_out, (long)n_steps, (long)n_envs);
+    HIP_TRY(hipGetLastError());
+    return FWG_OK;
+}
+
 int fwg_selftest_philox(const uint32_t* ctr_key_dev, uint32_t* out_dev, int64_t n, void* stream) {
     if (!ctr_key_dev || !out_dev || n < 1) return fail_with(FWG_ERR_INVALID, "fwg_selftest_philox: bad argument");
     hipLaunchKernelGGL(k_selftest_philox, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctr_key_dev, out_dev, (long)n);
@@ -2123,7 +2177,7 @@ static void launch_finish(fwg_handle* h, float* metrics_out, hipStream_t stream)
     KArgs A;
     base_args(h, &A);
     A.metrics = metrics_out;
-    hipLaunchKernelGGL(k_finish, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), 0, stream, h->d_cfg, A);
+    hipLaunchKernelGGL(k_finish<false>, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), 0, stream, h->d_cfg, A, (float*)nullptr);
 }
 int fwg_finish_episodes(fwg_handle* h, float* metrics_out, void* stream) {
     if (!h) return fail_with(FWG_ERR_INVALID, "null handle");
@@ -2148,8 +2202,13 @@ int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream) {
 
 int fwg_reduce_success_device(fwg_handle* h, float* out_dev, void* stream) {
     if (!h || !out_dev) return fail_with(FWG_ERR_INVALID, "null argument");
-    launch_finish(h, h->last_metrics_out, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_reduce_take, dim3(1), dim3(FWG_WAVE), 0, (hipStream_t)stream, h->d_reduce, out_dev);
+    // ONE launch: collect the finished-episode records, and the block that finishes last hands the sums out and clears them
+    // (a configuration without metrics has no records: the same kernel, every wave leaves after its ticket)
+    KArgs A;
+    base_args(h, &A);
+    A.metrics = h->h.metrics ? h->last_metrics_out : nullptr;
+    hipLaunchKernelGGL(k_finish<true>, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), 0, (hipStream_t)stream,
+                       h->d_cfg, A, out_dev);
     HIP_TRY(hipGetLastError());
     return FWG_OK;
 }

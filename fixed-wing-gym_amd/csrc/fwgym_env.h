@@ -214,10 +214,19 @@ __device__ __forceinline__ StepSlots load_slots(const StepSlots* p) {
 __device__ __forceinline__ KArgs resolve_slots(const DevCfg& c, const KArgs& A0) {
     KArgs A = A0;
     if (A0.slots_in != nullptr) {
+        // Freshness under graph replay: the record was written by the launch before this one (a vector store) and the same
+        // address was scalar-loaded two launches ago, so a scalar data cache that survived two dispatches would hand the kernel
+        // the positions of step g - 2.  Every AQL kernel-dispatch packet -- the kernel nodes of a replayed graph included --
+        // carries an acquire fence that invalidates that cache; what graph nodes skip is the completion-signal handshake.  Not
+        // relying on it was measured (round 6, same-box A/B, profiles/r06_slots_ab.txt): s_dcache_inv once per wave
+        // (FWG_SLOTS_DCACHE_INV) costs +0.3 us per C3 step -- every wave re-fetches its kernel arguments and configuration
+        // words --, scalar loads with GLC (miss the scalar cache) 91 us per step instead of 10.5.  The default trusts the
+        // dispatch; tests/test_obs_log.py replays 64-step graphs through nine time limits against eager launches, where a stale
+        // record shows as a wrong observation window.
         if (A0.reset_launch)   // k_reset: positions of the LAST completed step (rare launch: computed from scratch)
-            apply_slots(A, make_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, load_slots(A0.slots_in).gnow - 1));
+            apply_slots(A, make_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, load_slots(in).gnow - 1));
         else
-            apply_slots(A, load_slots(A0.slots_in));
+            apply_slots(A, load_slots(in));
     }
     return A;
 }

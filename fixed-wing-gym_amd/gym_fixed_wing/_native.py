@@ -3,7 +3,7 @@ module without a built library raises, there is no CPU fallback."""
 import ctypes as C
 import os
 
-FWG_ABI_VERSION = 19
+FWG_ABI_VERSION = 20
 N_VARS = 23
 N_RESET_VARS = 21
 N_PARAMS = 49
@@ -155,7 +155,7 @@ EXPORTS = ["fwg_abi_version", "fwg_get_layout", "fwg_create", "fwg_destroy", "fw
            "fwg_capture_begin", "fwg_capture_end", "fwg_capture_parity", "fwg_replay_check", "fwg_finish_episodes", "fwg_actor_create", "fwg_actor_destroy", "fwg_actor_set_weights",
            "fwg_actor_set_stats", "fwg_actor_get_stats", "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe",
            "fwg_actor_act", "fwg_attach_observer", "fwg_obs_log_floats", "fwg_obs_window", "fwg_reduce_success_device",
-           "fwg_obs_gather", "fwg_actor_set_obs_log", "fwg_selftest_philox", "fwg_rollout_available", "fwg_rollout_step"]
+           "fwg_obs_gather", "fwg_actor_set_obs_log", "fwg_selftest_philox", "fwg_rollout_available", "fwg_rollout_step", "fwg_gae"]
 _libs = {}
 
 
@@ -242,6 +242,8 @@ def load_library(path=None):
     lib.fwg_rollout_available.restype = C.c_int
     lib.fwg_rollout_step.argtypes = [vp, vp] + [vp] * 12 + [C.c_int, vp]
     lib.fwg_rollout_step.restype = C.c_int
+    lib.fwg_gae.argtypes = [i64, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp]
+    lib.fwg_gae.restype = C.c_int
     for name in ("fwg_actor_create", "fwg_actor_set_weights", "fwg_actor_set_stats", "fwg_actor_get_stats",
                  "fwg_actor_configure", "fwg_actor_seed", "fwg_actor_observe", "fwg_actor_act"):
         getattr(lib, name).restype = C.c_int

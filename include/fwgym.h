@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FWG_ABI_VERSION 19
+#define FWG_ABI_VERSION 20
 
 #define FWG_N_VARS 23        /* simulator variables, see fwg_var */
 #define FWG_N_RESET_VARS 21  /* the keys of reset(state=...) records (fixed_wing.py:287,308; test-set format) */
@@ -464,6 +464,17 @@ int fwg_rollout_available(const fwg_handle* env, const fwg_actor* head);
 int fwg_rollout_step(fwg_handle* env, fwg_actor* head, float* norm_obs_out, float* action_out, float* value_out, float* logp_out,
                      float* norm_reward_out, uint8_t* done_prev_out, float* obs_io, float* reward_io, uint8_t* done_io,
                      uint8_t* term_code_out, float* terminal_obs_out, float* metrics_out, int deterministic, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Learner side of the rollout.  fwg_gae: generalised advantage estimation over the rollout the calls above
+ * filled in place -- replaces the backward loop of PPO2's runner (stable-baselines ppo2.py Runner.run) behind
+ * `PPO2(policy, env).learn(...)`, reference gym_fixed_wing/examples/train_rl_controller.py:231-232.  All buffers are device
+ * pointers, step-major: rewards / values / adv_out / ret_out float [n_steps][n_envs], dones uint8 [n_steps][n_envs] (the flag
+ * the env returned FOR step t: the value behind it belongs to the next episode), last_value float [n_envs] (value of the
+ * observation after the last step).  adv_t = delta_t + gamma lam (1 - done_t) adv_(t+1), delta_t = r_t + gamma V_(t+1)
+ * (1 - done_t) - V_t; ret = adv + V.  One launch on `stream`, no synchronisation, no allocation. */
+int fwg_gae(int64_t n_steps, int64_t n_envs, const float* rewards, const float* values, const uint8_t* dones,
+            const float* last_value, float gamma, float lam, float* adv_out, float* ret_out, void* stream);
 
 /* Global step counter driving the ring slots (diagnostics/tests). */
 int64_t fwg_global_step(const fwg_handle* h);

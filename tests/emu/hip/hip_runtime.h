@@ -36,7 +36,7 @@ struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct emu_idx { unsigned x, y, z; };
-static EMU_TLS emu_idx threadIdx, blockIdx, blockDim;
+static EMU_TLS emu_idx threadIdx, blockIdx, blockDim, gridDim;
 
 typedef int hipError_t;
 typedef void* hipStream_t;
@@ -114,6 +114,8 @@ static std::mutex emu_atomic_mutex;
 static inline float atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); float o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); unsigned long long o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); unsigned o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); unsigned long long o = *p; *p = v; return o; }
+static inline void __threadfence() {}
 static inline int atomicOr(int* p, int v) { std::lock_guard<std::mutex> g(emu_atomic_mutex); int o = *p; *p = o | v; return o; }
 
 // ---- intrinsics ----------------------------------------------------------------------------------------------------
@@ -166,7 +168,7 @@ static void emu_trampoline() {
     emu_lanes[emu_cur].state = 2;
     swapcontext(&emu_lanes[emu_cur].ctx, &emu_sched_ctx);
 }
-static void emu_run_block(const std::function<void()>& body, unsigned b, dim3 block) {
+static void emu_run_block(const std::function<void()>& body, unsigned b, dim3 block, dim3 grid) {
     static const size_t STACK = 2u << 20;
     emu_body = &body;
     for (unsigned t = 0; t < block.x; ++t) {
@@ -208,7 +210,7 @@ static void emu_run_block(const std::function<void()>& body, unsigned b, dim3 bl
                 if (emu_lanes[t].state == 2) continue;
                 ++alive;
                 emu_cur = t;
-                threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; blockDim = {block.x, 1, 1};
+                threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; blockDim = {block.x, 1, 1}; gridDim = {grid.x, 1, 1};
                 emu_lanes[t].state = 0;
                 swapcontext(&emu_sched_ctx, &emu_lanes[t].ctx);
             }
@@ -221,6 +223,6 @@ static void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
 #ifdef FWG_EMU_OMP
 #pragma omp parallel for schedule(dynamic, 1)
 #endif
-    for (int b = 0; b < (int)grid.x; ++b) emu_run_block(body, (unsigned)b, block);
+    for (int b = 0; b < (int)grid.x; ++b) emu_run_block(body, (unsigned)b, block, grid);
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
