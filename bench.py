@@ -395,10 +395,10 @@ def main():
             """hipGraph of n consecutive fwg_step launches on pool actions (n even) + the chunk's success sums.  A captured
             sequence has the parity of the step counter baked in (double-buffered ring positions): one graph per parity."""
             vec = self.vec
-            key = (n, offset % len(self.pool), vec.global_step & 1, bool(want_obs), getattr(vec, "_graph_obs", "view"))
+            key = (n, offset % len(self.pool), vec.global_step & 1, bool(want_obs), getattr(vec, "_graph_obs", "gather"))
             if key not in self.graphs:
                 g = torch.cuda.CUDAGraph()
-                parity = vec.capture_begin()
+                parity = vec.capture_begin(n if want_obs else None)
                 with torch.cuda.graph(g):
                     for t in range(n):
                         vec.step_device(self.pool[(offset + t) % len(self.pool)], want_obs=want_obs)

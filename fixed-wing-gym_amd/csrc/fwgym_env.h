@@ -223,6 +223,11 @@ __device__ __forceinline__ KArgs resolve_slots(const DevCfg& c, const KArgs& A0)
         // words --, scalar loads with GLC (miss the scalar cache) 91 us per step instead of 10.5.  The default trusts the
         // dispatch; tests/test_obs_log.py replays 64-step graphs through nine time limits against eager launches, where a stale
         // record shows as a wrong observation window.
+#ifdef FWG_SLOTS_DCACHE_INV
+        const StepSlots* in = fwg_fresh_scalar_view(A0.slots_in);
+#else
+        const StepSlots* in = A0.slots_in;
+#endif
         if (A0.reset_launch)   // k_reset: positions of the LAST completed step (rare launch: computed from scratch)
             apply_slots(A, make_slots(c.obs_step, c.obs_log, c.obs_length, c.L.window, c.L.lag_depth, c.streak_req, load_slots(in).gnow - 1));
         else

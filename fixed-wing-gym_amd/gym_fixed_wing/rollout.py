@@ -126,7 +126,10 @@ class GraphedRollout(object):
                     "rewards": torch.empty((n_steps, N), device=dev),
                     "dones": torch.empty((n_steps, N), dtype=torch.uint8, device=dev)}
         self.action = torch.zeros((N, 3), device=dev)
-        vec.set_graph_mode(True)
+        # row-log envs: zero-copy windows only when the chunk is a whole number of window periods (they stay right under replay
+        # then); any other length gets the gathered copy per step
+        period = getattr(vec, "obs_window_period", 0)
+        vec.set_graph_mode(True, obs="view" if (period and n_steps % period == 0) else "gather")
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):          # warm-up outside capture (allocations, lazy initialisation)
@@ -134,7 +137,7 @@ class GraphedRollout(object):
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        self._parity = vec.capture_begin()
+        self._parity = vec.capture_begin(n_steps)
         with torch.cuda.graph(self.graph):
             self._body(n_steps)
         vec.capture_end()
@@ -272,7 +275,7 @@ class FusedRollout(object):
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        self._parity = vec.capture_begin()
+        self._parity = vec.capture_begin(self.n_steps)
         self._capturing = True
         with torch.cuda.graph(graph):
             self._body()

@@ -64,6 +64,16 @@ class _TorchBackend(object):
         return t.view(self.torch.int32)
 
 
+class CaptureToken(int):
+    """What capture_begin returns: the step parity of the capture (its int value, fwg_replay_check's argument) + the global step
+    it started at and whether zero-copy observation windows were handed out while it ran (replay_check's phase rule)."""
+
+    def __new__(cls, parity, gstep):
+        obj = int.__new__(cls, parity)
+        obj.gstep, obj.uses_views = int(gstep), False
+        return obj
+
+
 class LazyInfos(object):
     """The `infos` list of VecEnv.step_wait: dicts are materialised on first access (65 536 Python dicts per step would
     cost more than the simulation).  infos[i] has "target" always (fixed_wing.py:435) and, for finished episodes,
@@ -243,24 +253,25 @@ class FixedWingVecEnv(object):
             nat.check(self._lib, inst)
         return inst < (nat.INSTANCE_SHAPE if not shape_ok else nat.INSTANCE_GENERIC)
 
-    def set_graph_mode(self, enable=True, obs="view"):
+    def set_graph_mode(self, enable=True, obs="gather"):
         """Keeps the global step counter on the device so that a captured sequence of step launches (hipGraph /
         torch.cuda.CUDAGraph) can be replayed; see fwg_set_graph_mode in include/fwgym.h for the rules.
 
         Row-log envs, `obs`: what step()/step_device() hand out while the mode is on.
-        "view" (default): the zero-copy window of the log, as without graphs.  The window's position is a function of the global
+        "gather" (default): a dense copy gathered on the device after every step (fwg_obs_gather reads the position on the
+        device: right under replay for ANY chunk length; one more launch and ~700 B/env-step more traffic per step).
+        "view" (opt-in): the zero-copy window of the log, as without graphs.  The window's position is a function of the global
         step with period `obs_window_period` (obs_step x log depth: 64 steps for the default log of a 5 x 12 observation at
         step 2), so the views handed out during a CAPTURE stay right under replay exactly when every replay starts a whole
         number of periods after the capture did -- capture chunks whose length is a multiple of the period (the default log
-        depth is chosen so that 64, 128, 256 are); replay_check() raises otherwise.
-        "gather": a dense copy gathered on the device after every step (fwg_obs_gather reads the position on the device:
-        any chunk length; one more launch and ~700 B/env-step more traffic per step)."""
+        depth is chosen so that 64, 128, 256 are): capture_begin(n_steps) refuses other lengths, replay_check(token) other
+        phases.  The HIP rollout head reads the log in place (fwg_actor_set_obs_log) and needs neither."""
         if obs not in ("view", "gather"):
             raise ValueError("obs must be 'view' or 'gather'")
         nat.check(self._lib, self._lib.fwg_set_graph_mode(self._handle, int(bool(enable)), self._mem.stream()))
         self._graph_mode = bool(enable)
         self._graph_obs = obs
-        self._capturing, self._cap_views, self._cap_gstep = False, False, 0
+        self._capturing, self._cap_token = False, None
         self._refresh_obs_view()
 
     @property
@@ -270,26 +281,35 @@ class FixedWingVecEnv(object):
             return 0
         return int(self._c.obs_step) * (self.obs_log_rows - (int(self._c.obs_length) - 1))
 
-    def capture_begin(self):
-        """Brackets the step calls issued under stream capture.  Returns the step parity of the capture: the graph may only
-        be replayed at that parity (replay_check)."""
+    def capture_begin(self, n_steps=None):
+        """Brackets the step calls issued under stream capture.  Returns the capture's TOKEN -- an int, the step parity the graph
+        may be replayed at, that also carries the step the capture started at and whether zero-copy observation windows were
+        handed out during it: keep it with the graph and pass it to replay_check (one token per graph; several graphs of one env
+        may be alive).  `n_steps` (the number of steps about to be captured), when given in "view" mode, is checked against the
+        window period here instead of at the second replay."""
+        if n_steps is not None and self.obs_log_rows and getattr(self, "_graph_obs", "gather") == "view" and \
+                int(n_steps) % self.obs_window_period:
+            raise ValueError("set_graph_mode(obs='view'): a captured chunk must be a multiple of the observation window period "
+                             "({} steps), not {} steps -- or use obs='gather' / obs_layout='dense'".format(self.obs_window_period, n_steps))
         nat.check(self._lib, self._lib.fwg_capture_begin(self._handle))
-        self._capturing, self._cap_views, self._cap_gstep = True, False, self.global_step
-        return int(self._lib.fwg_capture_parity(self._handle))
+        self._capturing = True
+        self._cap_token = CaptureToken(int(self._lib.fwg_capture_parity(self._handle)), self.global_step)
+        return self._cap_token
 
     def capture_end(self):
         nat.check(self._lib, self._lib.fwg_capture_end(self._handle))
         self._capturing = False
+        return self._cap_token
 
     @property
     def global_step(self):
         return int(self._lib.fwg_global_step(self._handle))
 
-    def replay_check(self, capture_parity):
-        """Raises unless a graph captured at `capture_parity` (capture_begin's return value) may be replayed now."""
-        nat.check(self._lib, self._lib.fwg_replay_check(self._handle, int(capture_parity)))
-        if self.obs_log_rows and getattr(self, "_cap_views", False):
-            off = (self.global_step - self._cap_gstep) % self.obs_window_period
+    def replay_check(self, token):
+        """Raises unless the graph whose capture returned `token` (capture_begin) may be replayed now."""
+        nat.check(self._lib, self._lib.fwg_replay_check(self._handle, int(token)))
+        if self.obs_log_rows and getattr(token, "uses_views", False):
+            off = (self.global_step - token.gstep) % self.obs_window_period
             if off != 0:
                 raise RuntimeError("the captured steps handed out zero-copy observation windows of the row log: a replay must start a "
                                    "whole number of window periods ({} steps) after the capture did, this one starts {} steps past one.  "
@@ -299,7 +319,7 @@ class FixedWingVecEnv(object):
     def note_replayed_steps(self, n_steps):
         nat.check(self._lib, self._lib.fwg_note_replayed_steps(self._handle, int(n_steps)))
         # row-log mode: the window moved with the replayed steps (view mode: recomputed from the host's count of them)
-        self._refresh_obs_view(want_obs=getattr(self, "_graph_obs", "view") == "view")
+        self._refresh_obs_view(want_obs=getattr(self, "_graph_obs", "gather") == "view")
 
     @property
     def spec_index(self):
@@ -384,14 +404,14 @@ class FixedWingVecEnv(object):
         stale under replay, so the observation handed out is the dense copy gathered on the device instead."""
         if not self.obs_log_rows:
             return
-        if self._graph_mode and getattr(self, "_graph_obs", "view") == "gather":
+        if self._graph_mode and getattr(self, "_graph_obs", "gather") == "gather":
             if want_obs:
                 self._obs = self.obs_dense()
             return
         if self._graph_mode and not want_obs:
             return
-        if self._graph_mode and getattr(self, "_capturing", False):
-            self._cap_views = True   # (replay_check: the replays must keep the capture's phase of the window period)
+        if self._graph_mode and getattr(self, "_capturing", False) and self._cap_token is not None:
+            self._cap_token.uses_views = True   # (replay_check: the replays must keep the capture's phase of the window period)
         plane = ctypes.c_int64()
         nat.check(self._lib, self._lib.fwg_obs_window(self._handle, ctypes.byref(plane)))
         win = self._obs_buf[plane.value:plane.value + self._c.obs_length]

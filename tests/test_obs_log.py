@@ -186,7 +186,7 @@ def test_zero_copy_windows_stay_right_under_graph_replay_on_gpu():
     gen = torch.Generator(device="cuda"); gen.manual_seed(1)
     K = 64
     acts = [torch.rand((512, 3), device="cuda", generator=gen) * 2 - 1 for _ in range(K)]
-    log.set_graph_mode(True)   # obs="view"
+    log.set_graph_mode(True, obs="view")   # (opt-in: the default hands out gathered copies, right for any chunk length)
     side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for a in acts[:2]:
@@ -196,12 +196,12 @@ def test_zero_copy_windows_stay_right_under_graph_replay_on_gpu():
         dense.step_device(a)
     seen = torch.zeros((K, 512, 5, 12), device="cuda")
     g = torch.cuda.CUDAGraph()
-    parity = log.capture_begin()
+    parity = log.capture_begin(n_steps=K)
     with torch.cuda.graph(g):
         for t, a in enumerate(acts):
             o, _, _ = log.step_device(a)
             seen[t].copy_(o)          # the consumer: reads the zero-copy window of step t
-    log.capture_end()
+    assert log.capture_end() is parity and parity.uses_views and parity.gstep == 2
     for rep in range(7):
         log.replay_check(parity)
         g.replay(); log.note_replayed_steps(K); torch.cuda.synchronize()
@@ -239,20 +239,39 @@ def test_replay_check_guards_the_phase_of_captured_windows_emulated():
                 vec.replay_check(parity)    # 4 steps later: not a whole number of 12-step periods
         vec.set_graph_mode(False)
     # a chunk of one period replays for ever, and want_obs=False never pins the phase
-    vec.set_graph_mode(True)
-    parity = vec.capture_begin()
+    vec.set_graph_mode(True, obs="view")
+    with pytest.raises(ValueError, match="multiple of the observation window period"):
+        vec.capture_begin(n_steps=4)        # (told the length up front, the capture is refused instead of its second replay)
+    period = vec.capture_begin(n_steps=12)
     for _ in range(12):
         vec.step_device(a)
     vec.capture_end()
-    for _ in range(3):
-        vec.replay_check(parity)
-        vec.note_replayed_steps(12)
-    parity = vec.capture_begin()
+    vec.note_replayed_steps(12)             # (the emulation executed the captured calls)
+    # ... and a SECOND graph of the same env, captured later, has a token of its own: the first one's phase rule is not lost
+    blind = vec.capture_begin()
     for _ in range(4):
         vec.step_device(a, want_obs=False)
     vec.capture_end()
+    vec.note_replayed_steps(4)
+    assert period.uses_views and not blind.uses_views and period.gstep + 12 == blind.gstep
+    with pytest.raises(RuntimeError, match="window periods"):
+        vec.replay_check(period)            # 16 steps after its capture: off phase, and still guarded
+    for _ in range(2):
+        vec.replay_check(blind)
+        vec.note_replayed_steps(4)          # 24 steps past the capture of `period`: two whole periods
     for _ in range(3):
-        vec.replay_check(parity)
+        vec.replay_check(period)
+        vec.note_replayed_steps(12)
+    # the default mode (gather) accepts any chunk length
+    vec.set_graph_mode(False)
+    vec.set_graph_mode(True)
+    tok = vec.capture_begin(n_steps=4)
+    for _ in range(4):
+        vec.step_device(a)
+    vec.capture_end()
+    assert not tok.uses_views
+    for _ in range(3):
+        vec.replay_check(tok)
         vec.note_replayed_steps(4)
     vec.close()
 
