@@ -252,9 +252,10 @@ def main():
                     help="'auto' (default) = the env's default: lagged matrix observations are kept once as a row log and "
                          "handed out as a zero-copy window / read in place by the rollout head; 'dense' = fwg_step writes "
                          "the [N][5][12] batch every step")
-    ap.add_argument("--rollout", default="auto", choices=["auto", "none", "fused"],
+    ap.add_argument("--rollout", default="auto", choices=["auto", "none", "fused", "one_launch"],
                     help="c5 only: 'fused' (default for c5) = env step + HIP rollout head (VecNormalize + MlpPolicy + "
-                         "sampling); 'none' = env step on stored actions")
+                         "sampling), TWO launches per rollout step (the library's default path); 'one_launch' = the same as ONE "
+                         "launch per step (fwg_rollout_step, opt-in: see FusedRollout); 'none' = env step on stored actions")
     ap.add_argument("--head-precision", default="split", choices=["split", "bf16"],
                     help="c5: the rollout head's matrix products: 'split' (default) = every fp32 operand as bf16 hi + lo, three MFMA "
                          "products per tile (~1e-5 of a torch fp32 forward); 'bf16' = one plain bf16 product (~1e-2)")
@@ -274,6 +275,9 @@ def main():
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: host-emulation build of the kernels + gloo, tiny batch (exercises the launcher, the "
                          "sharding and the collective on a machine without GPUs; the numbers are not measurements)")
+    ap.add_argument("--emulate-steps-max", type=int, default=0,
+                    help="TEST ONLY (with --emulate): episode time limit, so that episodes end inside a dry run and the success "
+                         "all-gather + curriculum rule have something to agree on")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -414,9 +418,13 @@ def main():
                 if use_dist:
                     out = torch.empty(16 * world)
                     dist.all_gather_into_tensor(out, local_sums)
-                    seen["episodes"] += float(out.view(world, 16)[:, 0].sum())
+                    seen["allgathers"] = seen.get("allgathers", 0) + 1
+                    total = out.view(world, 16).sum(dim=0).numpy().astype("float64")
                 else:
-                    seen["episodes"] += float(local_sums[0])
+                    total = local_sums.numpy().astype("float64")
+                seen["episodes"] += float(total[0])
+                # the curriculum rule on the GLOBAL sums, on every rank (examples/train_rl_controller.py:80-87)
+                seen["level"] = sched.update(vec, fd.summarize(total, vec.target_names))
                 return
             if not in_graph:
                 vec.reduce_success_device(self.red_dev)     # local sums, device to device, stream-ordered (no host sync)
@@ -470,6 +478,9 @@ def main():
             torch.cuda.synchronize(dev)
             return (time.perf_counter() - t0) / (reps * c) * 1e3
 
+    if args.emulate and args.emulate_steps_max:
+        ckw = dict(ckw or {}, steps_max=args.emulate_steps_max)
+    sched = fd.CurriculumSchedule(level=0.25, cooldown=0)
     R = Runner(cfg, ckw, skw, n_envs, first, log_rows)
     vec = R.vec
     if args.stagger and not args.emulate:
@@ -491,7 +502,7 @@ def main():
 
         def get_rollout(n):
             if n not in rollouts:
-                rollouts[n] = FusedRollout(vec, actor, n, graph=True, fused="auto")
+                rollouts[n] = FusedRollout(vec, actor, n, graph=True, fused="auto" if args.rollout == "one_launch" else False)
             return rollouts[n]
 
     if graphs and not fused:
@@ -541,6 +552,19 @@ def main():
     # ---- side measurements (same launches, other regimes / consumers / configurations); never part of `value`
     sides = {}
     side_ok = graphs and not fused and not args.emulate and not args.no_side
+    if side_ok and replays and chunk != SIDE_CHUNK:
+        # What the timed region is made of: T(c) = c x k + F per replayed chunk (k: one step kernel in a replayed graph; F: the
+        # chunk's fixed cost -- graph launch from an idle device, episode collection + success sums, host launch + wake-up).
+        # Two chunk lengths on the same fresh env give both: the timed region's own (c steps) and a 128-step rollout.
+        t_long = R.time_replays(SIDE_CHUNK, 4) * 1e-3 * SIDE_CHUNK           # seconds per 128-step chunk
+        t_short = wall / max(replays, 1) if not singles else None
+        if t_short:
+            k_us = (t_long - t_short) / (SIDE_CHUNK - chunk) * 1e6
+            sides["timed_region"] = {"chunk_steps": chunk, "us_per_chunk": t_short * 1e6, "kernel_us_per_step": k_us,
+                                     "fixed_us_per_chunk": t_short * 1e6 - chunk * k_us, "us_per_step_at_128_step_chunks": t_long / SIDE_CHUNK * 1e6,
+                                     "note": "T(c) = c k + F from two chunk lengths on the same fresh env: F = launching one hipGraph on an idle "
+                                             "device + the chunk's episode collection and success sums (one launch since round 6) + host launch and "
+                                             "wake-up; no host wait policy moves it (profiles/r06_sync_policy.txt)"}
     # side measurements replay chunks of one PPO rollout (128 steps, the n_steps of the reference's shipped models and the
     # all-gather interval of BASELINE configs[3]) whatever --steps is: a 20-step chunk would put the per-chunk costs -- graph
     # launch, episode collection, success sums, all-gather -- on every 20th step, which no training run does
@@ -668,7 +692,7 @@ def main():
     if side_ok and world == 1 and args.workload == "c3" and not args.stagger and not args.envs and not args.total_envs:
         # BASELINE configs[4]: the PPO rollout loop (VecNormalize + 64-64 MlpPolicy + sampling + env step, end to end), 128-step
         # rollouts replayed as hipGraphs; head and env step in ONE launch per step where fwg_rollout_step applies
-        def side_c5(name, precise, wl="c5", what="BASELINE configs[4]"):
+        def side_c5(name, precise, wl="c5", what="BASELINE configs[4]", one_launch=False):
             try:
                 from gym_fixed_wing.actor import DeviceActor
                 from gym_fixed_wing.rollout import FusedRollout, MlpPolicy
@@ -677,7 +701,7 @@ def main():
                 torch.manual_seed(0)
                 act = DeviceActor.for_env(S.vec, seed=7, env_id_base=0, precise=precise)
                 act.load_policy(MlpPolicy(S.vec.obs_dim))
-                ro = FusedRollout(S.vec, act, sc, graph=True, fused="auto")   # (the one-launch step is opt-in: asked for here)
+                ro = FusedRollout(S.vec, act, sc, graph=True, fused="auto" if one_launch else False)
                 for _ in range(3):
                     ro.run()
                 torch.cuda.synchronize(dev)
@@ -699,10 +723,47 @@ def main():
             except Exception as e:
                 sides[name] = {"error": str(e)[:300]}
 
+        # `c5` is the path the library runs by DEFAULT (two launches per rollout step: env step with the batch moments attached,
+        # then the head).  The one-launch step (fwg_rollout_step) is opt-in -- an intermittent bit-mismatch against the two-launch
+        # path seen twice in round 4's suite runs was never root-caused (22 000 clean iterations since, profiles/r05_soak.txt) --
+        # and is published under its own keys until it is (rounds 4-5 published it as `c5`).
         side_c5("c5", True)
-        side_c5("c5_bf16", False)
-        # what the user of a SMALL batch runs: policy + env step in one launch at BASELINE configs[1]'s 4 096 envs
+        side_c5("c5_fused", True, one_launch=True)
+        side_c5("c5_fused_bf16", False, one_launch=True)
+        # what the user of a SMALL batch runs: policy + env step at BASELINE configs[1]'s 4 096 envs
         side_c5("c2_rollout", True, "c2", "BASELINE configs[1] under the rollout loop: 16 workgroups of 256 envs, launch-latency bound")
+        side_c5("c2_rollout_fused", True, "c2", "BASELINE configs[1] under the rollout loop, one launch per step", one_launch=True)
+        # BASELINE configs[4] WITH the learner: rollouts + fwg_gae + the PPO2 update (gym_fixed_wing/ppo.py, the
+        # recipe of examples/train_ppo.py: 4 epochs x 128 minibatches, graph-captured minibatch steps) -- env-steps/s of training
+        try:
+            from gym_fixed_wing.ppo import PPO
+            c5 = workload("c5")
+            S = Runner(c5[0], c5[1], c5[2], c5[3], 0, 0)
+            ppo = PPO(S.vec, seed=0, nminibatches=128, learning_rate=5e-4)
+            ppo.update(ppo.collect())
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            n_up = 2
+            t_roll = 0.0
+            for _ in range(n_up):
+                t2 = time.perf_counter()
+                batch = ppo.collect()
+                torch.cuda.synchronize(dev)
+                t_roll += time.perf_counter() - t2
+                ppo.update(batch)
+                S.reduce_step(False)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            n_tr = n_up * ppo.n_steps * c5[3]
+            sides["c5_train"] = {"value": n_tr / dt, "unit": "env-steps/s", "ms_per_update": dt / n_up * 1e3, "rollout_ms_per_update": t_roll / n_up * 1e3,
+                                 "envs": c5[3], "n_steps": ppo.n_steps, "transitions_per_update": ppo.n_steps * c5[3],
+                                 "optimiser_steps_per_update": int(ppo.hp["noptepochs"]) * int(ppo.hp["nminibatches"]),
+                                 "note": c5[4] + ": PPO training, env-steps/s INCLUDING advantages (fwg_gae) and the optimiser (PPO2 objective, "
+                                         "4 epochs x 128 minibatches of 65 536 transitions, each minibatch step one replayed hipGraph); the "
+                                         "rollout itself is `rollout_ms_per_update` of `ms_per_update`"}
+            S.vec.close()
+        except Exception as e:
+            sides["c5_train"] = {"error": str(e)[:300]}
     if side_ok and world > 1 and args.workload == "c3" and north_star_default:
         # multi-GPU side figures: BASELINE configs[3] (32 768 envs per GPU) and weak scaling at the one-GPU workload (65 536 per GPU)
         for name, n_side, first_side in (("c4_32768_per_gpu", 32768, rank * 32768), ("weak_65536_per_gpu", 65536, rank * 65536)):
@@ -724,6 +785,11 @@ def main():
             except Exception as e:
                 sides[name] = {"error": str(e)[:300]}
 
+    shards, levels = [[first, n_envs]], [seen.get("level", sched.level)]
+    if args.emulate and use_dist:   # (dry run: every rank's shard and curriculum level, for tests/test_bench_cli.py)
+        got = [None] * world
+        dist.all_gather_object(got, (first, n_envs, seen.get("level", sched.level)))
+        shards, levels = [[g[0], g[1]] for g in got], [g[2] for g in got]
     out = None
     if rank == 0:
         total_envs = args.total_envs if args.total_envs else n_envs * world
@@ -779,6 +845,9 @@ def main():
             out[k] = v
         if args.emulate:
             out["emulated_episodes_seen"] = seen["episodes"]
+            out["emulated_allgathers"] = seen.get("allgathers", 0)
+            out["emulated_shards"] = shards
+            out["emulated_curriculum_levels"] = levels
     vec.close()
     if use_dist:
         dist.barrier()

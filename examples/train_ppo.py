@@ -30,7 +30,7 @@ from gym_fixed_wing.ppo import PPO  # noqa: E402
 
 
 def train(envs=4096, timesteps=100e6, seed=0, nminibatches=128, noptepochs=4, learning_rate=5e-4, n_steps=128, curriculum=True,
-          config="examples", log=print, rank=0, world=1, local=0, fused="auto", ent_coef=0.01, on_update=None):
+          config="examples", log=print, rank=0, world=1, local=0, fused=None, ent_coef=0.01, on_update=None):
     vec = make_sharded_env(presets.preset(config), total_envs=envs, rank=rank, world_size=world, device=local, derived_views=False,
                            seed=seed)
     sched = CurriculumSchedule(level=0.25 if curriculum else 1.0)     # (train_rl_controller.py:162: curriculum_level = 0.25)

@@ -79,7 +79,7 @@ class PPO(object):
     rollouts of n_steps x num_envs transitions with noptepochs x nminibatches gradient steps; `callback(self, info)` runs after
     every update (the reference's monitor_training)."""
 
-    def __init__(self, vec, policy=None, seed=0, fused="auto", graph=True, curriculum=None, group=None, precise=True,
+    def __init__(self, vec, policy=None, seed=0, fused=None, graph=True, curriculum=None, group=None, precise=True,
                  graph_update=True, **kw):
         from .actor import DeviceActor
         hp = dict(PPO2_DEFAULTS)

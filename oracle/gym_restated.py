@@ -9,9 +9,13 @@ reference's unbounded history lists), so that pinning it
 (tests/test_oracle_vs_reference.py, build container only, and the committed vectors under tests/golden/) also
 validates that reformulation.  The simulator underneath is oracle/pyfly_restated.PyFly (PARITY UNPINNED vs real PyFly).
 
-Unsupported (raise NotImplementedError, same as the product): target class attitude_angular (:474-478), sampler hook
-(:273-283), integrator observations / int_error reward (:708-711,:804-810), sampling of simulator keys other than states/model on
-the device path, FixedWingAircraftGoal (:1165-1277).
+Supported since rounds 3-4 (pinned against the verbatim reference like the rest): integrator observations and the int_error
+reward factor (:708-711, :804-810, incl. the reset observation that reads the previous episode's history, :317-321), sampling of
+the simulator keys `turbulence` / `turbulence_intensity` (:560-569), simulator["model"] (:532-559), reward.randomize_scaling
+(:330-334).  FixedWingAircraftGoal (:1165-1277) is a host class of the product (gym_fixed_wing/fixed_wing.py) checked against
+vectors recorded from the verbatim reference class (tests/golden/g4_goal_*.json), not restated here.
+Unsupported (raise NotImplementedError, same as the product): target class attitude_angular (:474-478), the sampler hook
+(:273-283), sampling of simulator keys other than states / model / the two turbulence keys.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """

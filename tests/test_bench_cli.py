@@ -95,3 +95,21 @@ def test_multi_gpu_default_is_the_north_star_point():
     assert bench.default_total_envs(8, "c3", 32768, 0, False) == 0
     assert bench.default_total_envs(8, "c3", 0, 131072, False) == 0
     assert bench.default_total_envs(2, "c3", 0, 0, True) == 0
+
+
+def test_eight_ranks_of_configs3_dry_run():
+    """BASELINE configs[3] as the driver would launch it on an 8-GPU node -- `bench.py --gpus 8 --workload c4` -- on the host
+    emulation + gloo: 8 x 32 768 envs in contiguous shards keyed by global env ids, ONE success all-gather per replayed chunk
+    (64 B per rank), and the curriculum rule applied to the global sums lands on the SAME level on every rank.  (No 8-GPU node
+    has reached the driver in six rounds: this is the part of row (e) that can be checked without one.)"""
+    p, out = _bench("--gpus", "8", "--emulate", "--workload", "c4", "--envs", "32768", "--emulate-steps-max", "3", "--steps", "4",
+                    "--warmup", "2", "--no-cpu-baseline")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["config"]["ranks"] == 8
+    assert out["config"]["envs_per_gpu"] == 32768 and out["config"]["total_envs"] == 262144 and out["scaling"] == "weak"
+    assert out["emulated_shards"] == [[r * 32768, 32768] for r in range(8)]
+    # 2 warm-up steps + 4 timed steps = one all-gather per launch sequence here (the emulation runs eagerly: one reduction per run() call)
+    assert out["emulated_allgathers"] >= 2
+    assert out["emulated_episodes_seen"] >= 262144          # 3-step episodes: every env finished at least one, counted over ALL ranks
+    lv = out["emulated_curriculum_levels"]
+    assert len(lv) == 8 and len(set(lv)) == 1, lv

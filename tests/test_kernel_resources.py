@@ -43,3 +43,28 @@ def test_no_preset_step_kernel_spills_or_uses_scratch():
         assert r.get("VGPRs", 0) + r.get("AGPRs", 0) <= 256, name   # two waves per SIMD
     assert seen >= len(presets.SPECIALISED), "the report holds no specialised kernels"
     assert not bad, "kernels with a scratch frame / spilled vector registers: {}".format(bad)
+
+
+# Scalar spills of the BENCHED instances (v_writelane / v_readlane pairs on the dependent chain: DESIGN section 5, "the scalar
+# file, not the vector file, is what this kernel is short of").  Ceilings = the build of round 6 + 2; a change that pushes one
+# of them up did not come for free and has to say so here.
+SGPR_SPILL_CEILING = {
+    "k_step2<true, 6>": 27,        # c3_cnn_step2_dryden_lean_log: bench.py's `value`            (round 5: 27, round 6: 25)
+    "k_step2<true, 4>": 22,        # c3_cnn_step2_dryden_lean: `dense_layout`                     (20)
+    "k_step2<false, 0>": 13,       # c2_default: `c2`                                             (11)
+    "k_step2<false, 5>": 8,        # c5_examples_lean: the env step of `c5`                       (6)
+    "k_rollout<false, 5, 3>": 30,  # c5_examples_lean, split operands: `c5_fused`                 (28)
+    "k_step2<true, 1006>": 70,     # the shape instance of the benched kernel: `shape_instance`   (round 5: 55 reported, 68 built)
+}
+
+
+def test_scalar_spills_of_the_benched_instances_stay_under_their_ceilings():
+    rep = _report()
+    found = {}
+    for name, r in rep["kernels"].items():
+        for key in SGPR_SPILL_CEILING:
+            if name.startswith("void " + key + "("):
+                found[key] = r.get("SGPRs Spill", 0)
+    assert set(found) == set(SGPR_SPILL_CEILING), sorted(set(SGPR_SPILL_CEILING) - set(found))
+    over = {k: (v, SGPR_SPILL_CEILING[k]) for k, v in found.items() if v > SGPR_SPILL_CEILING[k]}
+    assert not over, "scalar spills above their ceilings (spills, ceiling): {}".format(over)

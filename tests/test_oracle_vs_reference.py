@@ -56,3 +56,50 @@ def test_restated_gym_equals_verbatim_reference(case, tmp_path):
             episodes += 1
             worst = max(worst, _cmp(e1.reset(), e2.reset(), "reset"))
     assert worst < 1e-9, worst
+
+
+# ---- the presets against the configuration FILES the reference ships ------------------------------------------------------
+# keys a preset may carry / lack without changing what the environment computes, each with the reason it is inert
+INERT = {
+    "mlp": {"+": {"action.scale_high": "read only when action.scale_space is true (fixed_wing.py:349-354); the mlp file sets it false",
+                  "action.scale_low": "as scale_high"}, "-": {}},
+    "cnn": {"+": {}, "-": {"action.bounds_outside_cost": "never read by fixed_wing.py (grep: no occurrence)"}},
+}
+SHIPPED = {"default": "fixed_wing_config.json", "dev": "fixed_wing_config_dev.json", "examples": "examples/fixed_wing_config.json",
+           "mlp": "examples/models/mlp_controller/fixed_wing_config.json", "cnn": "examples/models/cnn_controller/fixed_wing_config.json"}
+
+
+def _flat(d, prefix=""):
+    out = {}
+    if isinstance(d, dict):
+        for k, v in d.items():
+            out.update(_flat(v, prefix + ("." if prefix else "") + str(k)))
+    elif isinstance(d, list):
+        for i, v in enumerate(d):
+            out.update(_flat(v, prefix + "[{}]".format(i)))
+    else:
+        out[prefix] = d
+    return out
+
+
+@pytest.mark.parametrize("kind", sorted(SHIPPED))
+def test_preset_equals_the_shipped_configuration_file(kind):
+    """presets.preset(kind) -- what the kernels are frozen for and what every test calls 'the reference's configuration' -- is
+    the file the reference ships, key by key and value by value, modulo the stated inert keys."""
+    import json
+    import os
+    from gym_fixed_wing import presets
+    with open(os.path.join("/root/reference/gym_fixed_wing", SHIPPED[kind])) as f:
+        shipped = _flat(json.load(f))
+    ours = _flat({k: v for k, v in presets.preset(kind).items() if k != "_comment"})
+    extra = {k: v for k, v in ours.items() if k not in shipped}
+    missing = {k: v for k, v in shipped.items() if k not in ours}
+    differ = {k: (ours[k], shipped[k]) for k in ours if k in shipped and ours[k] != shipped[k]}
+    allowed = INERT.get(kind, {"+": {}, "-": {}})
+    assert set(extra) == set(allowed["+"]), ("keys only the preset has", extra)
+    assert set(missing) == set(allowed["-"]), ("keys only the shipped file has", missing)
+    assert not differ, differ
+    # the inert keys really are: the reference module never reads `bounds_outside_cost`
+    if kind == "cnn":
+        with open("/root/reference/gym_fixed_wing/fixed_wing.py") as f:
+            assert "bounds_outside_cost" not in f.read()
