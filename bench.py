@@ -594,6 +594,7 @@ def main():
             # then reads is its own traffic, as with any layout.
             per = vec.obs_window_period
             if per and sc % per == 0:
+                vec.set_graph_mode(True, obs="view")   # (opt-in: the library default hands out gathered copies)
                 sides["obs_delivered"] = side_entry(R.time_replays(sc, sreps, want_obs=True), n_envs, route="row_log_view",
                     window_period_steps=per,
                     note="steady state with the zero-copy observation window handed out on every step of the replayed graph (views "

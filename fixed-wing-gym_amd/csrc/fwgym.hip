@@ -233,6 +233,53 @@ struct HandToGym {
     }
 };
 
+// =====================================================================================================================
+// step_wave: ONE env step of 64 environments (fixed_wing.py:338-437), in three ROLES compiled from this one body
+//   ROLE 0  one wave does everything                    (k_step: the generic kernel and FWGYM_SPLIT=0)
+//   ROLE 1  PHYSICS wave | ROLE 2  GYM wave of a pair   (k_step2, k_rollout: `if (SPLIT && PHYS)` / `if (SPLIT && GYM)` blocks)
+// and two observation LAYOUTS (c.obs_log > 0: row log + zero-copy window; 0: dense batch with a lag ring in the arena).
+//
+// MAP (in source order; [P] physics wave / one wave, [G] gym wave / one wave)
+//   A  entry      ring positions (resolve_slots), LDS areas, message tags cleared by their WRITER, one workgroup barrier.
+//                 [P] requests the simulator rows (+ per-lane aircraft constants), reads the raw action;  [G] requests nothing
+//                 until the raw action / actuator state arrive as a message (FWG_TAG_RAW), then its part-1 bookkeeping rows.
+//   B  simulator  [P] action scaling -> sim_step (RK4; asks for the deflections at t + h/2 and t + h: FWG_TAG_ACTS) -> sends the
+//                 candidate state + Euler-angle arguments (FWG_TAG_STATE), then Va / alpha / beta + failure code (FWG_TAG_RESULT);
+//                 a FAILED step re-sends the untouched state (FWG_TAG_OLD) with the COMMITTED step's air data (store_sim).
+//                 [G] meanwhile: actuator micro-steps, turbulence noise (Philox), everything of the gym logic that does not
+//                 depend on this step's integration (counters, action-class reward factors, "action" observation entries,
+//                 control variation, target propagation), one piece of the next episode's prepared draw, the padding rows of
+//                 early-episode lanes, and -- for an end that is FORESEEN (time limit) -- the prefetch of what its end branch
+//                 reads (pre_end / pre_draw / pre_rows).  Sends FWG_TAG_TAIL (step index, padding-row index, install flag).
+//   C  gym logic  [G] errors, goal window / streak, state reward factors, metrics accumulators, done / termination code;
+//                 an UNFORESEEN end (failure, success, or a foreseen end whose last step failed) requests its operands here,
+//                 before the bookkeeping stores.  Scalar outputs (reward, done, code) leave as soon as they are final.
+//   D  observation [G] record 0 of this step (build_row0), lagged rows (row log: planes of the log; dense: lag ring), the
+//                 terminal observation of an ending lane, the episode-end branch (finished-episode record, reset_finish).
+//   E  stores     [G] bookkeeping rows (store_gym), observation (row log: one row; dense: staged through LDS, write_obs).
+//   T  tail       [P] after its last message: Dryden advance + next gust sample, simulator rows back (store_sim), and the side
+//                 work that prepares the NEXT step: padding rows of early lanes into the log (tail_rows), and for a foreseen
+//                 end with a valid prepared draw the whole next episode (pre_install: window, record 0, simulator + cold rows;
+//                 partner_rows: the old window's lagged rows copied into the terminal batch first).  Raises the one-way mark
+//                 (level 1: hand-off areas read; level 2: its row stores acknowledged).
+//
+// INVARIANTS the episode-end paths rest on (each was a bug once; the test that holds it is named)
+//   I1  A failed step leaves state AND air data as the last committed step left them (Va / alpha / beta derived with THAT
+//       step's gust, kept in the second derived group): tests/test_emu_parity.py::test_failed_steps_under_turbulence_...,
+//       tests/test_gpu_oracle_coverage.py [fail_prone]; mutant `airdata` of tools/mutation_check.py.
+//   I2  The partner installs the next episode ONLY for a foreseen end whose last step SUCCEEDED (pre_rows / end_p carry
+//       `fail == 0`), in both layouts: a failed step's terminal observation reads lagged rows one record further back -- in the
+//       dense layout out of the very lag-ring slot an install pushes the new record 0 into.  tests/test_emu_coverage.py
+//       [lockstep-dense], tests/test_gpu_oracle_coverage.py [fail_prone_lockstep-dense]; mutant `install_on_failed_last_step`.
+//   I3  What the gym wave reads of an ending lane's OLD window it has in registers (FWG_TOUCH) before FWG_TAG_TAIL leaves:
+//       after that message the partner may overwrite those planes / slots at any time.
+//   I4  The gym wave re-initialises an env itself (unforeseen end) only after mark level 2: the partner's stores of the old
+//       episode's simulator rows are acknowledged.
+//   I5  No draw piece in a wave that hosts an end; a prepared draw is used only with a matching (generation, episode) tag,
+//       otherwise the end draws on the spot (tests/test_emu_parity.py::test_prepared_draw_is_discarded_...).
+//   I6  Ring slots are positions of the GLOBAL step counter (StepSlots); an env's validity inside a ring is its own age.
+// The fuzzer (tests/test_emu_fuzz.py) runs the three roles against each other and the oracle over drawn configurations.
+// =====================================================================================================================
 // `sub` = index of the 64-environment group this wave (pair of waves) steps: the workgroup index in k_step / k_step2, four
 // groups per workgroup in k_rollout, whose head phase leaves the actions in LDS (`act_lds`: this group's [64][4] floats) and
 // its updated running statistics in `hs`.
@@ -1558,7 +1605,7 @@ __global__ void k_check_nan(const float* __restrict__ a, long n, int* flag) {
 // fwg_finish_episodes: finished-episode records not yet collected -> metrics block + success sums (per-wave reduction by
 // shuffles, one atomic per value per wave: the per-GPU part of the success reduction of examples/train_rl_controller.py:51-66,
 // 80-85); the pending mark is cleared.  One lane per env; a wave without a pending record leaves after one 16-byte load.
-__device__ __forceinline__ void finish_wave(const DevCfg& c, const KArgs& A, long e, int lane, bool pending, float4 fl) {
+__device__ __forceinline__ unsigned long long finish_wave(const DevCfg& c, const KArgs& A, long e, int lane, bool pending, float4 fl) {
     float red[FWG_N_REDUCE];
 #pragma unroll
     for (int i = 0; i < FWG_N_REDUCE; ++i) red[i] = 0.f;
@@ -1577,11 +1624,16 @@ __device__ __forceinline__ void finish_wave(const DevCfg& c, const KArgs& A, lon
 #pragma unroll
     for (int i = 0; i < 32; ++i) v32[i] = i < FWG_N_REDUCE ? red[i] : 0.f;
     const float tot = wave_totals32(v32, lane);   // lane l holds the total of value l & 31
-    if (lane < FWG_N_REDUCE && tot != 0.f) atomicAdd(A.reduce + lane, reduce_fixed(lane, tot));
+    unsigned long long old = 0ull;   // (returned: the caller's ticket waits for the atomics to have been performed)
+    if (lane < FWG_N_REDUCE && tot != 0.f) old = atomicAdd(A.reduce + lane, reduce_fixed(lane, tot));
+    return old;
 }
-// TAKE (fwg_reduce_success_device): the same launch also hands the sums out and clears them -- the block that finishes LAST
-// (a device-wide ticket, A.reduce[FWG_N_REDUCE]) exchanges the 16 accumulators for zero and writes the floats; rounds 1-5 ran a
-// second one-wave launch (k_reduce_take) behind this one, 3-4 us per chunk of a replayed graph for nothing but its launch.
+// TAKE (fwg_reduce_success_device, FWGYM_TAKE=ticket): the same launch also hands the sums out and clears them -- the block that
+// finishes LAST (a device-wide ticket, A.reduce[FWG_N_REDUCE]) exchanges the 16 accumulators for zero and writes the floats.
+// Ordering without a fence: a block's accumulating atomics RETURN their old values and the ticket is taken only after they
+// have come back (performed at the device's coherence point), so the last ticket holder's exchanges see every contribution.
+// (First form of round 6: __threadfence() before the ticket -- on this part an agent-scope release writes the XCD's L2 back:
+// 21.6 us per launch under rocprofv3 against ~4.5 + ~2 for the two launches it replaced; profiles/r06_finish_take.txt.)
 template <bool TAKE>
 __global__ __launch_bounds__(FWG_WAVE) void k_finish(const DevCfg* __restrict__ cp, const KArgs A, float* __restrict__ take_out) {
     const DevCfg& c = *cp;
@@ -1591,14 +1643,15 @@ __global__ __launch_bounds__(FWG_WAVE) void k_finish(const DevCfg* __restrict__ 
     const long e = valid ? e0 : A.N - 1;
     const float4 fl = CGROUP(A.S, A.N, (c.L.gym >> 2) + 1, e);
     const bool pending = valid && (f2u(fl.x) & FWG_FLAG_FIN_PENDING);
-    if (__ballot(pending) != 0ull) finish_wave(c, A, e, lane, pending, fl);
+    unsigned long long seen = 0ull;
+    if (__ballot(pending) != 0ull) seen = finish_wave(c, A, e, lane, pending, fl);
     if (TAKE) {
-        __threadfence();   // this block's atomics are performed before its ticket
+        FWG_TOUCH((unsigned)seen);   // (the returned values in registers: the wave's accumulating atomics have been performed)
+        FWG_TOUCH((unsigned)(seen >> 32));
         unsigned ticket = 0u;
         if (lane == 0) ticket = atomicAdd(reinterpret_cast<unsigned*>(A.reduce + FWG_N_REDUCE), 1u);
         const bool last = __ballot(lane == 0 && ticket == gridDim.x - 1u) != 0ull;
         if (last) {
-            __threadfence();
             if (lane < FWG_N_REDUCE) {
                 const long long q = (long long)atomicExch(A.reduce + lane, 0ull);
                 take_out[lane] = lane < 5 ? (float)q : (float)((double)q / (double)FWG_ACC_SCALE);
@@ -1607,38 +1660,86 @@ __global__ __launch_bounds__(FWG_WAVE) void k_finish(const DevCfg* __restrict__ 
         }
     }
 }
+// the two-launch form of fwg_reduce_success_device (default): fixed-point sums -> floats, accumulators cleared
+__global__ void k_reduce_take(unsigned long long* __restrict__ acc, float* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < FWG_N_REDUCE) {
+        const long long q = (long long)acc[i];
+        out[i] = i < 5 ? (float)q : (float)((double)q / (double)FWG_ACC_SCALE);
+        acc[i] = 0ull;
+    }
+}
 
 // fwg_gae: generalised advantage estimation over a rollout stored step-major ([T][N], as fwg_rollout_step / fwg_actor_act
 // fill it) -- the backward loop of PPO2's runner behind examples/train_rl_controller.py:231-232 (`PPO2(...).learn`):
 //   delta_t = r_t + gamma V_(t+1) (1 - done_t) - V_t,  A_t = delta_t + gamma lambda (1 - done_t) A_(t+1),  R_t = A_t + V_t
 // with done_t the flag the env returned for step t (the observation behind V_(t+1) then belongs to the next episode) and V_T
-// the value of the observation after the last step.  One lane per env: consecutive lanes read consecutive floats of a
-// step's row (coalesced); the recurrence is two FMAs per step, the loads of eight steps are in flight ahead of it.
-// HBM-bound: 17 B per stored transition (4 + 4 + 1 read, 4 + 4 written).
+// the value of the observation after the last step.
+// HBM-bound: 17 B per stored transition (4 + 4 + 1 read, 4 + 4 written).  The recurrence is AFFINE in A_(t+1), so it splits over
+// time: a workgroup of four waves takes 64 envs x up to 128 steps, wave w the steps [w L, (w + 1) L), L = 32.  Every lane requests
+// its 32 x 3 values at once (nothing in the first pass depends on another load: 4 096 waves x 96 loads in flight at 65 536 x 128),
+// scans its segment backwards from A = 0 keeping per step the partial advantage A0_t and the coefficient product a_t
+// (A_t = A0_t + a_t B, B = the advantage at the first step AFTER the segment), publishes (A0, a) of its first step through LDS,
+// folds the later segments' summaries into its B after ONE barrier, and writes A and A + V from registers -- every byte is read
+// once.  Rollouts longer than 128 steps are walked in 128-step spans from the end, the boundary carried in a register.
+// (first build of round 6: one lane per env walking all T steps with 8 steps of loads in flight -- 48 us for 65 536 x 128,
+// 0.37 of the roofline: 1 024 waves cannot keep 8 TB/s busy)
+#define FWG_GAE_L 32
 __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, const float* __restrict__ val, const unsigned char* __restrict__ done,
                                              const float* __restrict__ last_value, float gamma, float lam, float* __restrict__ adv,
                                              float* __restrict__ ret, long T, long N) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    float next_v = last_value[e], run = 0.f;
-    for (long t0 = T; t0 > 0; t0 -= 8) {
-        float r[8], v[8], nt[8];
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][64 lanes][2]: (A0, a) of each segment's first step
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long e0 = (long)blockIdx.x * 64 + lane;
+    const bool valid = e0 < N;
+    const long e = valid ? e0 : N - 1;
+    float carry = 0.f;                                            // advantage at the first step of the span handled before (later in time)
+    for (long hi = T; hi > 0; hi -= 4 * FWG_GAE_L) {              // span [lo, hi), walked from the end of the rollout
+        const long lo = hi - 4 * FWG_GAE_L > 0 ? hi - 4 * FWG_GAE_L : 0;
+        const long s0 = lo + (long)w * FWG_GAE_L;                 // this wave's segment [s0, s1)
+        const long s1 = s0 + FWG_GAE_L < hi ? s0 + FWG_GAE_L : hi;
+        float r[FWG_GAE_L], v[FWG_GAE_L], A0[FWG_GAE_L], ac[FWG_GAE_L];
+        unsigned char d[FWG_GAE_L];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const long t = t0 - 1 - k;
-            if (t >= 0) { r[k] = rew[t * N + e]; v[k] = val[t * N + e]; nt[k] = done[t * N + e] ? 0.f : 1.f; }
+        for (int k = 0; k < FWG_GAE_L; ++k) {
+            const long t = s0 + k;
+            if (t < s1) { r[k] = rew[t * N + e]; v[k] = val[t * N + e]; d[k] = done[t * N + e]; }
         }
+        float vnext = 0.f;
+        if (s0 < s1) vnext = s1 < T ? val[s1 * N + e] : last_value[e];
+        float run = 0.f, prod = 1.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const long t = t0 - 1 - k;
-            if (t >= 0) {
-                const float delta = r[k] + gamma * next_v * nt[k] - v[k];
-                run = delta + gamma * lam * nt[k] * run;
-                adv[t * N + e] = run;
-                ret[t * N + e] = run + v[k];
-                next_v = v[k];
+        for (int k = FWG_GAE_L - 1; k >= 0; --k) {
+            if (s0 + k < s1) {
+                const float nt = d[k] ? 0.f : 1.f;
+                const float delta = r[k] + gamma * vnext * nt - v[k];
+                const float c = gamma * lam * nt;
+                run = delta + c * run;
+                prod = c * prod;
+                A0[k] = run; ac[k] = prod;
+                vnext = v[k];
             }
         }
+        lds[(w * 64 + lane) * 2] = run;                            // (an empty segment publishes the identity: A0 = 0, a = 1)
+        lds[(w * 64 + lane) * 2 + 1] = prod;
+        __syncthreads();
+        float B = carry, first = carry;                            // B: boundary of THIS wave's segment; first: advantage at step lo
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            if (j == w) B = first;
+            first = lds[(j * 64 + lane) * 2] + lds[(j * 64 + lane) * 2 + 1] * first;
+        }
+        carry = first;
+#pragma unroll
+        for (int k = 0; k < FWG_GAE_L; ++k) {
+            const long t = s0 + k;
+            if (t < s1 && valid) {
+                const float a = A0[k] + ac[k] * B;
+                __builtin_nontemporal_store(a, adv + t * N + e);
+                __builtin_nontemporal_store(a + v[k], ret + t * N + e);
+            }
+        }
+        __syncthreads();                                           // the summaries are read before the next span overwrites them
     }
 }
 
@@ -1691,6 +1792,7 @@ struct fwg_handle {
     int graph_mode; // the ring positions live on the device (d_slots[2], double-buffered by the parity of the host count)
     int64_t gstep_at_capture;
     unsigned generation_at_capture;   // configuration generation the captured launch sequences belong to
+    int spec_at_capture;              // ... and the kernel INSTANCE they hold (a frozen kernel has the configuration's values folded in)
     StepSlots* d_slots;
     size_t lds_bytes;
     float* last_metrics_out;      // metrics block of the last fwg_step (what fwg_reduce_success* collect into)
@@ -1974,6 +2076,7 @@ int fwg_create(const fwg_config* cfg, int64_t n_envs, int device, void* state_ar
     std::string why;
     if (lower_config(*cfg, &h->h, &h->hd, &why) != 0) { delete h; return fail_with(FWG_ERR_INVALID, why); }
     h->spec = match_spec(h->h);
+    h->spec_at_capture = h->spec;
     {   // FWGYM_SPLIT=0 keeps the one-wave kernel (A/B measurements)
         const char* env = getenv("FWGYM_SPLIT");
         h->split = !(env != nullptr && env[0] == '0');
@@ -2147,7 +2250,7 @@ int fwg_gae(int64_t n_steps, int64_t n_envs, const float* rewards, const float* 
             float gamma, float lam, float* adv_out, float* ret_out, void* stream) {
     if (!rewards || !values || !dones || !last_value || !adv_out || !ret_out) return fail_with(FWG_ERR_INVALID, "fwg_gae: null argument");
     if (n_steps < 1 || n_envs < 1) return fail_with(FWG_ERR_INVALID, "fwg_gae: n_steps and n_envs must be positive");
-    hipLaunchKernelGGL(k_gae, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, values, dones, last_value,
+    hipLaunchKernelGGL(k_gae, dim3((unsigned)((n_envs + 63) / 64)), dim3(256), 4 * 64 * 2 * sizeof(float), (hipStream_t)stream, rewards, values, dones, last_value,
                        gamma, lam, adv_out, ret_out, (long)n_steps, (long)n_envs);
     HIP_TRY(hipGetLastError());
     return FWG_OK;
@@ -2202,13 +2305,19 @@ int fwg_reduce_success(fwg_handle* h, float* out_host, void* stream) {
 
 int fwg_reduce_success_device(fwg_handle* h, float* out_dev, void* stream) {
     if (!h || !out_dev) return fail_with(FWG_ERR_INVALID, "null argument");
-    // ONE launch: collect the finished-episode records, and the block that finishes last hands the sums out and clears them
-    // (a configuration without metrics has no records: the same kernel, every wave leaves after its ticket)
-    KArgs A;
-    base_args(h, &A);
-    A.metrics = h->h.metrics ? h->last_metrics_out : nullptr;
-    hipLaunchKernelGGL(k_finish<true>, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), 0, (hipStream_t)stream,
-                       h->d_cfg, A, out_dev);
+    // default: collection, then a one-wave launch that hands the sums out and clears them.  FWGYM_TAKE=ticket: ONE launch
+    // (k_finish<true>: the block that finishes last does it) -- see k_finish for what each costs
+    static const bool ticket = [] { const char* e = getenv("FWGYM_TAKE"); return e != nullptr && e[0] == 't'; }();
+    if (ticket) {
+        KArgs A;
+        base_args(h, &A);
+        A.metrics = h->h.metrics ? h->last_metrics_out : nullptr;
+        hipLaunchKernelGGL(k_finish<true>, dim3((unsigned)((h->n_envs + FWG_WAVE - 1) / FWG_WAVE)), dim3(FWG_WAVE), 0, (hipStream_t)stream,
+                           h->d_cfg, A, out_dev);
+    } else {
+        launch_finish(h, h->last_metrics_out, (hipStream_t)stream);
+        hipLaunchKernelGGL(k_reduce_take, dim3(1), dim3(FWG_WAVE), 0, (hipStream_t)stream, h->d_reduce, out_dev);
+    }
     HIP_TRY(hipGetLastError());
     return FWG_OK;
 }
@@ -2246,6 +2355,7 @@ int fwg_capture_begin(fwg_handle* h) {
                                           "issue fwg_reset or an even number of direct fwg_step calls before capturing");
     h->gstep_at_capture = h->gstep;
     h->generation_at_capture = h->hd.generation;
+    h->spec_at_capture = h->spec;
     return FWG_OK;
 }
 int fwg_capture_end(fwg_handle* h) {   // the captured calls did not execute: take the host count back
@@ -2268,6 +2378,10 @@ int fwg_replay_check(const fwg_handle* h, int capture_parity) {
     if (h->d_mq != nullptr && (h->hd.generation != h->generation_at_capture || h->model_all_stale))
         return fail_with(FWG_ERR_INVALID, "hipGraph captured before fwg_update_config / fwg_seed: its launches would keep using per-env "
                                           "parameter sets drawn under the old ranges (issue two direct fwg_step calls, then capture again)");
+    if (h->spec != h->spec_at_capture)
+        return fail_with(FWG_ERR_INVALID, "hipGraph captured before an fwg_update_config that moved the configuration to another kernel instance "
+                                          "(a frozen configuration's kernel has its values folded in: set_curriculum_level on a preset leaves "
+                                          "it for the shape instance): its launches would keep computing with the old values -- capture again");
     if ((int)(h->gstep & 1) != (capture_parity & 1))
         return fail_with(FWG_ERR_INVALID, "hipGraph captured at the other step parity: its launches would read the stale copy of the ring "
                                           "positions (run an even number of direct steps between capture and replay, or capture again)");

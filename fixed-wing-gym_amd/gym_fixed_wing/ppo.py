@@ -96,6 +96,7 @@ class PPO(object):
         self.actor.load_policy(self.policy)
         self._rollout_kw = dict(graph=bool(graph) and self._torch_dev.type == "cuda", fused=fused)
         self.rollout = FusedRollout(vec, self.actor, self.n_steps, **self._rollout_kw)
+        self._spec_at_capture = vec.spec_index
         on_gpu = self._torch_dev.type == "cuda"
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=hp["learning_rate"], eps=1e-5, capturable=on_gpu)
         self._graph_update, self._step_graph = bool(graph_update) and on_gpu, None
@@ -225,12 +226,12 @@ class PPO(object):
                 info["success"] = dict(summary["success"])
                 info["control_variation"] = summary["control_variation"]["all"]
             if self.curriculum is not None:
-                before = self.curriculum.level
                 info["level"] = self.curriculum.update(self.vec, summary)
-                if info["level"] != before and self._rollout_kw["graph"]:
-                    # a captured rollout holds the kernel INSTANCE of the configuration it was captured under (a frozen preset's
-                    # kernel has the init / target ranges folded in; the ranges of another level run its shape instance): capture anew
+                if self._rollout_kw["graph"] and self.vec.spec_index != self._spec_at_capture:
+                    # (a captured rollout holds a kernel INSTANCE; the curriculum's ranges are read from memory and do not move it,
+                    # but a configuration update that changes a folded value would: capture anew, fwg_replay_check refuses otherwise)
                     self.rollout = FusedRollout(self.vec, self.actor, self.n_steps, **self._rollout_kw)
+                    self._spec_at_capture = self.vec.spec_index
             self.history.append(info)
             if log is not None:
                 log(info)

@@ -179,15 +179,15 @@ class FixedWingVecEnv(object):
                                      obs_log_rows=self.obs_log_rows):
                     warnings.warn("FixedWingVecEnv: this configuration is not one of the build-time presets; compiling a "
                                   "specialised kernel for it with hipcc (one to two minutes, cached afterwards; "
-                                  "specialize=False or FWGYM_JIT=0 run the ~5x slower generic kernel instead)", RuntimeWarning, stacklevel=2)
+                                  "specialize=False or FWGYM_JIT=0 run the ~35x slower generic kernel instead)", RuntimeWarning, stacklevel=2)
                 path = jit.specialised_library(ec, auto_reset=auto_reset, store_derived=self.derived_views, base_lib=self._lib,
                                                obs_log_rows=self.obs_log_rows)
                 if path is not None:
                     self._lib = nat.load_library(path)
             if path is None:
                 warnings.warn("FixedWingVecEnv: this configuration is not one of the build-time presets and no specialised "
-                              "kernel is available ({}): it runs the GENERIC kernel, about 5x slower per step than a specialised "
-                              "one".format("specialisation switched off" if not specialize else "hipcc missing or the compile failed"),
+                              "kernel is available ({}): it runs the GENERIC kernel, about 35x slower per step than a specialised "
+                              "one at 65 536 envs".format("specialisation switched off" if not specialize else "hipcc missing or the compile failed"),
                               RuntimeWarning, stacklevel=2)
         self.layout = nat.Layout()
         nat.check(self._lib, self._lib.fwg_get_layout(ctypes.byref(self._c), ctypes.byref(self.layout)))

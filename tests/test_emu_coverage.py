@@ -43,16 +43,16 @@ def test_steady_state_sampled_against_oracles_emulated(regime, layout):
     cfg = configs.reference_like(kind)
     rows = presets.OBS_LOG_ROWS if layout == "row_log" else 0
     lib = _spec_lib(cfg, ckw, skw, rows)
-    n = 384 if regime == "staggered" else 320
+    n = 256 if regime == "staggered" else 448   # (lock-step: ~1 lane in 200 fails ON the step its time limit runs out)
     vec = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=n, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw), seed=11,
                           derived_views=False, obs_log_rows=rows, _backend=HostBackend(), _lib_path=lib)
     assert vec.spec_index == 0 and vec.obs_log_rows == rows        # the two-wave kernel k_step2 of this configuration
-    res = cr.steady_state_sampled(vec, cfg, ckw, skw, 11, window=130 if regime == "staggered" else 100, sample=96,
+    res = cr.steady_state_sampled(vec, cfg, ckw, skw, 11, window=100 if regime == "staggered" else 50, sample=64,
                                   parts=None if regime == "staggered" else 0, what="{} {}".format(regime, layout))
     print(regime, layout, res)
-    assert res["failure_ends"] >= 100 and res["time_limit_ends"] >= 300, res
+    assert res["failure_ends"] >= 60 and res["time_limit_ends"] >= 150, res
     assert res["failed_on_the_limit_step_checked"] >= 1, res      # (the lanes of round 5's second bug are among the checked)
-    assert res["sampled_ends"] >= 150, res
+    assert res["sampled_ends"] >= 50, res
     vec.close()
 
 

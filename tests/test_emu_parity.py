@@ -173,6 +173,39 @@ def test_replay_check_rejects_a_graph_captured_at_the_other_parity(emu_lib):
     vec.close()
 
 
+def test_replay_check_rejects_a_graph_captured_on_another_kernel_instance(emu_lib):
+    """A frozen configuration's kernel has the configuration's VALUES folded in: an update that changes one of them (here the
+    turbulence intensity: the gust gain) moves the env to another kernel instance -- the preset's shape instance on the GPU, the
+    generic kernel in this build -- and a graph captured before it would keep launching the preset's kernel with the old value:
+    silently, until round 6.  (The curriculum's init / target RANGES are not such values: they live in the dynamic part of the
+    configuration, which every kernel reads from memory, and a captured graph follows set_curriculum_level.)"""
+    import gym_fixed_wing._native as nat
+    name, kind, ckw, skw = [c for c in configs.CASES if c[0] == "spec_c3"][0]
+    vec = FixedWingVecEnv(configs.reference_like(kind), num_envs=8, config_kw=ckw, sim_config_kw=skw, seed=2, as_numpy=True,
+                          _backend=HostBackend(), _lib_path=emu_lib)
+    frozen = vec.spec_index
+    assert frozen >= 0
+    vec.reset()
+    a = np.zeros((8, 3), dtype=np.float32)
+    vec.set_graph_mode(True)
+    token = vec.capture_begin()
+    vec.step_device(a, want_obs=False), vec.step_device(a, want_obs=False)
+    vec.capture_end()
+    vec.note_replayed_steps(2)
+    vec.replay_check(token)
+    vec.set_curriculum_level(0.5)            # ranges only: the same kernel instance
+    assert vec.spec_index == frozen
+    vec.replay_check(token)
+    vec.set_simulator_attr("turbulence_intensity", "light")
+    assert vec.spec_index != frozen
+    with pytest.raises(nat.NativeError, match="another kernel instance"):
+        vec.replay_check(token)
+    vec.set_simulator_attr("turbulence_intensity", "moderate")   # back on the preset: the captured launches are right again
+    assert vec.spec_index == frozen
+    vec.replay_check(token)
+    vec.close()
+
+
 @pytest.mark.parametrize("layout,n", [("row_log", 5), ("row_log", 3), ("dense", 5)])
 def test_two_wave_kernel_through_foreseen_episode_ends_emulated(layout, n):
     """k_step2 (two waves per 64 envs) through time-limit episode ends, row log and dense batch: the next episode's prepared

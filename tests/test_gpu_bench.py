@@ -40,15 +40,23 @@ def test_bench_through_torchrun_with_rccl():
     assert j["n_gpus"] == 1 and j["value"] > 1e9
 
 
-def test_bench_line_carries_the_rollout_figure():
-    """BASELINE configs[4] (the PPO rollout loop) rides in the default line as `c5` (+ `c5_bf16`)."""
+def test_bench_line_carries_the_rollout_and_training_figures():
+    """BASELINE configs[4] (the PPO rollout loop) rides in the default line: `c5` = the library's default two-launch path, `c5_fused`
+    (+ `c5_fused_bf16`) = the opt-in one-launch step, `c5_train` = with advantages and the optimiser; `timed_region` splits the
+    driver's line into kernel time per step and fixed cost per chunk."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     j = _last_json(out.stdout)
-    for k in ("c5", "c5_bf16", "steady_state", "c2"):
+    for k in ("c5", "c5_fused", "c5_fused_bf16", "c5_train", "steady_state", "obs_delivered", "c2", "timed_region"):
         assert k in j and "error" not in j[k], (k, j.get(k))
-    assert j["c5"]["value"] > 1.5e9 and j["c5"]["launches_per_step"] == 1 and j["rccl_ranks"] is None
+    assert j["c5"]["value"] > 1.5e9 and j["c5"]["launches_per_step"] == 2 and j["c5_fused"]["launches_per_step"] == 1
+    assert j["c5_fused"]["value"] > j["c5"]["value"] and j["rccl_ranks"] is None
+    assert j["c5_train"]["value"] > 1e6 and j["c5_train"]["rollout_ms_per_update"] < 0.1 * j["c5_train"]["ms_per_update"]
+    tr = j["timed_region"]
+    assert 5.0 < tr["kernel_us_per_step"] < 20.0 and 0.0 < tr["fixed_us_per_chunk"] < 200.0
+    # the zero-copy window costs what the step costs (a gathered copy would be 1.5x)
+    assert j["obs_delivered"]["route"] == "row_log_view" and j["obs_delivered"]["ms_per_step"] < 1.15 * j["steady_state"]["ms_per_step"]
 
 
 def test_two_rank_rccl_smoke():

@@ -40,14 +40,14 @@ def _check_gae(lib, mem, T, N, to_np):
     np.testing.assert_allclose(to_np(ret), want_ret, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("T,N", [(1, 1), (7, 70), (128, 300), (19, 513)])
+@pytest.mark.parametrize("T,N", [(1, 1), (7, 70), (128, 300), (19, 513), (260, 100)])
 def test_gae_kernel_matches_the_runner_loop_emulated(T, N):
     from emu.host_backend import HostBackend, build_emu
     _check_gae(nat.load_library(build_emu()), HostBackend(), T, N, np.asarray)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T,N", [(128, 4096), (128, 65536), (5, 1000)])
+@pytest.mark.parametrize("T,N", [(128, 4096), (128, 65536), (5, 1000), (300, 777)])
 def test_gae_kernel_matches_the_runner_loop_on_gpu(T, N):
     from gym_fixed_wing.vec_env import _TorchBackend
     _check_gae(nat.load_library(), _TorchBackend(0), T, N, lambda t: t.cpu().numpy())
