@@ -79,3 +79,46 @@ def test_two_rank_sharded_run_matches_single_process(tmp_path):
     np.testing.assert_array_equal(s0, s1)                                      # every rank sees the global summary
     assert s0[0] == ref["episodes"] == 2 * TOTAL
     assert s0[1] == pytest.approx(ref["success"]["all"]) and s0[2] == pytest.approx(ref["success"]["roll"])
+
+
+# ---- the learner over two ranks (data-parallel PPO: one all-reduce of the gradient per minibatch step) ------------------------
+def _ppo_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "fixed-wing-gym_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emu.host_backend import HostBackend, build_emu
+    from gym_fixed_wing import distributed as fd
+    from gym_fixed_wing import presets
+    from gym_fixed_wing.ppo import PPO
+    from gym_fixed_wing.vec_env import FixedWingVecEnv
+    first, n = fd.shard(128, rank, world)
+    vec = FixedWingVecEnv(presets.preset("examples"), num_envs=n, config_kw={"steps_max": 12}, seed=5, env_id_base=first,
+                          _backend=HostBackend(), _lib_path=build_emu())
+    vec.set_curriculum_level(0.25)
+    vec.reset()
+    ppo = PPO(vec, seed=100 + rank, n_steps=8, nminibatches=2, noptepochs=1,          # (different seeds: rank 0's weights are broadcast)
+              curriculum=fd.CurriculumSchedule(level=0.25, cooldown=0))
+    w0 = torch.cat([p.detach().reshape(-1) for p in ppo.policy.parameters()]).clone()
+    logs = []
+    ppo.learn(3 * 8 * 128, log=logs.append)
+    w1 = torch.cat([p.detach().reshape(-1) for p in ppo.policy.parameters()])
+    torch.save({"w0": w0, "w1": w1, "timesteps": ppo.num_timesteps, "updates": ppo.updates, "level": ppo.curriculum.level,
+                "episodes": [l["episodes"] for l in logs]}, os.path.join(out_dir, "ppo_{}.pt".format(rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_learner_keeps_one_set_of_weights(tmp_path):
+    """Both ranks start from rank 0's weights, average their gradients at every minibatch step and therefore hold the SAME
+    weights after every update; timesteps count all ranks' transitions; the episode counts and the curriculum level are global."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_ppo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "ppo_0.pt"), torch.load(tmp_path / "ppo_1.pt")
+    assert torch.equal(a["w0"], b["w0"])                      # the broadcast
+    assert not torch.equal(a["w0"], a["w1"])                  # the updates happened
+    assert torch.allclose(a["w1"], b["w1"], rtol=0, atol=1e-7), float((a["w1"] - b["w1"]).abs().max())
+    assert a["timesteps"] == b["timesteps"] == 3 * 8 * 128 and a["updates"] == b["updates"] == 3
+    assert a["episodes"] == b["episodes"] and sum(a["episodes"]) >= 128 and a["level"] == b["level"]
