@@ -137,7 +137,15 @@ __host__ __device__ inline long long log_plane(int S, int L, int len, long long 
     const int p = log_pmod(gp, S);
     const long long qp = log_fdiv(gp, S);
     const long long qc = log_fdiv(g - log_pmod(g - p, S), S);   // newest step of that parity not after g
-    return (long long)p * L + (P - 1 - log_pmod(qp, P)) + (long long)P * (log_fdiv(qc, P) - log_fdiv(qp, P));
+    // A record is written at its HOME plane P - 1 - (qp mod P); the parity's wrap step carries the len - 1 newest records (home
+    // planes 0 .. len - 2) to home + P, where the windows after the wrap find them.  A record one further back -- the oldest row
+    // of a FAILED step's terminal observation at obs_step 1, which shows the window of the step before -- was not carried: it
+    // is still at its home plane (the window reaches that plane again only P - len steps later).  Rounds 1-5 computed home + P
+    // for it as well: plane L, one past the parity's planes -- 1 failure end in P on the shipped cnn configuration read its
+    // oldest terminal row from whatever follows the log (found by tests/test_emu_fuzz.py, seeds 7 and 8, round 6).
+    const int home = P - 1 - log_pmod(qp, P);
+    const long long wraps = log_fdiv(qc, P) - log_fdiv(qp, P);
+    return (long long)p * L + home + ((wraps > 0 && home <= len - 2) ? (long long)P * wraps : 0);
 }
 // Ring positions of one global step g (graph mode keeps them on the device): everything here is g modulo something,
 // so the next step's positions follow from this step's by increments with wrap-around -- no division on the device.

@@ -49,7 +49,7 @@ def _take(buf, w, pos):
 
 
 def steady_state_sampled(vec, cfg, ckw, skw, seed, window=300, parts=None, sample=256, pool_size=8, anchor_every=10,
-                         rtol=4e-3, atol=4e-3, workers=None, what="", metrics_every=100, select_seed=0):
+                         rtol=4e-3, atol=4e-3, workers=None, what="", metrics_every=100, select_seed=0, first_pick=None):
     """`vec`: device tensors (as_numpy=False) or the emulation backend, auto_reset=True, freshly constructed with `seed`.
     parts = 0: no run-in -- the window starts at the reset of a fresh VecEnv, all episodes in LOCK-STEP (the regime of a real
     run's time-limit ends: whole cohorts of lanes end in one launch, next to lanes that failed earlier and are at other ages).
@@ -129,6 +129,10 @@ def steady_state_sampled(vec, cfg, ckw, skw, seed, window=300, parts=None, sampl
             cands = list(sel_rng.choice(cands, size=k, replace=False))
         chosen.extend(int(c) for c in cands)
 
+    picked_first = 0
+    if first_pick is not None:   # (a test's own class of lanes: first_pick(fail_ends [W, N], steps_ends [W, N], g0) -> env ids)
+        add(first_pick(fail_ends, steps_ends, g0), sample // 4)
+        picked_first = len(chosen)
     add(fail_on_limit, sample // 4)
     add(np.nonzero(fail_ends.any(axis=0))[0], sample // 4)
     add(np.nonzero(steps_ends.any(axis=0))[0], sample // 4)
@@ -171,5 +175,5 @@ def steady_state_sampled(vec, cfg, ckw, skw, seed, window=300, parts=None, sampl
     res.update({"sampled": len(pos), "ends_in_window": int(done_h.sum()), "failure_ends": int(fail_ends.sum()),
                 "time_limit_ends": int(steps_ends.sum()), "failed_on_the_limit_step": int(len(fail_on_limit)),
                 "failed_on_the_limit_step_checked": int(sum(1 for e in fail_on_limit if int(e) in where)),
-                "sampled_ends": int(ends_per_env.sum())})
+                "sampled_ends": int(ends_per_env.sum()), "first_pick_checked": picked_first})
     return res

@@ -72,14 +72,29 @@ def draw_case(rng):
     return {"kind": kind, "cfg": cfg, "ckw": ckw, "skw": skw, "lean": lean, "want_log": want_log, "order": order}
 
 
-def _cases():
-    rng = np.random.default_rng(SEED)
+# draws of other seeds that FOUND something (kept in the default run): (seed, index) -- s7c4 / s8c1: the shipped cnn
+# configuration's observation (5 rows at step 1) on the row log, a step that fails on the log's wrap step: the oldest row of the
+# terminal observation was read one plane past the log (log_plane, csrc/fwgym_env.h), rounds 1-5
+PINNED = [(7, 4), (8, 1)]
+
+
+def _draws(seed, count):
+    rng = np.random.default_rng(seed)
     out = []
-    while len(out) < N_CONFIGS:
+    while len(out) < count:
         c = draw_case(rng)
-        c["id"] = "s{}c{}_{}_T{}_{}_{}".format(SEED, len(out), c["kind"], c["ckw"]["steps_max"], "log" if c["want_log"] else "dense",
+        c["seed"], c["index"] = seed, len(out)
+        c["id"] = "s{}c{}_{}_T{}_{}_{}".format(seed, len(out), c["kind"], c["ckw"]["steps_max"], "log" if c["want_log"] else "dense",
                                              "turb" if c["skw"] else "calm")
         out.append(c)
+    return out
+
+
+def _cases():
+    out = _draws(SEED, N_CONFIGS)
+    if "FWGYM_FUZZ_SEED" not in os.environ:
+        for seed, index in PINNED:
+            out.append(_draws(seed, index + 1)[index])
     return out
 
 
@@ -128,7 +143,7 @@ def _arena_diff(a, b, skip):
 def test_tiers_agree_with_each_other_and_with_the_oracle(case):
     cfg, ckw, skw = case["cfg"], case["ckw"], case["skw"]
     n, steps = 70, 140                                          # two workgroups, the second partially filled
-    rng = np.random.default_rng(SEED * 1000 + int(case["id"].split("c")[1].split("_")[0]))
+    rng = np.random.default_rng(case["seed"] * 1000 + case["index"])
     acts, resets = _schedule(rng, n, steps)
     probe = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=1, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw),
                             _backend=HostBackend(), _lib_path=build_emu())

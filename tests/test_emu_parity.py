@@ -206,6 +206,26 @@ def test_replay_check_rejects_a_graph_captured_on_another_kernel_instance(emu_li
     vec.close()
 
 
+def test_failed_step_on_the_row_log_s_wrap_step_with_single_step_lags(emu_lib):
+    """The SHIPPED cnn configuration (5 observation rows at step 1) on the row log: a failed step's terminal observation shows the
+    window of the step BEFORE -- its oldest row is the record of five steps ago, one further back than the four rows the log's wrap
+    step carries to the top of the log.  On a wrap step (every 32nd global step) rounds 1-5 read that row one plane past the log;
+    the fuzzer of round 6 found it (tests/test_emu_fuzz.py PINNED).  Dense batch and obs_step 2 were never affected."""
+    import oracle_pool as op
+    cfg = configs.reference_like("cnn")
+    ckw = {"steps_max": 40, "simulator": {"states": {6: {"constraint_min": -60, "constraint_max": 60}}}}
+    n, steps = 256, 135
+    acts = np.random.default_rng(5).uniform(-1.5, 1.5, (steps, n, 3)).astype(np.float32)
+    vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, seed=11, as_numpy=True, _backend=HostBackend(), _lib_path=emu_lib)
+    assert vec.obs_log_rows == 36 and vec.obs_window_period == 32 and int(vec._c.obs_step) == 1
+    rec = op.record_run(vec, acts)
+    tr = op.run_traces(cfg, list(range(n)), acts, 11, config_kw=ckw)
+    res = op.compare(rec, tr, 4e-3, 4e-3, what="shipped cnn observation on the row log, fail-prone")
+    on_wrap = [(t, j) for (t, j), name in tr["term"].items() if name not in ("steps", "success") and t > 0 and t % 32 == 0]
+    assert len(on_wrap) >= 3, (on_wrap, res)     # the case occurred: failed steps on global steps 32, 64, 96, 128
+    vec.close()
+
+
 @pytest.mark.parametrize("layout,n", [("row_log", 5), ("row_log", 3), ("dense", 5)])
 def test_two_wave_kernel_through_foreseen_episode_ends_emulated(layout, n):
     """k_step2 (two waves per 64 envs) through time-limit episode ends, row log and dense batch: the next episode's prepared

@@ -145,3 +145,29 @@ def test_steady_state_of_65536_envs_sampled_against_oracles(variant, layout):
     else:
         assert res["failure_ends"] >= 10000 and res["failed_on_the_limit_step_checked"] >= 32, res
     vec.close()
+
+
+def test_shipped_cnn_configuration_failed_steps_on_the_log_s_wrap_step():
+    """The shipped cnn configuration (5 rows at step 1, row log) with a tight roll-rate constraint, on its shape instance: a step
+    that fails on a wrap step of the row log (every 32nd global step) shows the record of five steps ago in its terminal
+    observation's oldest row -- one further back than the four rows the wrap carries.  Rounds 1-5 read it one plane past the log
+    (found by tests/test_emu_fuzz.py in round 6; tools/mutation_check.py mutant `log_plane_past_the_log`).  The lanes that failed
+    on a wrap step are picked first."""
+    t0 = time.time()
+    n = 65536
+    cfg = presets.preset("cnn")
+    ckw = copy.deepcopy(FAIL_PRONE_CKW)
+    vec = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=n, device=0, config_kw=copy.deepcopy(ckw), seed=11, specialize=False)
+    want = [e[0] for e in presets.SPECIALISED].index("ship_cnn_log")
+    assert vec.spec_index == nat.INSTANCE_SHAPE + want and vec.obs_log_rows == presets.OBS_LOG_ROWS and vec.obs_window_period == 32
+
+    def on_wrap(fail_ends, steps_ends, g0):
+        w = np.arange(fail_ends.shape[0])
+        rows = fail_ends[(g0 + w) % 32 == 0]
+        return np.nonzero(rows.any(axis=0))[0]
+
+    res = cr.steady_state_sampled(vec, cfg, ckw, None, 11, window=200, sample=256, first_pick=on_wrap,
+                                  what="shipped cnn configuration, fail-prone, {} envs".format(n))
+    print("ship_cnn", res, "{:.0f} s".format(time.time() - t0))
+    assert res["first_pick_checked"] >= 32 and res["failure_ends"] >= 10000, res
+    vec.close()
