@@ -124,6 +124,9 @@ def steady_state_sampled(vec, cfg, ckw, skw, seed, window=300, parts=None, sampl
     chosen = []
 
     def add(cands, k):
+        k = min(k, sample - len(chosen))
+        if k <= 0:
+            return
         cands = [int(c) for c in cands if int(c) not in set(chosen)]
         if len(cands) > k:
             cands = list(sel_rng.choice(cands, size=k, replace=False))
