@@ -276,12 +276,13 @@ def test_failed_steps_under_turbulence_keep_the_committed_air_data(emu_lib):
     from gym_fixed_wing import presets
     ec = EnvConfig(copy.deepcopy(cfg), config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw))
     two_wave = build_emu_spec(ec, auto_reset=True, store_derived=True, obs_log_rows=presets.OBS_LOG_ROWS)   # k_step2: the OLD message carries them
+    import oracle_pool as op
+    tr = op.run_traces(cfg, list(range(n)), acts, 11, config_kw=ckw, sim_config_kw=skw)   # (one set of oracle traces for the three runs)
     for rows, lib in ((0, emu_lib), (12, emu_lib), (presets.OBS_LOG_ROWS, two_wave)):
         vec = FixedWingVecEnv(cfg, num_envs=n, config_kw=ckw, sim_config_kw=skw, seed=11, as_numpy=True, _backend=HostBackend(),
                               _lib_path=lib, obs_log_rows=rows)
         assert (vec.spec_index == 0) == (lib is two_wave)
-        orc = parity.make_oracles(cfg, n, 11, config_kw=ckw, sim_config_kw=skw)
-        res = parity.run_gym_parity(vec, orc, steps, lambda t: acts[t], rtol=4e-3, atol=4e-3)
+        res = op.compare(op.record_run(vec, acts), tr, 4e-3, 4e-3, what="rows {}".format(rows))
         assert res["episodes"] >= n and res["terminations"].get("omega_p", 0) >= 10, res["terminations"]
         vec.close()
 
