@@ -171,3 +171,30 @@ def test_shipped_cnn_configuration_failed_steps_on_the_log_s_wrap_step():
     print("ship_cnn", res, "{:.0f} s".format(time.time() - t0))
     assert res["first_pick_checked"] >= 32 and res["failure_ends"] >= 10000, res
     vec.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the other frozen configurations: every shipped configuration file + the randomised-aircraft workload, on their SHAPE instances
+# with fail-prone values (45-step episodes, tight roll-rate constraint), in both regimes -- the two-wave kernel's episode-end
+# machinery with vector observations (dense batch, attached-less), the mlp variant's unscaled actions, per-env aircraft constants
+SWEEP = [("c2_default", "default", None, None, True), ("c5_examples", "examples", None, None, True), ("ship_mlp", "mlp", None, None, True),
+         ("c3_model16_lean_log", "cnn_model16", {"observation": {"step": 2}}, dict(presets.TURB_MODERATE), False)]
+
+
+@pytest.mark.parametrize("regime", ["staggered", "lockstep"])
+@pytest.mark.parametrize("entry", SWEEP, ids=[e[0] for e in SWEEP])
+def test_preset_shape_instances_fail_prone_against_oracles(entry, regime):
+    t0 = time.time()
+    name, kind, ckw0, skw, derived = entry
+    n = 16384
+    cfg = presets.preset(kind)
+    ckw = dict(copy.deepcopy(ckw0 or {}), **copy.deepcopy(FAIL_PRONE_CKW))
+    vec = FixedWingVecEnv(copy.deepcopy(cfg), num_envs=n, device=0, config_kw=copy.deepcopy(ckw), sim_config_kw=copy.deepcopy(skw), seed=11,
+                          derived_views=derived, specialize=False)
+    want = [e[0] for e in presets.SPECIALISED].index(name)
+    assert vec.spec_index == nat.INSTANCE_SHAPE + want, (name, vec.spec_index)
+    res = cr.steady_state_sampled(vec, cfg, ckw, skw, 11, window=200, sample=192, parts=0 if regime == "lockstep" else None,
+                                  what="{} shape instance, fail-prone, {} envs, {}".format(name, n, regime))
+    print(name, regime, res, "{:.0f} s".format(time.time() - t0))
+    assert res["failure_ends"] >= 1000 and res["time_limit_ends"] >= 1000 and res["sampled_ends"] >= 200, res
+    vec.close()
