@@ -72,6 +72,45 @@ def draw_case(rng):
     return {"kind": kind, "cfg": cfg, "ckw": ckw, "skw": skw, "lean": lean, "want_log": want_log, "order": order}
 
 
+def draw_case_v2(rng):
+    """Seeds >= 100: a wider feature space (the draws of the seeds below 100 stay what they were, PINNED refers to them) --
+    + linear / sinusoidal targets, the mixed reward (quadratic / exponential classes, success and goal factors), integrator
+    observations + int_error reward, sampled simulator keys, randomised reward scalings, normalised observations."""
+    kind = str(rng.choice(["default", "examples", "mlp", "cnn", "dynamic_targets", "reward_mix", "integrator", "sim_keys",
+                           "reward_random_scaling", "model_uniform"]))
+    cfg = configs.reference_like(kind)
+    ckw = {"steps_max": int(rng.integers(7, 61))}
+    if kind == "cnn":
+        ckw["observation"] = {"step": int(rng.choice([1, 2, 3]))}
+    elif kind == "integrator" and rng.uniform() < 0.5:
+        ckw["observation"] = {"length": int(rng.choice([2, 3])), "shape": "matrix", "step": int(rng.choice([1, 2]))}
+    elif rng.uniform() < 0.25:
+        ckw["observation"] = {"normalize": True}
+    skw = None
+    turb = "increment" if kind == "sim_keys" else str(rng.choice(["off", "increment", "filter"]))
+    if turb != "off":
+        skw = {"turbulence": True, "turbulence_intensity": str(rng.choice(["light", "moderate", "severe"]))}
+        if turb == "filter" or (kind == "sim_keys" and rng.uniform() < 0.5):
+            skw["turbulence_output"] = "filter"
+    if rng.uniform() < 0.6:
+        lim = float(rng.integers(40, 90))
+        ckw["simulator"] = {"states": {6: {"constraint_min": -lim, "constraint_max": lim}}}
+    on_success = str(rng.choice(["none", "none", "done", "new"]))
+    tgt = {"on_success": on_success}
+    if kind != "reward_mix" and (on_success != "none" or rng.uniform() < 0.3):
+        tgt.update({"success_streak_req": int(rng.integers(5, 13)), "success_streak_fraction": float(rng.choice([0.5, 0.75, 0.9])),
+                    "states": {0: {"bound": 90}, 1: {"bound": 40}, 2: {"bound": 10}}})
+    if rng.uniform() < 0.35:
+        tgt["resample_every"] = int(rng.integers(9, 30))
+    ckw["target"] = tgt
+    if rng.uniform() < 0.4:
+        ckw["reward"] = {"form": "potential"}
+    lean = bool(rng.uniform() < 0.5)
+    want_log = bool(rng.uniform() < 0.6)
+    order = str(rng.choice(["0", "1", "r{}".format(int(rng.integers(1, 1000)))]))
+    return {"kind": kind, "cfg": cfg, "ckw": ckw, "skw": skw, "lean": lean, "want_log": want_log, "order": order}
+
+
 # draws of other seeds that FOUND something (kept in the default run): (seed, index) -- s7c4 / s8c1: the shipped cnn
 # configuration's observation (5 rows at step 1) on the row log, a step that fails on the log's wrap step: the oldest row of the
 # terminal observation was read one plane past the log (log_plane, csrc/fwgym_env.h), rounds 1-5
@@ -82,7 +121,11 @@ def _draws(seed, count):
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < count:
-        c = draw_case(rng)
+        c = draw_case(rng) if seed < 100 else draw_case_v2(rng)
+        try:   # (a drawn combination the configuration compiler refuses is redrawn)
+            EnvConfig(copy.deepcopy(c["cfg"]), config_kw=copy.deepcopy(c["ckw"]), sim_config_kw=copy.deepcopy(c["skw"])).compile()
+        except (NotImplementedError, ValueError, KeyError):
+            continue
         c["seed"], c["index"] = seed, len(out)
         c["id"] = "s{}c{}_{}_T{}_{}_{}".format(seed, len(out), c["kind"], c["ckw"]["steps_max"], "log" if c["want_log"] else "dense",
                                              "turb" if c["skw"] else "calm")
