@@ -98,7 +98,8 @@ class PPO(object):
         self.rollout = FusedRollout(vec, self.actor, self.n_steps, **self._rollout_kw)
         self._spec_at_capture = vec.spec_index
         on_gpu = self._torch_dev.type == "cuda"
-        self.opt = torch.optim.Adam(self.policy.parameters(), lr=hp["learning_rate"], eps=1e-5, capturable=on_gpu)
+        # (GPU: the fused, capturable form -- ONE launch for all thirteen parameter tensors inside the captured minibatch step)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=hp["learning_rate"], eps=1e-5, **({"capturable": True, "fused": True} if on_gpu else {}))
         self._graph_update, self._step_graph = bool(graph_update) and on_gpu, None
         self.curriculum = curriculum
         m, N, T = vec._mem, vec.num_envs, self.n_steps
@@ -156,8 +157,17 @@ class PPO(object):
         snap_p = [p.detach().clone() for p in self.policy.parameters()]
         snap_o = [{k: v.clone() for k, v in st.items() if isinstance(v, torch.Tensor)} for st in self.opt.state.values()]
 
+        # ONE gather per step: the six per-transition arrays side by side in a [n, D + 7] buffer, refreshed once per update
+        D = batch["obs"].shape[1]
+        g["packed"] = torch.empty((batch["obs"].shape[0], D + 7), device=dev)
+        g["pack"] = lambda: torch.cat([batch["obs"], batch["actions"], batch["values"][:, None], batch["logp"][:, None],
+                                       batch["adv"][:, None], batch["returns"][:, None]], dim=1, out=g["packed"])
+        g["pack"]()
+
         def body():
-            mbatch = {k: batch[k].index_select(0, g["idx"]) for k in batch}
+            m = g["packed"].index_select(0, g["idx"])
+            mbatch = {"obs": m[:, :D], "actions": m[:, D:D + 3], "values": m[:, D + 3], "logp": m[:, D + 4], "adv": m[:, D + 5],
+                      "returns": m[:, D + 6]}
             g["acc"].add_(self._minibatch_step(mbatch, cliprange))
 
         g["idx"].copy_(torch.arange(mb, device=dev))
@@ -196,6 +206,7 @@ class PPO(object):
             if self._step_graph is None or self._step_graph["key"] != key:
                 self._step_graph = self._capture_step(batch, mb, cliprange)
             sg = self._step_graph
+            sg["pack"]()
             sg["acc"].zero_()
         acc = torch.zeros(len(STAT_KEYS), device=self._torch_dev)
         for _ in range(int(hp["noptepochs"])):
