@@ -127,7 +127,7 @@ def steady_state_sampled(vec, cfg, ckw, skw, seed, window=300, parts=None, sampl
         k = min(k, sample - len(chosen))
         if k <= 0:
             return
-        cands = [int(c) for c in cands if int(c) not in set(chosen)]
+        cands = list(dict.fromkeys(int(c) for c in cands if int(c) not in set(chosen)))   # (no duplicates: an env checked twice would get its masked reset once)
         if len(cands) > k:
             cands = list(sel_rng.choice(cands, size=k, replace=False))
         chosen.extend(int(c) for c in cands)
@@ -143,6 +143,7 @@ def steady_state_sampled(vec, cfg, ckw, skw, seed, window=300, parts=None, sampl
     add(neigh, sample // 8)
     add(sel_rng.choice(N, size=min(N, 4 * sample), replace=False), sample - len(chosen))
     pos = np.array(sorted(chosen[:sample]))
+    assert len(set(pos.tolist())) == len(pos)
     # ---- the oracles: the same life by global env id
     T = g
     acts = np.stack([pool_h[t % pool_size][pos] for t in range(T)])
