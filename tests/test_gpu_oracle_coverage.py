@@ -148,7 +148,8 @@ def test_steady_state_of_65536_envs_sampled_against_oracles(variant, layout):
     vec.close()
 
 
-def test_shipped_cnn_configuration_failed_steps_on_the_log_s_wrap_step():
+@pytest.mark.parametrize("regime", ["staggered", "lockstep"])
+def test_shipped_cnn_configuration_failed_steps_on_the_log_s_wrap_step(regime):
     """The shipped cnn configuration (5 rows at step 1, row log) with a tight roll-rate constraint, on its shape instance: a step
     that fails on a wrap step of the row log (every 32nd global step) shows the record of five steps ago in its terminal
     observation's oldest row -- one further back than the four rows the wrap carries.  Rounds 1-5 read it one plane past the log
@@ -167,8 +168,8 @@ def test_shipped_cnn_configuration_failed_steps_on_the_log_s_wrap_step():
         rows = fail_ends[(g0 + w) % 32 == 0]
         return np.nonzero(rows.any(axis=0))[0]
 
-    res = cr.steady_state_sampled(vec, cfg, ckw, None, SEED, window=200, sample=256, first_pick=on_wrap,
-                                  what="shipped cnn configuration, fail-prone, {} envs".format(n))
+    res = cr.steady_state_sampled(vec, cfg, ckw, None, SEED, window=200, sample=256, first_pick=on_wrap, parts=0 if regime == "lockstep" else None,
+                                  what="shipped cnn configuration, fail-prone, {} envs, {}".format(n, regime))
     print("ship_cnn", res, "{:.0f} s".format(time.time() - t0))
     assert res["first_pick_checked"] >= 32 and res["failure_ends"] >= 10000, res
     vec.close()
